@@ -1,0 +1,149 @@
+/*
+ * include/kanpyo_gpu.h -- C ABI of libkanpyo_gpu.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE path of togatoga/kanpyo: Tokenizer::tokenize()
+ * (lattice build over the double-array trie + Viterbi over the connection
+ * matrix).  The reference has no FFI of its own (pure safe Rust); these are the
+ * entry points a Rust `kanpyo::Tokenizer` shim binds with `extern "C"` (the
+ * binding is shown in INTEGRATION.md).  Each entry point cites the reference
+ * interface it replaces; paths are relative to the reference checkout.
+ *
+ * Plain pointers and sizes only; no torch / HIP types in the signatures (a HIP
+ * stream crosses as void*).  All functions return KGPU_OK (0) or a KGPU_ERR_*
+ * code and never abort; kgpu_last_error() gives the thread-local message.
+ */
+#ifndef KANPYO_GPU_H
+#define KANPYO_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KGPU_OK 0
+#define KGPU_ERR_INVALID_ARG 1 /* null pointer, offsets not monotone, ...                */
+#define KGPU_ERR_BAD_DICT 2    /* truncated blob, or a dictionary on which the reference
+                                  itself would panic (index out of bounds)               */
+#define KGPU_ERR_HIP 3         /* HIP runtime error (message has the hipError string)    */
+#define KGPU_ERR_CAPACITY 4    /* caller's token buffer too small; *n_tokens = needed    */
+#define KGPU_ERR_NO_DEVICE 5   /* no usable gfx950 device / extension built without one  */
+#define KGPU_ERR_INTERNAL 6
+
+/* Per-sentence status (uint8). */
+#define KGPU_SENT_OK 0
+#define KGPU_SENT_INVALID_UTF8 1 /* Rust's &str cannot carry this; the C boundary checks
+                                    (reference src/tokenizer.rs:16 takes &str).  The
+                                    sentence yields zero tokens.                        */
+
+/* TokenClass (reference src/token.rs:3-8). */
+#define KGPU_CLASS_DUMMY 0
+#define KGPU_CLASS_KNOWN 1
+#define KGPU_CLASS_UNKNOWN 2
+
+/* Token (reference src/token.rs:10-18) as a fixed 24-byte record.  `surface`
+ * is not materialised: it is input[position .. position + byte_len] of the
+ * sentence, or the literal "EOS" when cls == KGPU_CLASS_DUMMY (byte_len == 0,
+ * end == start + 3 because "EOS".chars().count() == 3, src/tokenizer.rs:28,34). */
+typedef struct kgpu_token {
+    int32_t id;        /* Token.id (KeywordID; 0 for the EOS dummy)      */
+    uint32_t cls;      /* Token.class                                     */
+    uint32_t position; /* Token.position: byte offset inside the sentence */
+    uint32_t start;    /* Token.start: char index                         */
+    uint32_t end;      /* Token.end: char index                           */
+    uint32_t byte_len; /* surface length in bytes                         */
+} kgpu_token;
+
+/* The dictionary tables exactly as the reference serialises them
+ * (DictReadWrite::write_dict, kanpyo-dict/src/dict.rs:13-18): the hot-path
+ * table internals are private in the reference (trie/da.rs:14-20,
+ * index.rs:10-13, connection.rs:5-9, morph.rs:24), write_dict is their only
+ * public egress, so the shim hands over those bytes.
+ *   index_dict      index.rs:75-84 + trie/da.rs:237-245
+ *   connection_dict connection.rs:44-51
+ *   morph_dict      morph.rs:61-72
+ *   unk_dict        unk_dict.rs:60-73 (the trailing feature table is ignored)
+ *   char_category / invoke_list / group_list: the pub Vec<u8>/Vec<bool> fields
+ *                   of CharCategoryDef (char_category_def.rs:14-20), one byte each */
+typedef struct kgpu_dict_blobs {
+    const uint8_t *index_dict;      size_t index_len;
+    const uint8_t *connection_dict; size_t connection_len;
+    const uint8_t *morph_dict;      size_t morph_len;
+    const uint8_t *unk_dict;        size_t unk_len;
+    const uint8_t *char_category;   size_t char_category_len;
+    const uint8_t *invoke_list;     size_t invoke_len;
+    const uint8_t *group_list;      size_t group_len;
+} kgpu_dict_blobs;
+
+typedef struct kgpu_dict kgpu_dict; /* owns the HBM-resident tables           */
+typedef struct kgpu_ctx kgpu_ctx;   /* one stream + scratch; one per thread   */
+
+typedef struct kgpu_dict_info {
+    uint64_t da_len;        /* double-array nodes (8 B each)                   */
+    uint64_t n_morphs;      /* known morphs                                    */
+    uint64_t n_unk_morphs;  /* unknown morphs                                  */
+    uint64_t conn_rows;     /* right-id dimension                              */
+    uint64_t conn_cols;     /* left-id dimension                               */
+    uint64_t device_bytes;  /* HBM held by the dictionary                      */
+    int32_t device;         /* HIP device ordinal                              */
+    int32_t reserved;
+} kgpu_dict_info;
+
+/* Per-launch timing of the dominant kernel, collected with HIP events on the
+ * ctx stream (bench.py roofline leg). */
+typedef struct kgpu_profile {
+    uint64_t launches;     /* tokenize kernel launches timed                  */
+    double tokenize_ms;    /* sum of the fused lattice+Viterbi kernel durations */
+    double aux_ms;         /* sum of scan + compaction kernel durations         */
+} kgpu_profile;
+
+const char *kgpu_last_error(void);
+int kgpu_device_count(void);
+
+/* Tokenizer::new(dict) (src/tokenizer.rs:12-14): parse + validate the blobs,
+ * upload once to HBM of `device`.  A dictionary on which the reference would
+ * panic at tokenize time (morph id / connection index / invoke_list index out
+ * of bounds: src/lattice.rs:54,182,195, connection.rs:13) is rejected here with
+ * KGPU_ERR_BAD_DICT instead. */
+int kgpu_dict_create(const kgpu_dict_blobs *blobs, int device, kgpu_dict **out);
+void kgpu_dict_destroy(kgpu_dict *d);
+int kgpu_dict_get_info(const kgpu_dict *d, kgpu_dict_info *out);
+
+/* Tokenizer::tokenize(&self, &str) -> Vec<Token> (src/tokenizer.rs:16-45) for a
+ * batch of n sentences in host memory: sentence i is
+ * utf8[offsets[i] .. offsets[i+1]) (offsets has n+1 entries).  Tokens are
+ * written densely in sentence order; tok_offsets (n+1 entries) delimits each
+ * sentence's Vec<Token>.  A sentence whose EOS is unreachable yields zero
+ * tokens, as in the reference (src/lattice.rs:144-153).  status may be NULL.
+ * Thread-safe per dict (&self, src/tokenizer.rs:16): each call checks a ctx
+ * out of an internal pool.  token_capacity >= total_chars + n always suffices. */
+int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
+                        kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets,
+                        uint8_t *status, uint64_t *n_tokens);
+
+/* Device-resident form (inputs already in HBM, outputs left in HBM, e.g. for
+ * the RCCL gather).  All d_* pointers are device pointers on the dict's
+ * device.  kgpu_tokenize_device only enqueues on the ctx stream;
+ * kgpu_ctx_sync waits and reports the dense token count (or KGPU_ERR_CAPACITY). */
+int kgpu_ctx_create(kgpu_dict *d, void *hip_stream /* NULL: ctx-owned stream */, kgpu_ctx **out);
+void kgpu_ctx_destroy(kgpu_ctx *c);
+int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n,
+                         uint64_t total_bytes, kgpu_token *d_tokens, uint64_t token_capacity,
+                         uint64_t *d_tok_offsets, uint8_t *d_status);
+int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens);
+int kgpu_ctx_set_profiling(kgpu_ctx *c, int enabled);
+int kgpu_ctx_get_profile(kgpu_ctx *c, kgpu_profile *out, int reset);
+
+/* IndexTable::build + write_dict (kanpyo-dict/src/index.rs:16-38,75-84 over
+ * trie/da.rs:22-131,191-217): sorted keywords (duplicates adjacent) -> the
+ * index.dict blob, byte-identical to the reference's first-fit packing.  Host
+ * only.  Free the blob with kgpu_free. */
+int kgpu_index_build(const uint8_t *keys, const uint64_t *key_offsets, uint64_t n,
+                     uint8_t **blob, size_t *blob_len);
+void kgpu_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

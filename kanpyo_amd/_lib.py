@@ -1,0 +1,91 @@
+"""ctypes binding of libkanpyo_gpu.so (include/kanpyo_gpu.h).  Fails loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkanpyo_gpu.so")
+
+KGPU_OK = 0
+KGPU_ERR_INVALID_ARG = 1
+KGPU_ERR_BAD_DICT = 2
+KGPU_ERR_HIP = 3
+KGPU_ERR_CAPACITY = 4
+KGPU_ERR_NO_DEVICE = 5
+KGPU_ERR_INTERNAL = 6
+KGPU_SENT_OK = 0
+KGPU_SENT_INVALID_UTF8 = 1
+
+# every symbol include/kanpyo_gpu.h declares
+SYMBOLS = [
+    "kgpu_last_error", "kgpu_device_count", "kgpu_dict_create", "kgpu_dict_destroy", "kgpu_dict_get_info",
+    "kgpu_tokenize_batch", "kgpu_ctx_create", "kgpu_ctx_destroy", "kgpu_tokenize_device", "kgpu_ctx_sync",
+    "kgpu_ctx_set_profiling", "kgpu_ctx_get_profile", "kgpu_index_build", "kgpu_free",
+]
+
+
+class KgpuError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"kgpu error {code}: {msg}")
+        self.code = code
+
+
+class DictBlobs(C.Structure):
+    _fields_ = [
+        (n, t)
+        for name in ("index", "connection", "morph", "unk", "char_category", "invoke", "group")
+        for n, t in ((name + "_p", C.c_void_p), (name + "_len", C.c_size_t))
+    ]
+
+
+class DictInfo(C.Structure):
+    _fields_ = [
+        ("da_len", C.c_uint64), ("n_morphs", C.c_uint64), ("n_unk_morphs", C.c_uint64), ("conn_rows", C.c_uint64),
+        ("conn_cols", C.c_uint64), ("device_bytes", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class Profile(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("tokenize_ms", C.c_double), ("aux_ms", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the in-tree HIP extension; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C kanpyo_amd/csrc). "
+                "kanpyo_amd has no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.kgpu_last_error.restype = C.c_char_p
+        L.kgpu_device_count.restype = C.c_int
+        L.kgpu_dict_create.argtypes = [C.POINTER(DictBlobs), C.c_int, C.POINTER(vp)]
+        L.kgpu_dict_destroy.argtypes = [vp]
+        L.kgpu_dict_destroy.restype = None
+        L.kgpu_dict_get_info.argtypes = [vp, C.POINTER(DictInfo)]
+        L.kgpu_tokenize_batch.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, C.POINTER(C.c_uint64)]
+        L.kgpu_ctx_create.argtypes = [vp, vp, C.POINTER(vp)]
+        L.kgpu_ctx_destroy.argtypes = [vp]
+        L.kgpu_ctx_destroy.restype = None
+        L.kgpu_tokenize_device.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, vp]
+        L.kgpu_ctx_sync.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.kgpu_ctx_set_profiling.argtypes = [vp, C.c_int]
+        L.kgpu_ctx_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
+        L.kgpu_index_build.argtypes = [vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.kgpu_free.argtypes = [vp]
+        L.kgpu_free.restype = None
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != KGPU_OK:
+        raise KgpuError(rc, lib().kgpu_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,496 @@
+// kanpyo_amd/csrc/kgpu_api.cpp -- host runtime behind include/kanpyo_gpu.h.
+//
+// Owns: blob parsing + validation (the panics of the reference's hot path are
+// turned into KGPU_ERR_BAD_DICT at create time), the one-time dictionary upload
+// to HBM, per-ctx stream / scratch arena / staging, the launch sequence
+// (tokenize -> scan -> compact) and the host-buffer convenience entry point.
+// There is NO CPU fallback: without a HIP device every entry point that would
+// compute returns KGPU_ERR_NO_DEVICE.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "kgpu_internal.h"
+
+namespace kgpu {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace kgpu
+
+using namespace kgpu;
+
+#define HIPCHECK(expr)                                                                  \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return KGPU_ERR_HIP;                                                        \
+        }                                                                               \
+    } while (0)
+
+namespace {
+
+struct Reader {
+    const uint8_t *p; size_t n, at = 0; bool bad = false;
+    Reader(const uint8_t *p_, size_t n_) : p(p_), n(n_) {}
+    template <class T> T get() {
+        T v{};
+        if (at + sizeof(T) > n) { bad = true; return v; }
+        std::memcpy(&v, p + at, sizeof(T));
+        at += sizeof(T);
+        return v;
+    }
+    size_t left() const { return n - at; }
+};
+
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return KGPU_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        size_t want = need + need / 4 + 256;
+        HIPCHECK(hipMalloc(&p, want));
+        bytes = want;
+        return KGPU_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+}  // namespace
+
+struct kgpu_dict {
+    int device = 0;
+    DictView view{};
+    kgpu_dict_info info{};
+    std::vector<void *> allocs;
+    std::mutex pool_mu;
+    std::vector<kgpu_ctx *> pool;
+};
+
+struct kgpu_ctx {
+    kgpu_dict *dict = nullptr;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    Control *d_ctl = nullptr;
+    Control *h_ctl = nullptr;  // pinned
+    DevBuf arena, stage, tok_start, tok_count;
+    // host-buffer path staging
+    DevBuf in_utf8, in_off, out_tok, out_off, out_status;
+    // last enqueued batch (for the arena-overflow retry and for sync)
+    BatchArgs last{};
+    bool pending = false;
+    int n_wg_max = 2048;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    kgpu_profile prof{};
+};
+
+extern "C" const char *kgpu_last_error(void) { return g_err; }
+
+extern "C" int kgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------- dictionary
+
+template <class T>
+static int upload(kgpu_dict *d, const std::vector<T> &h, const T **out) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(h.size() * sizeof(T), 16);
+    HIPCHECK(hipMalloc(&p, bytes));
+    d->allocs.push_back(p);
+    if (!h.empty()) HIPCHECK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    d->info.device_bytes += bytes;
+    *out = (const T *)p;
+    return KGPU_OK;
+}
+
+static int parse_morphs(Reader &r, std::vector<Morph8> &out, const char *what) {
+    int64_t n = r.get<int64_t>();  // morph.rs:74-78
+    if (r.bad || n < 0 || (uint64_t)n > r.left() / 6) { set_error("%s: truncated morph block", what); return KGPU_ERR_BAD_DICT; }
+    out.resize((size_t)n);
+    for (auto &m : out) { m.left = r.get<int16_t>(); m.right = r.get<int16_t>(); m.cost = r.get<int16_t>(); m.dup = 0; }
+    return KGPU_OK;
+}
+
+extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict **out) {
+    if (!b || !out) { set_error("kgpu_dict_create: null argument"); return KGPU_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (!b->index_dict || !b->connection_dict || !b->morph_dict || !b->unk_dict || !b->char_category ||
+        (!b->invoke_list && b->invoke_len) || (!b->group_list && b->group_len)) {
+        set_error("kgpu_dict_create: null blob");
+        return KGPU_ERR_INVALID_ARG;
+    }
+    // ---- parse (layouts: SURVEY.md App. B) ----
+    std::vector<DaNode> da;
+    std::vector<std::pair<int64_t, uint64_t>> dup;
+    {
+        Reader r(b->index_dict, b->index_len);  // trie/da.rs:220-236, index.rs:57-73
+        uint64_t n = r.get<uint64_t>();
+        if (r.bad || n > r.left() / 8 || n >= (1ull << 31)) { set_error("index.dict: bad double-array length"); return KGPU_ERR_BAD_DICT; }
+        da.resize((size_t)n);
+        if (n) { std::memcpy(da.data(), r.p + r.at, (size_t)n * 8); r.at += (size_t)n * 8; }
+        uint64_t m = r.get<uint64_t>();
+        if (r.bad || m > r.left() / 16) { set_error("index.dict: bad duplicate map"); return KGPU_ERR_BAD_DICT; }
+        dup.resize((size_t)m);
+        for (auto &kv : dup) { kv.first = r.get<int64_t>(); kv.second = r.get<uint64_t>(); }
+    }
+    // DoubleArray::search_common_prefix_of indexes self.0[1] unconditionally
+    // (da.rs:156,161) and panics on a 1-element array (empty keyword list);
+    // here such a trie simply matches nothing.
+    while (da.size() < 2) da.push_back(DaNode{0, 0});
+
+    uint64_t rows, cols;
+    std::vector<int16_t> conn;
+    {
+        Reader r(b->connection_dict, b->connection_len);  // connection.rs:28-42
+        rows = r.get<uint64_t>(); cols = r.get<uint64_t>();
+        if (r.bad || rows >= (1ull << 31) || cols >= (1ull << 31) || (rows && cols > r.left() / 2 / rows)) {
+            set_error("connection.dict: truncated"); return KGPU_ERR_BAD_DICT;
+        }
+        if (rows * cols >= (1ull << 32)) { set_error("connection.dict: matrix too large"); return KGPU_ERR_BAD_DICT; }
+        conn.resize((size_t)(rows * cols));
+        if (!conn.empty()) std::memcpy(conn.data(), r.p + r.at, conn.size() * 2);
+    }
+    std::vector<Morph8> morphs, unk_morphs;
+    {
+        Reader r(b->morph_dict, b->morph_len);
+        int rc = parse_morphs(r, morphs, "morph.dict");
+        if (rc) return rc;
+    }
+    std::vector<CatInfo> cinfo(256, CatInfo{0, 0, 0, 0});
+    {
+        Reader r(b->unk_dict, b->unk_len);  // unk_dict.rs:75-99
+        uint64_t k = r.get<uint64_t>();
+        if (r.bad || k > r.left() / 17) { set_error("unk.dict: truncated"); return KGPU_ERR_BAD_DICT; }
+        struct E { uint8_t cat; int64_t first; uint64_t count; };
+        std::vector<E> ents((size_t)k);
+        for (auto &e : ents) { e.cat = r.get<uint8_t>(); e.first = r.get<int64_t>(); e.count = r.get<uint64_t>(); }
+        int rc = parse_morphs(r, unk_morphs, "unk.dict");
+        if (rc) return rc;
+        for (auto &e : ents) {
+            // lattice.rs:195 unk_dict.morphs[id - 1] must be in bounds for every id the entry yields
+            if (e.count && (e.first < 1 || (uint64_t)e.first - 1 + e.count > unk_morphs.size())) {
+                set_error("unk.dict: category %u maps to morph ids %lld..+%llu outside 1..%zu (reference would panic, lattice.rs:195)",
+                          e.cat, (long long)e.first, (unsigned long long)e.count, unk_morphs.size());
+                return KGPU_ERR_BAD_DICT;
+            }
+            cinfo[e.cat].flags |= CAT_HAS_UNK;
+            cinfo[e.cat].unk_first = (int32_t)e.first;
+            cinfo[e.cat].unk_count = (uint32_t)e.count;
+        }
+    }
+    if (b->char_category_len == 0) { set_error("char_category: empty table (reference would panic, char_category_def.rs:37)"); return KGPU_ERR_BAD_DICT; }
+    for (size_t i = 0; i < b->invoke_len && i < 256; ++i) if (b->invoke_list[i]) cinfo[i].flags |= CAT_INVOKE;
+    for (size_t i = 0; i < b->group_len && i < 256; ++i) if (b->group_list[i]) cinfo[i].flags |= CAT_GROUP;
+    {
+        bool seen[256] = {false};
+        for (size_t i = 0; i < b->char_category_len; ++i) seen[b->char_category[i]] = true;
+        for (int c = 0; c < 256; ++c)
+            if (seen[c] && (size_t)c >= b->invoke_len) {
+                set_error("char_category: category %d has no invoke_list entry (reference would panic, lattice.rs:54)", c);
+                return KGPU_ERR_BAD_DICT;
+            }
+    }
+    // duplicate counts ride in the first record's padding
+    for (auto &kv : dup) {
+        if (kv.first < 1 || (uint64_t)kv.first > morphs.size() || kv.second > 65535 ||
+            (uint64_t)kv.first + kv.second > morphs.size()) {
+            set_error("index.dict: duplicate entry (%lld,+%llu) outside 1..%zu morphs", (long long)kv.first,
+                      (unsigned long long)kv.second, morphs.size());
+            return KGPU_ERR_BAD_DICT;
+        }
+        morphs[(size_t)kv.first - 1].dup = (uint16_t)kv.second;
+    }
+    // every leaf id (and its duplicates) must index morphs (lattice.rs:182)
+    for (size_t a = 0; a < da.size(); ++a) {
+        const DaNode &nd = da[a];
+        if (nd.base < 0 && nd.check > 0 && (size_t)nd.check < da.size() && da[(size_t)nd.check].base == (int32_t)a) {
+            int64_t id = -(int64_t)nd.base;
+            if (id > (int64_t)morphs.size()) {
+                set_error("index.dict: keyword id %lld has no morph (reference would panic, lattice.rs:182)", (long long)id);
+                return KGPU_ERR_BAD_DICT;
+            }
+        }
+    }
+    // ConnectionTable::get(right, left) = data[rows*left + right] (connection.rs:12-14):
+    // every (right, left) combination of the dictionary must stay in bounds.
+    {
+        int64_t max_l = 0, max_r = 0;
+        auto scan = [&](const std::vector<Morph8> &v) {
+            for (auto &m : v) {
+                if (m.left < 0 || m.right < 0) return false;
+                max_l = std::max<int64_t>(max_l, m.left); max_r = std::max<int64_t>(max_r, m.right);
+            }
+            return true;
+        };
+        if (!scan(morphs) || !scan(unk_morphs)) { set_error("morph: negative context id (reference would panic, connection.rs:13)"); return KGPU_ERR_BAD_DICT; }
+        if ((uint64_t)max_l * rows + (uint64_t)max_r >= conn.size()) {
+            set_error("connection.dict: %llux%llu matrix does not cover left_id %lld / right_id %lld (reference would panic, connection.rs:13)",
+                      (unsigned long long)rows, (unsigned long long)cols, (long long)max_l, (long long)max_r);
+            return KGPU_ERR_BAD_DICT;
+        }
+    }
+
+    // ---- upload once to HBM ----
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("kgpu_dict_create: no HIP device (the HIP path has no CPU fallback)");
+        return KGPU_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { set_error("kgpu_dict_create: device %d out of range (0..%d)", device, ndev - 1); return KGPU_ERR_INVALID_ARG; }
+    HIPCHECK(hipSetDevice(device));
+    kgpu_dict *d = new kgpu_dict();
+    d->device = device;
+    std::vector<uint8_t> cat(b->char_category, b->char_category + b->char_category_len);
+    int rc;
+    if ((rc = upload(d, da, &d->view.da)) || (rc = upload(d, morphs, &d->view.morph)) ||
+        (rc = upload(d, unk_morphs, &d->view.unk_morph)) || (rc = upload(d, conn, &d->view.conn)) ||
+        (rc = upload(d, cat, &d->view.cat)) || (rc = upload(d, cinfo, &d->view.cinfo))) {
+        kgpu_dict_destroy(d);
+        return rc;
+    }
+    d->view.da_len = (uint32_t)da.size();
+    d->view.n_morph = (uint32_t)morphs.size();
+    d->view.n_unk_morph = (uint32_t)unk_morphs.size();
+    d->view.conn_rows = (uint32_t)rows;
+    d->view.cat_len = (uint32_t)std::min<size_t>(cat.size(), 0x110000);
+    d->info.da_len = da.size(); d->info.n_morphs = morphs.size(); d->info.n_unk_morphs = unk_morphs.size();
+    d->info.conn_rows = rows; d->info.conn_cols = cols; d->info.device = device;
+    *out = d;
+    return KGPU_OK;
+}
+
+extern "C" void kgpu_dict_destroy(kgpu_dict *d) {
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    for (auto *c : d->pool) kgpu_ctx_destroy(c);
+    d->pool.clear();
+    for (void *p : d->allocs) (void)hipFree(p);
+    delete d;
+}
+
+extern "C" int kgpu_dict_get_info(const kgpu_dict *d, kgpu_dict_info *out) {
+    if (!d || !out) { set_error("kgpu_dict_get_info: null argument"); return KGPU_ERR_INVALID_ARG; }
+    *out = d->info;
+    return KGPU_OK;
+}
+
+// ----------------------------------------------------------------------- ctx
+
+static constexpr size_t ARENA_INITIAL = 1ull << 31;  // 2 GiB of the 288 GB
+static constexpr size_t ARENA_MAX = 1ull << 37;      // 128 GiB
+
+extern "C" int kgpu_ctx_create(kgpu_dict *d, void *hip_stream, kgpu_ctx **out) {
+    if (!d || !out) { set_error("kgpu_ctx_create: null argument"); return KGPU_ERR_INVALID_ARG; }
+    *out = nullptr;
+    HIPCHECK(hipSetDevice(d->device));
+    kgpu_ctx *c = new kgpu_ctx();
+    c->dict = d;
+    if (hip_stream) c->stream = (hipStream_t)hip_stream;
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete c; return KGPU_ERR_HIP; }
+        c->own_stream = true;
+    }
+    if (hipMalloc((void **)&c->d_ctl, sizeof(Control)) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_ctl, sizeof(Control), hipHostMallocDefault) != hipSuccess) {
+        set_error("kgpu_ctx_create: control block allocation failed");
+        kgpu_ctx_destroy(c);
+        return KGPU_ERR_HIP;
+    }
+    c->n_wg_max = tokenize_max_workgroups(d->device);
+    *out = c;
+    return KGPU_OK;
+}
+
+extern "C" void kgpu_ctx_destroy(kgpu_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->dict->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    c->arena.release(); c->stage.release(); c->tok_start.release(); c->tok_count.release();
+    c->in_utf8.release(); c->in_off.release(); c->out_tok.release(); c->out_off.release(); c->out_status.release();
+    if (c->d_ctl) (void)hipFree(c->d_ctl);
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int next_event(kgpu_ctx *c, hipEvent_t *ev) {
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e;
+        HIPCHECK(hipEventCreate(&e));
+        c->ev_pool.push_back(e);
+    }
+    *ev = c->ev_pool[c->ev_used++];
+    return KGPU_OK;
+}
+
+static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
+    HIPCHECK(hipMemsetAsync(c->d_ctl, 0, sizeof(Control), c->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    int rc;
+    if (c->profiling) {
+        if ((rc = next_event(c, &e0)) || (rc = next_event(c, &e1)) || (rc = next_event(c, &e2))) return rc;
+        HIPCHECK(hipEventRecord(e0, c->stream));
+    }
+    if (a.n) {
+        uint64_t wg = std::min<uint64_t>(a.n, (uint64_t)c->n_wg_max);
+        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, (int)wg, c->stream);
+        if (e != hipSuccess) { set_error("k_tokenize launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    }
+    if (c->profiling) HIPCHECK(hipEventRecord(e1, c->stream));
+    {
+        hipError_t e = (hipError_t)launch_scan_compact(a, c->stream);
+        if (e != hipSuccess) { set_error("scan/compact launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    }
+    if (c->profiling) HIPCHECK(hipEventRecord(e2, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->h_ctl, c->d_ctl, sizeof(Control), hipMemcpyDeviceToHost, c->stream));
+    c->last = a;
+    c->pending = true;
+    return KGPU_OK;
+}
+
+extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n,
+                                    uint64_t total_bytes, kgpu_token *d_tokens, uint64_t token_capacity,
+                                    uint64_t *d_tok_offsets, uint8_t *d_status) {
+    if (!c || !d_offsets || !d_tok_offsets || (n && !d_status) || (total_bytes && !d_utf8) ||
+        (token_capacity && !d_tokens)) {
+        set_error("kgpu_tokenize_device: null argument");
+        return KGPU_ERR_INVALID_ARG;
+    }
+    if (total_bytes >= (1ull << 32)) { set_error("kgpu_tokenize_device: batch larger than 4 GiB; split it"); return KGPU_ERR_INVALID_ARG; }
+    HIPCHECK(hipSetDevice(c->dict->device));
+    int rc;
+    if (c->pending && (rc = kgpu_ctx_sync(c, nullptr)) != KGPU_OK && rc != KGPU_ERR_CAPACITY) return rc;
+    if ((rc = c->arena.ensure(ARENA_INITIAL)) || (rc = c->stage.ensure((size_t)token_capacity * sizeof(kgpu_token) + 64)) ||
+        (rc = c->tok_start.ensure((size_t)(n + 1) * 8)) || (rc = c->tok_count.ensure((size_t)(n + 1) * 4)))
+        return rc;
+    BatchArgs a{};
+    a.utf8 = d_utf8; a.offsets = d_offsets; a.n = n; a.ctl = c->d_ctl;
+    a.arena = (uint8_t *)c->arena.p; a.arena_bytes = c->arena.bytes;
+    a.stage = (kgpu_token *)c->stage.p; a.stage_cap = token_capacity;
+    a.tok_start = (uint64_t *)c->tok_start.p; a.tok_count = (uint32_t *)c->tok_count.p;
+    a.status = d_status; a.out = d_tokens; a.out_cap = token_capacity; a.tok_offsets = d_tok_offsets;
+    return enqueue(c, a);
+}
+
+extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
+    if (!c) { set_error("kgpu_ctx_sync: null ctx"); return KGPU_ERR_INVALID_ARG; }
+    HIPCHECK(hipSetDevice(c->dict->device));
+    for (;;) {
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        if (!c->pending) { if (n_tokens) *n_tokens = 0; return KGPU_OK; }
+        if (c->h_ctl->arena_overflow) {
+            // a lattice did not fit the scratch arena: grow it and redo the batch
+            size_t want = c->arena.bytes * 2;
+            if (want > ARENA_MAX) { set_error("scratch arena exceeded %zu bytes", ARENA_MAX); c->pending = false; return KGPU_ERR_INTERNAL; }
+            int rc = c->arena.ensure(want);
+            if (rc) { c->pending = false; return rc; }
+            BatchArgs a = c->last;
+            a.arena = (uint8_t *)c->arena.p; a.arena_bytes = c->arena.bytes;
+            if ((rc = enqueue(c, a))) { c->pending = false; return rc; }
+            continue;
+        }
+        break;
+    }
+    c->pending = false;
+    if (c->profiling) {
+        for (size_t i = 0; i + 3 <= c->ev_used; i += 3) {
+            float t01 = 0, t12 = 0;
+            if (hipEventElapsedTime(&t01, c->ev_pool[i], c->ev_pool[i + 1]) == hipSuccess &&
+                hipEventElapsedTime(&t12, c->ev_pool[i + 1], c->ev_pool[i + 2]) == hipSuccess) {
+                c->prof.launches++; c->prof.tokenize_ms += t01; c->prof.aux_ms += t12;
+            }
+        }
+        c->ev_used = 0;
+    }
+    uint64_t need = c->h_ctl->tok_overflow ? c->h_ctl->tok_cursor : c->h_ctl->n_tokens;
+    if (n_tokens) *n_tokens = need;
+    if (c->h_ctl->tok_overflow || c->h_ctl->n_tokens > c->last.out_cap) {
+        set_error("token buffer too small: need %llu, capacity %llu", (unsigned long long)need, (unsigned long long)c->last.out_cap);
+        return KGPU_ERR_CAPACITY;
+    }
+    return KGPU_OK;
+}
+
+extern "C" int kgpu_ctx_set_profiling(kgpu_ctx *c, int enabled) {
+    if (!c) { set_error("kgpu_ctx_set_profiling: null ctx"); return KGPU_ERR_INVALID_ARG; }
+    c->profiling = enabled != 0;
+    return KGPU_OK;
+}
+
+extern "C" int kgpu_ctx_get_profile(kgpu_ctx *c, kgpu_profile *out, int reset) {
+    if (!c || !out) { set_error("kgpu_ctx_get_profile: null argument"); return KGPU_ERR_INVALID_ARG; }
+    *out = c->prof;
+    if (reset) c->prof = kgpu_profile{};
+    return KGPU_OK;
+}
+
+// ------------------------------------------------------- host-buffer entry point
+
+extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
+                                   kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets,
+                                   uint8_t *status, uint64_t *n_tokens) {
+    if (!d || !offsets || !tok_offsets || (token_capacity && !tokens)) {
+        set_error("kgpu_tokenize_batch: null argument");
+        return KGPU_ERR_INVALID_ARG;
+    }
+    for (uint64_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i]) { set_error("kgpu_tokenize_batch: offsets not monotone at %llu", (unsigned long long)i); return KGPU_ERR_INVALID_ARG; }
+    const uint64_t base = offsets[0], total = offsets[n] - base;
+    if (total && !utf8) { set_error("kgpu_tokenize_batch: null utf8"); return KGPU_ERR_INVALID_ARG; }
+    HIPCHECK(hipSetDevice(d->device));
+
+    kgpu_ctx *c = nullptr;
+    {
+        std::lock_guard<std::mutex> g(d->pool_mu);
+        if (!d->pool.empty()) { c = d->pool.back(); d->pool.pop_back(); }
+    }
+    int rc = KGPU_OK;
+    if (!c && (rc = kgpu_ctx_create(d, nullptr, &c))) return rc;
+    auto give_back = [&]() { std::lock_guard<std::mutex> g(d->pool_mu); d->pool.push_back(c); };
+
+    std::vector<uint64_t> rel((size_t)n + 1);
+    for (uint64_t i = 0; i <= n; ++i) rel[(size_t)i] = offsets[i] - base;
+    uint64_t got = 0;
+    do {
+        if ((rc = c->in_utf8.ensure((size_t)total + 16)) || (rc = c->in_off.ensure((size_t)(n + 1) * 8)) ||
+            (rc = c->out_tok.ensure((size_t)token_capacity * sizeof(kgpu_token) + 64)) ||
+            (rc = c->out_off.ensure((size_t)(n + 1) * 8)) || (rc = c->out_status.ensure((size_t)n + 16)))
+            break;
+        hipError_t e;
+        if (total && (e = hipMemcpyAsync(c->in_utf8.p, utf8 + base, (size_t)total, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { set_error("H2D utf8: %s", hipGetErrorString(e)); rc = KGPU_ERR_HIP; break; }
+        if ((e = hipMemcpyAsync(c->in_off.p, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { set_error("H2D offsets: %s", hipGetErrorString(e)); rc = KGPU_ERR_HIP; break; }
+        // rel must stay alive until the copy is done: the sync below covers it
+        if ((rc = kgpu_tokenize_device(c, (const uint8_t *)c->in_utf8.p, (const uint64_t *)c->in_off.p, n, total,
+                                       (kgpu_token *)c->out_tok.p, token_capacity, (uint64_t *)c->out_off.p,
+                                       (uint8_t *)c->out_status.p)))
+            break;
+        rc = kgpu_ctx_sync(c, &got);
+        if (n_tokens) *n_tokens = got;
+        if (rc) break;
+        if (got && (e = hipMemcpy(tokens, c->out_tok.p, (size_t)got * sizeof(kgpu_token), hipMemcpyDeviceToHost)) != hipSuccess) { set_error("D2H tokens: %s", hipGetErrorString(e)); rc = KGPU_ERR_HIP; break; }
+        if ((e = hipMemcpy(tok_offsets, c->out_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost)) != hipSuccess) { set_error("D2H offsets: %s", hipGetErrorString(e)); rc = KGPU_ERR_HIP; break; }
+        if (status && n && (e = hipMemcpy(status, c->out_status.p, (size_t)n, hipMemcpyDeviceToHost)) != hipSuccess) { set_error("D2H status: %s", hipGetErrorString(e)); rc = KGPU_ERR_HIP; break; }
+    } while (0);
+    give_back();
+    return rc;
+}

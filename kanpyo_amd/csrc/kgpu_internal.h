@@ -1,0 +1,71 @@
+// kanpyo_amd/csrc/kgpu_internal.h -- shared between the host runtime
+// (kgpu_api.cpp, kgpu_index_build.cpp) and the HIP kernels (kgpu_kernels.hip)
+// of libkanpyo_gpu.so.  Not part of the public ABI.  Plain structs only, so it
+// compiles as host C++ and as HIP.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/kanpyo_gpu.h"
+
+namespace kgpu {
+
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+// ---- HBM-resident dictionary (uploaded once by kgpu_dict_create) ----------
+struct alignas(8) DaNode {  // trie/da.rs:13-17: one {base, check} pair = one 64-bit load
+    int32_t base, check;
+};
+struct alignas(8) Morph8 {  // morph.rs:7-11 padded to 8 bytes
+    int16_t left, right, cost;
+    uint16_t dup;  // IndexTable.dup[id] (index.rs:12,47) when this record is the
+                   // first of its surface, else 0; rides in the padding
+};
+struct alignas(16) CatInfo {  // one per category byte value
+    uint32_t flags;  // bit0 invoke_list[cat], bit1 group_list[cat], bit2 unk entry present
+    int32_t unk_first;   // UnkDict.char_category_to_morph_id[cat].0 (unk_dict.rs:15)
+    uint32_t unk_count;  //                                        .1
+    uint32_t pad;
+};
+enum : uint32_t { CAT_INVOKE = 1u, CAT_GROUP = 2u, CAT_HAS_UNK = 4u };
+
+struct DictView {
+    const DaNode *da;        uint32_t da_len;
+    const Morph8 *morph;     uint32_t n_morph;
+    const Morph8 *unk_morph; uint32_t n_unk_morph;
+    const int16_t *conn;     uint32_t conn_rows;  // element (right,left) at left*rows+right
+    const uint8_t *cat;      uint32_t cat_len;    // char_category_def.rs:17,33-38
+    const CatInfo *cinfo;                          // 256 entries
+};
+
+// ---- per-ctx control block in device memory (zeroed before every batch) ---
+struct Control {
+    unsigned long long queue_head;    // next sentence index to dequeue
+    unsigned long long arena_cursor;  // bump allocator over the scratch arena (bytes)
+    unsigned long long tok_cursor;    // bump allocator over the staging tokens
+    unsigned int arena_overflow;      // a slab request did not fit
+    unsigned int tok_overflow;        // staging tokens did not fit token_capacity
+    unsigned long long n_tokens;      // dense token count (written by the scan kernel)
+    unsigned long long pad[2];
+};
+
+struct BatchArgs {
+    const uint8_t *utf8;          // concatenated sentences
+    const uint64_t *offsets;      // n+1
+    uint64_t n;
+    Control *ctl;
+    uint8_t *arena;  uint64_t arena_bytes;
+    kgpu_token *stage;  uint64_t stage_cap;  // staging tokens (bump-allocated per sentence)
+    uint64_t *tok_start;          // n: staging index of sentence's first token
+    uint32_t *tok_count;          // n
+    uint8_t *status;              // n
+    kgpu_token *out;  uint64_t out_cap;      // dense output
+    uint64_t *tok_offsets;        // n+1
+};
+
+// Launchers (kgpu_kernels.hip).  `stream` is a hipStream_t.
+int launch_tokenize(const DictView &d, const BatchArgs &a, int n_workgroups, void *stream);
+int launch_scan_compact(const BatchArgs &a, void *stream);
+int tokenize_max_workgroups(int device);
+
+}  // namespace kgpu

@@ -1,0 +1,409 @@
+// kanpyo_amd/csrc/kgpu_kernels.hip -- hand-written gfx950 (CDNA4) kernels for
+// the Tokenizer::tokenize hot path (reference src/tokenizer.rs:16-45).
+//
+// One 64-lane wavefront owns one sentence from UTF-8 bytes to token records:
+//   phase 0  UTF-8 decode + validation, char -> byte offset, char category
+//            (char_category_def.rs:33-38)
+//   phase 1  lattice COUNT: one lane per start position walks the double array
+//            (trie/da.rs:155-182), expands duplicates (index.rs:46-51), decides the
+//            unknown-word span (lattice.rs:42-99); per-position node counts and
+//            per-end-position bucket counts
+//   phase 2  wave prefix sums -> node numbering in reference insertion order
+//            (lattice.rs:105-110) and bucket offsets (= Lattice.edges, lattice.rs:9)
+//   phase 3  lattice EMIT: same walk, nodes written to their numbered slots
+//   phase 4  Viterbi sweep over start positions (lattice.rs:116-142): all nodes
+//            starting at q share the predecessor bucket edges[q]; lanes take
+//            targets, the bucket is broadcast; min is lexicographic on
+//            (total, predecessor index) = strict '<' over ascending insertion order
+//   phase 5  backtrace (lattice.rs:144-153) + Node -> Token (tokenizer.rs:22-43)
+// Integer/indexing work only: no MFMA anywhere.
+//
+// This file holds the GENERAL kernel: every per-sentence array lives in a
+// bump-allocated HBM scratch slab, so any sentence length / lattice size works.
+#include <hip/hip_runtime.h>
+
+#include "kgpu_internal.h"
+
+namespace kgpu {
+
+namespace {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr int32_t INF = 1 << 30;               // lattice.rs:117
+constexpr uint32_t MAX_UNKNOWN_LEN = 1024;     // lattice.rs:55
+
+__device__ __forceinline__ uint32_t bcast32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t bcast64(uint64_t v) {
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t ld_l2(const uint32_t *p) {  // bypass the CU's L1
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+struct Slab {
+    uint8_t *ptr;
+    uint64_t size;
+};
+
+// Grow-only slab owned by this wavefront, carved from the ctx arena.
+__device__ __forceinline__ bool slab_ensure(Slab &s, uint64_t need, const BatchArgs &a, uint32_t lane) {
+    if (need <= s.size) return true;
+    uint64_t want = round_up(need + need / 2 + 256, 256);
+    uint64_t off = 0;
+    if (lane == 0) off = atomicAdd(&a.ctl->arena_cursor, (unsigned long long)want);
+    off = bcast64(off);
+    if (off + want > a.arena_bytes) {
+        if (lane == 0) atomicExch(&a.ctl->arena_overflow, 1u);
+        return false;
+    }
+    s.ptr = a.arena + off;
+    s.size = want;
+    return true;
+}
+
+// One double-array walk from byte k0 of the sentence (trie/da.rs:155-182).
+// F(id, byte_len_so_far_chars, morph_of_first) is invoked per match in
+// ascending byte length.  Returns nothing; `matched` is set by the callback.
+template <class F>
+__device__ __forceinline__ void da_walk(const DictView &d, const uint8_t *text, uint32_t k, uint32_t B,
+                                        int32_t base_root, F &&on_match) {
+    int32_t p = 1;  // ROOT_ID
+    int32_t bp = base_root;
+    uint32_t nch = 0;
+    for (; k < B; ++k) {
+        uint32_t c = text[k];
+        int32_t q = bp + (int32_t)c;
+        if ((uint32_t)q >= d.da_len) break;  // negative or past the end: "None" (da.rs:162)
+        DaNode nd = d.da[q];
+        if (nd.check != p) break;
+        p = q;
+        bp = nd.base;
+        nch += (c & 0xC0) != 0x80;
+        int32_t ah = bp;  // + TERMINATOR (da.rs:166)
+        if ((uint32_t)ah < d.da_len) {
+            DaNode t = d.da[ah];
+            if (t.check == p && t.base < 0) on_match((uint32_t)(-t.base), nch);
+        }
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a) {
+    const uint32_t lane = threadIdx.x;
+    Slab sa{nullptr, 0}, sn{nullptr, 0};
+    const int32_t base_root = d.da[1].base;
+
+    for (;;) {
+        uint64_t s = 0;
+        if (lane == 0) s = atomicAdd(&a.ctl->queue_head, 1ull);
+        s = bcast64(s);
+        if (s >= a.n) break;
+
+        const uint64_t b0 = a.offsets[s];
+        const uint32_t B = (uint32_t)(a.offsets[s + 1] - b0);
+        const uint8_t *text = a.utf8 + b0;
+
+        // ---- slab A: per-char arrays (C <= B) --------------------------------
+        const uint64_t na = (uint64_t)B + 4;
+        if (!slab_ensure(sa, na * 25 + 64, a, lane)) {
+            if (lane == 0) { a.status[s] = 2; a.tok_count[s] = 0; a.tok_start[s] = 0; }
+            continue;
+        }
+        uint32_t *cbyte = (uint32_t *)sa.ptr;  // char -> byte offset, [C] = B
+        uint32_t *uspan = cbyte + na;          // unknown span in chars (0 = none)
+        uint32_t *nb = uspan + na;             // node count, then first node index, per start
+        uint32_t *boff = nb + na;              // bucket count, then offset, per end
+        uint32_t *bfill = boff + na;           // bucket fill cursor
+        uint32_t *path = bfill + na;           // backtrace
+        uint8_t *ccat = (uint8_t *)(path + na);
+
+        // ---- phase 0: decode ------------------------------------------------
+        uint32_t C = 0, bad = 0, lensum = 0;
+        for (uint32_t k0 = 0; k0 < B; k0 += 64) {
+            uint32_t k = k0 + lane;
+            uint32_t b = k < B ? text[k] : 0x80u;
+            bool start = k < B && (b & 0xC0) != 0x80;
+            uint64_t m = __ballot(start);
+            uint32_t ci = C + __popcll(m & ((1ull << lane) - 1));
+            if (start) {
+                uint32_t l, cp;
+                if (b < 0x80) { l = 1; cp = b; }
+                else if (b >= 0xC2 && b <= 0xDF) { l = 2; cp = b & 0x1F; }
+                else if ((b & 0xF0) == 0xE0) { l = 3; cp = b & 0x0F; }
+                else if (b >= 0xF0 && b <= 0xF4) { l = 4; cp = b & 0x07; }
+                else { l = 1; cp = 0; bad = 1; }
+                if (k + l > B) { bad = 1; l = 1; }
+                for (uint32_t j = 1; j < l; ++j) {
+                    uint32_t bb = text[k + j];
+                    if ((bb & 0xC0) != 0x80) bad = 1;
+                    cp = (cp << 6) | (bb & 0x3F);
+                }
+                if (l == 3 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) bad = 1;
+                if (l == 4 && (cp < 0x10000 || cp > 0x10FFFF)) bad = 1;
+                lensum += l;
+                cbyte[ci] = k;
+                // char_category_def.rs:33-38: table[ch] if in range else table[0]
+                ccat[ci] = bad ? 0 : (cp < d.cat_len ? d.cat[cp] : d.cat[0]);
+            }
+            C += __popcll(m);
+        }
+        lensum = wave_sum(lensum);
+        if (__ballot(bad != 0) != 0 || lensum != B) {  // stray continuation bytes leave lensum < B
+            if (lane == 0) { a.status[s] = KGPU_SENT_INVALID_UTF8; a.tok_count[s] = 0; a.tok_start[s] = 0; }
+            continue;
+        }
+        if (lane == 0) cbyte[C] = B;
+        for (uint32_t e = lane; e < C + 3; e += 64) { boff[e] = 0; bfill[e] = 0; }
+        __syncthreads();
+
+        // ---- phase 1: count ----------------------------------------------------
+        const int nchunks = (int)((C + 63) / 64);
+        uint32_t carry_end = C;
+        for (int ch = nchunks - 1; ch >= 0; --ch) {
+            const uint32_t i = (uint32_t)ch * 64 + lane;
+            const bool active = i < C;
+            const uint32_t cat = active ? ccat[i] : 0x1FFu;
+            const uint32_t ncat = (i + 1 < C) ? ccat[i + 1] : 0x2FFu;
+            const uint64_t bm = __ballot(active && ncat != cat);
+            const uint64_t rest = bm >> lane;
+            const uint32_t run_end = rest ? i + (uint32_t)__ffsll((unsigned long long)rest) : carry_end;
+            carry_end = bcast32(run_end);
+            if (active) {
+                uint32_t cnt = 0;
+                da_walk(d, text, cbyte[i], B, base_root, [&](uint32_t id, uint32_t nch) {
+                    uint32_t nrec = 1u + d.morph[id - 1].dup;  // index.rs:46-51
+                    cnt += nrec;
+                    atomicAdd(&boff[i + nch], nrec);
+                });
+                const CatInfo ci = d.cinfo[cat];
+                uint32_t span = 0;
+                // lattice.rs:54: !matched_known || invoke_list[cat]; lattice.rs:87-92: no unk entry -> nothing
+                if ((cnt == 0 || (ci.flags & CAT_INVOKE)) && (ci.flags & CAT_HAS_UNK) && ci.unk_count) {
+                    span = 1;
+                    if (ci.flags & CAT_GROUP) {  // lattice.rs:66-84
+                        uint32_t r = run_end - i;
+                        span = r < MAX_UNKNOWN_LEN ? r : MAX_UNKNOWN_LEN;
+                    }
+                    cnt += ci.unk_count;
+                    atomicAdd(&boff[i + span], ci.unk_count);
+                }
+                uspan[i] = span;
+                nb[i] = cnt;
+            }
+        }
+        if (lane == 0) {
+            nb[C] = 1;      // EOS starts at C (lattice.rs:165-175)
+            nb[C + 1] = 0;
+            atomicAdd(&boff[0], 1u);  // BOS ends at 0 (lattice.rs:156-164)
+        }
+        __syncthreads();
+
+        // ---- phase 2: prefix sums ------------------------------------------------
+        uint32_t ncarry = 1, bcarry = 0;  // node 0 is BOS
+        for (uint32_t i0 = 0; i0 < C + 2; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const uint32_t v = i < C + 2 ? nb[i] : 0;
+            const uint32_t w = i < C + 2 ? ld_l2(&boff[i]) : 0;  // updated by L2 atomics
+            const uint32_t vs = wave_incl_scan(v, lane), ws = wave_incl_scan(w, lane);
+            if (i < C + 2) { nb[i] = ncarry + vs - v; boff[i] = bcarry + ws - w; }
+            ncarry += __shfl(vs, 63, 64);
+            bcarry += __shfl(ws, 63, 64);
+        }
+        const uint32_t N = ncarry;  // BOS + words + EOS
+        __syncthreads();
+
+        // ---- slab N: per-node arrays -----------------------------------------------
+        if (!slab_ensure(sn, (uint64_t)N * 44 + 64, a, lane)) {
+            if (lane == 0) { a.status[s] = 2; a.tok_count[s] = 0; a.tok_start[s] = 0; }
+            continue;
+        }
+        uint4 *nodeA = (uint4 *)sn.ptr;   // {left | right << 16, cost, bucket slot, signed id}
+        uint4 *bucket = nodeA + N;        // {dp, right_id, node index, -}
+        uint2 *nodeB = (uint2 *)(bucket + N);  // {start char, end char}
+        uint32_t *pre = (uint32_t *)(nodeB + N);
+
+        // ---- phase 3: emit -----------------------------------------------------------
+        for (uint32_t i = lane; i < C; i += 64) {
+            uint32_t t = nb[i];
+            da_walk(d, text, cbyte[i], B, base_root, [&](uint32_t id, uint32_t nch) {
+                const uint32_t end = i + nch;
+                const uint32_t nrec = 1u + d.morph[id - 1].dup;
+                for (uint32_t r = 0; r < nrec; ++r) {  // lattice.rs:177-188
+                    const Morph8 m = d.morph[id - 1 + r];
+                    const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
+                    nodeA[t] = make_uint4((uint16_t)m.left | ((uint32_t)(uint16_t)m.right << 16),
+                                          (uint32_t)(int32_t)m.cost, slot, id + r);
+                    nodeB[t] = make_uint2(i, end);
+                    ++t;
+                }
+            });
+            const uint32_t span = uspan[i];
+            if (span) {  // lattice.rs:87-97,190-201
+                const CatInfo ci = d.cinfo[ccat[i]];
+                const uint32_t end = i + span;
+                for (uint32_t r = 0; r < ci.unk_count; ++r) {
+                    const Morph8 m = d.unk_morph[ci.unk_first - 1 + (int32_t)r];
+                    const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
+                    nodeA[t] = make_uint4((uint16_t)m.left | ((uint32_t)(uint16_t)m.right << 16),
+                                          (uint32_t)(int32_t)m.cost, slot,
+                                          (uint32_t)(-(ci.unk_first + (int32_t)r)));
+                    nodeB[t] = make_uint2(i, end);
+                    ++t;
+                }
+            }
+        }
+        if (lane == 0) {
+            nodeA[N - 1] = make_uint4(0, 0, NONE, 0);  // EOS: Morph(0,0,0), id 0
+            nodeB[N - 1] = make_uint2(C, C);
+            bucket[0] = make_uint4(0, 0, 0, 0);        // BOS: dp None -> 0 (lattice.rs:127)
+            pre[0] = NONE;
+        }
+        __syncthreads();
+
+        // ---- phase 4: Viterbi sweep ---------------------------------------------------
+        uint32_t t0 = nb[0], p0 = boff[0];
+        for (uint32_t q = 0; q <= C; ++q) {
+            const uint32_t t1 = nb[q + 1], p1 = boff[q + 1];
+            const uint32_t P = p1 - p0;
+            for (uint32_t t = t0 + lane; t < t1; t += 64) {
+                const uint4 na_ = nodeA[t];
+                const int16_t *col = d.conn + (size_t)d.conn_rows * (na_.x & 0xFFFFu);
+                int32_t best = 0x7FFFFFFF;
+                uint32_t bidx = NONE;
+                for (uint32_t j = 0; j < P; ++j) {
+                    const uint4 e = bucket[p0 + j];
+                    const int32_t v = (int32_t)e.x + (int32_t)col[e.y];
+                    if (v < best || (v == best && e.z < bidx)) { best = v; bidx = e.z; }
+                }
+                int32_t dpv = INF;
+                uint32_t prv = NONE;
+                if (P) {
+                    const int32_t tot = best + (int32_t)na_.y;  // min(.., INF) then strict '<' INF
+                    if (tot < INF) { dpv = tot; prv = bidx; }
+                }
+                pre[t] = prv;
+                if (na_.z != NONE) bucket[na_.z] = make_uint4((uint32_t)dpv, na_.x >> 16, t, 0);
+            }
+            t0 = t1;
+            p0 = p1;
+            __syncthreads();
+        }
+
+        // ---- phase 5: backtrace + tokens -----------------------------------------------
+        uint32_t K = 0;
+        if (lane == 0) {
+            uint32_t pos = N - 1, pr;
+            while ((pr = pre[pos]) != NONE) { path[K++] = pos; pos = pr; }
+        }
+        K = bcast32(K);
+        uint64_t ts = 0;
+        if (lane == 0) ts = atomicAdd(&a.ctl->tok_cursor, (unsigned long long)K);
+        ts = bcast64(ts);
+        __syncthreads();
+        if (ts + K <= a.stage_cap) {
+            for (uint32_t k = lane; k < K; k += 64) {
+                const uint32_t t = path[K - 1 - k];
+                const int32_t sid = (int32_t)nodeA[t].w;
+                const uint2 se = nodeB[t];
+                kgpu_token tk;
+                if (sid == 0) {  // Dummy -> "EOS" (tokenizer.rs:27-28,34)
+                    tk.id = 0; tk.cls = KGPU_CLASS_DUMMY; tk.position = B; tk.start = C; tk.end = C + 3; tk.byte_len = 0;
+                } else {
+                    const uint32_t bs = cbyte[se.x];
+                    tk.id = sid > 0 ? sid : -sid;
+                    tk.cls = sid > 0 ? KGPU_CLASS_KNOWN : KGPU_CLASS_UNKNOWN;
+                    tk.position = bs; tk.start = se.x; tk.end = se.y; tk.byte_len = cbyte[se.y] - bs;
+                }
+                a.stage[ts + k] = tk;
+            }
+        } else if (lane == 0) {
+            atomicExch(&a.ctl->tok_overflow, 1u);
+        }
+        if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; a.tok_start[s] = ts; }
+        __syncthreads();
+    }
+}
+
+// Exclusive scan of per-sentence token counts -> tok_offsets (single workgroup;
+// n is at most a few million per batch).
+__global__ __launch_bounds__(1024) void k_scan_counts(BatchArgs a) {
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < a.n; base += 1024) {
+        const uint64_t i = base + tid;
+        const uint32_t v = i < a.n ? a.tok_count[i] : 0;
+        const uint32_t vs = wave_incl_scan(v, lane);
+        if (lane == 63) wsum[wid] = vs;
+        __syncthreads();
+        uint64_t woff = 0;
+        for (uint32_t w = 0; w < wid; ++w) woff += wsum[w];
+        const uint64_t carry = carry_s;
+        if (i < a.n) a.tok_offsets[i] = carry + woff + vs - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + vs;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.tok_offsets[a.n] = carry_s;
+        a.ctl->n_tokens = carry_s;
+    }
+}
+
+// Staging (dequeue order) -> dense sentence order.  One wavefront per sentence,
+// dword-granular coalesced copy.
+__global__ __launch_bounds__(256) void k_compact(BatchArgs a) {
+    if (a.ctl->tok_overflow) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t s = wave; s < a.n; s += nwaves) {
+        const uint32_t cnt = a.tok_count[s];
+        const uint64_t dst = a.tok_offsets[s];
+        if (dst + cnt > a.out_cap) continue;
+        const uint32_t *src = (const uint32_t *)(a.stage + a.tok_start[s]);
+        uint32_t *out = (uint32_t *)(a.out + dst);
+        for (uint32_t w = lane; w < cnt * 6; w += 64) out[w] = src[w];
+    }
+}
+
+int launch_tokenize(const DictView &d, const BatchArgs &a, int n_workgroups, void *stream) {
+    hipLaunchKernelGGL(k_tokenize_general, dim3(n_workgroups), dim3(64), 0, (hipStream_t)stream, d, a);
+    return (int)hipGetLastError();
+}
+
+int launch_scan_compact(const BatchArgs &a, void *stream) {
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    uint64_t blocks = (a.n + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+int tokenize_max_workgroups(int device) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return 2048;
+    return p.multiProcessorCount * 16;  // 16 single-wave workgroups per CU
+}
+
+}  // namespace kgpu

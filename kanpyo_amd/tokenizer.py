@@ -1,0 +1,121 @@
+"""Tokenizer (reference src/tokenizer.rs:7-45) over the HIP path.
+
+    tokenizer = Tokenizer(dict)          # Tokenizer::new(dict)   src/tokenizer.rs:12-14
+    tokens = tokenizer.tokenize("...")   # -> Vec<Token>          src/tokenizer.rs:16-45
+
+plus the batched forms the GPU wants (many sentences per launch).  Everything
+computes on the device through include/kanpyo_gpu.h; there is no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence
+
+import numpy as np
+
+from . import _lib
+from .dict import Dict
+from .token import Token, TokenClass
+
+# kgpu_token (include/kanpyo_gpu.h)
+TOKEN_DTYPE = np.dtype(
+    [("id", "<i4"), ("cls", "<u4"), ("position", "<u4"), ("start", "<u4"), ("end", "<u4"), ("byte_len", "<u4")]
+)
+
+
+def pack_sentences(sentences: Sequence) -> tuple:
+    """list of str/bytes -> (uint8 concatenation, uint64 offsets[n+1])."""
+    enc = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in sentences]
+    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+    if enc:
+        offs[1:] = np.cumsum(np.fromiter((len(e) for e in enc), dtype=np.uint64, count=len(enc)))
+    return np.frombuffer(b"".join(enc), dtype=np.uint8), offs
+
+
+class Tokenizer:
+    def __init__(self, dict: Dict, device: int = 0):
+        self.dict = dict  # pub dict: Dict (src/tokenizer.rs:7-9)
+        L = _lib.lib()
+        b = _lib.DictBlobs()
+        self._keep = []
+        for name, blob in (
+            ("index", dict.index_dict), ("connection", dict.connection_dict), ("morph", dict.morph_dict),
+            ("unk", dict.unk_dict), ("char_category", dict.char_category), ("invoke", dict.invoke_list),
+            ("group", dict.group_list),
+        ):
+            a = np.frombuffer(blob, dtype=np.uint8) if isinstance(blob, (bytes, bytearray)) else np.ascontiguousarray(blob, dtype=np.uint8)
+            self._keep.append(a)
+            setattr(b, name + "_p", a.ctypes.data if a.size else None)
+            setattr(b, name + "_len", a.size)
+        h = C.c_void_p()
+        _lib.check(L.kgpu_dict_create(C.byref(b), int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().kgpu_dict_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self) -> dict:
+        i = _lib.DictInfo()
+        _lib.check(_lib.lib().kgpu_dict_get_info(self._h, C.byref(i)))
+        return {n: int(getattr(i, n)) for n, _ in i._fields_ if n != "reserved"}
+
+    # ---- packed batch: the form the C ABI speaks -------------------------------
+    def tokenize_packed(self, utf8: np.ndarray, offsets: np.ndarray, token_capacity: int | None = None):
+        """-> (tokens[TOKEN_DTYPE], tok_offsets[uint64 n+1], status[uint8 n])."""
+        utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        if n < 0:
+            raise ValueError("offsets needs n+1 entries")
+        total = int(offsets[-1] - offsets[0]) if n else 0
+        cap = int(token_capacity) if token_capacity is not None else total // 2 + n + 64
+        L = _lib.lib()
+        while True:
+            tokens = np.empty(cap, dtype=TOKEN_DTYPE)
+            toff = np.zeros(n + 1, dtype=np.uint64)
+            status = np.zeros(max(n, 1), dtype=np.uint8)
+            got = C.c_uint64(0)
+            rc = L.kgpu_tokenize_batch(
+                self._h, utf8.ctypes.data if utf8.size else None, offsets.ctypes.data, n, tokens.ctypes.data, cap,
+                toff.ctypes.data, status.ctypes.data, C.byref(got),
+            )
+            if rc == _lib.KGPU_ERR_CAPACITY and token_capacity is None:
+                cap = int(got.value) + 64  # exact size reported by the device
+                continue
+            _lib.check(rc)
+            return tokens[: int(got.value)], toff, status[:n]
+
+    # ---- reference-shaped API --------------------------------------------------
+    def tokenize_batch(self, sentences: Sequence[str]) -> List[List[Token]]:
+        utf8, offs = pack_sentences(sentences)
+        tokens, toff, status = self.tokenize_packed(utf8, offs)
+        out = []
+        for i, s in enumerate(sentences):
+            if status[i] == _lib.KGPU_SENT_INVALID_UTF8:
+                raise UnicodeDecodeError("utf-8", bytes(utf8[int(offs[i]) : int(offs[i + 1])]), 0, 1, "invalid UTF-8 sentence")
+            raw = utf8[int(offs[i]) : int(offs[i + 1])].tobytes()
+            row = []
+            for t in tokens[int(toff[i]) : int(toff[i + 1])]:
+                cls = TokenClass(int(t["cls"]))
+                pos, bl = int(t["position"]), int(t["byte_len"])
+                surface = "EOS" if cls == TokenClass.Dummy else raw[pos : pos + bl].decode("utf-8")
+                row.append(Token(int(t["id"]), cls, pos, int(t["start"]), int(t["end"]), surface))
+            out.append(row)
+        return out
+
+    def tokenize(self, input: str) -> List[Token]:
+        """Tokenizer::tokenize (src/tokenizer.rs:16-45): one sentence == a batch of one."""
+        return self.tokenize_batch([input])[0]
