@@ -98,6 +98,23 @@ typedef struct kgpu_profile {
     double aux_ms;         /* sum of scan + compaction kernel durations         */
 } kgpu_profile;
 
+/* Work counters of one or more batches, counted on the device when
+ * kgpu_ctx_set_profiling(ctx, KGPU_PROFILE_WORK) is on (the
+ * algorithmic-byte formulas are written in these).  Slower: not for timed runs. */
+typedef struct kgpu_work {
+    uint64_t sentences;
+    uint64_t B; /* input bytes                                              */
+    uint64_t C; /* input chars                                              */
+    uint64_t T; /* double-array byte steps attempted (incl. the failing one) */
+    uint64_t N; /* lattice nodes excluding BOS                              */
+    uint64_t E; /* Viterbi relaxations (target, predecessor) pairs          */
+    uint64_t K; /* emitted tokens                                           */
+} kgpu_work;
+
+#define KGPU_PROFILE_OFF 0
+#define KGPU_PROFILE_EVENTS 1 /* HIP events around the kernels            */
+#define KGPU_PROFILE_WORK 2   /* device-side work counters (kgpu_work)    */
+
 const char *kgpu_last_error(void);
 int kgpu_device_count(void);
 
@@ -132,8 +149,9 @@ int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_o
                          uint64_t total_bytes, kgpu_token *d_tokens, uint64_t token_capacity,
                          uint64_t *d_tok_offsets, uint8_t *d_status);
 int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens);
-int kgpu_ctx_set_profiling(kgpu_ctx *c, int enabled);
+int kgpu_ctx_set_profiling(kgpu_ctx *c, int mode /* KGPU_PROFILE_* bit mask */);
 int kgpu_ctx_get_profile(kgpu_ctx *c, kgpu_profile *out, int reset);
+int kgpu_ctx_get_work(kgpu_ctx *c, kgpu_work *out, int reset);
 
 /* IndexTable::build + write_dict (kanpyo-dict/src/index.rs:16-38,75-84 over
  * trie/da.rs:22-131,191-217): sorted keywords (duplicates adjacent) -> the

@@ -21,7 +21,7 @@ KGPU_SENT_INVALID_UTF8 = 1
 SYMBOLS = [
     "kgpu_last_error", "kgpu_device_count", "kgpu_dict_create", "kgpu_dict_destroy", "kgpu_dict_get_info",
     "kgpu_tokenize_batch", "kgpu_ctx_create", "kgpu_ctx_destroy", "kgpu_tokenize_device", "kgpu_ctx_sync",
-    "kgpu_ctx_set_profiling", "kgpu_ctx_get_profile", "kgpu_index_build", "kgpu_free",
+    "kgpu_ctx_set_profiling", "kgpu_ctx_get_profile", "kgpu_ctx_get_work", "kgpu_index_build", "kgpu_free",
 ]
 
 
@@ -48,6 +48,10 @@ class DictInfo(C.Structure):
 
 class Profile(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("tokenize_ms", C.c_double), ("aux_ms", C.c_double)]
+
+
+class Work(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("sentences", "B", "C", "T", "N", "E", "K")]
 
 
 _lib = None
@@ -79,6 +83,7 @@ def lib():
         L.kgpu_ctx_sync.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.kgpu_ctx_set_profiling.argtypes = [vp, C.c_int]
         L.kgpu_ctx_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
+        L.kgpu_ctx_get_work.argtypes = [vp, C.POINTER(Work), C.c_int]
         L.kgpu_index_build.argtypes = [vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.kgpu_free.argtypes = [vp]
         L.kgpu_free.restype = None

@@ -93,7 +93,9 @@ struct kgpu_ctx {
     bool pending = false;
     int n_wg_max = 2048;
     // profiling
-    bool profiling = false;
+    bool profiling = false;   // KGPU_PROFILE_EVENTS
+    bool count_work = false;  // KGPU_PROFILE_WORK
+    kgpu_work work{};
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     kgpu_profile prof{};
@@ -389,6 +391,7 @@ extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const ui
     a.stage = (kgpu_token *)c->stage.p; a.stage_cap = token_capacity;
     a.tok_start = (uint64_t *)c->tok_start.p; a.tok_count = (uint32_t *)c->tok_count.p;
     a.status = d_status; a.out = d_tokens; a.out_cap = token_capacity; a.tok_offsets = d_tok_offsets;
+    a.count_work = c->count_work ? 1u : 0u;
     return enqueue(c, a);
 }
 
@@ -422,6 +425,11 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
         }
         c->ev_used = 0;
     }
+    if (c->last.count_work) {
+        const unsigned long long *w = c->h_ctl->work;
+        c->work.sentences += w[0]; c->work.B += w[1]; c->work.C += w[2]; c->work.T += w[3];
+        c->work.N += w[4]; c->work.E += w[5]; c->work.K += w[6];
+    }
     uint64_t need = c->h_ctl->tok_overflow ? c->h_ctl->tok_cursor : c->h_ctl->n_tokens;
     if (n_tokens) *n_tokens = need;
     if (c->h_ctl->tok_overflow || c->h_ctl->n_tokens > c->last.out_cap) {
@@ -431,9 +439,17 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
     return KGPU_OK;
 }
 
-extern "C" int kgpu_ctx_set_profiling(kgpu_ctx *c, int enabled) {
+extern "C" int kgpu_ctx_set_profiling(kgpu_ctx *c, int mode) {
     if (!c) { set_error("kgpu_ctx_set_profiling: null ctx"); return KGPU_ERR_INVALID_ARG; }
-    c->profiling = enabled != 0;
+    c->profiling = (mode & KGPU_PROFILE_EVENTS) != 0;
+    c->count_work = (mode & KGPU_PROFILE_WORK) != 0;
+    return KGPU_OK;
+}
+
+extern "C" int kgpu_ctx_get_work(kgpu_ctx *c, kgpu_work *out, int reset) {
+    if (!c || !out) { set_error("kgpu_ctx_get_work: null argument"); return KGPU_ERR_INVALID_ARG; }
+    *out = c->work;
+    if (reset) c->work = kgpu_work{};
     return KGPU_OK;
 }
 

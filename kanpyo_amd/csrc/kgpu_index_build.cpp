@@ -11,7 +11,8 @@
 // cursor kept in slot 0, cursor advanced when the scanned window is >= 95 %
 // occupied, depth-first in byte order).  The implementation here is an
 // explicit-stack DFS over key ranges (the sorted keyword list makes every
-// trie node a contiguous key range), not the reference's recursion over
+// trie node a contiguous key range; unsorted-but-prefix-grouped lists such as the
+// reference fixture src/tests.rs:9-13 still are), not the reference's recursion over
 // Vec<KeywordID>.
 #include <cstdint>
 #include <cstdlib>
@@ -60,7 +61,10 @@ struct Builder {
         }
     }
     struct Frame { size_t p, depth; uint64_t lo, hi; };
-    void build(uint64_t nkeys) {
+    // Returns false where the reference's `add` would hit its assert (da.rs:106-111):
+    // the same byte shows up in two non-adjacent runs of a branch list, i.e. the
+    // keyword list is not grouped by prefix (sorted input always is).
+    bool build(uint64_t nkeys) {
         std::vector<Frame> st;
         st.push_back({1, 0, 0, nkeys});
         uint8_t ch[257]; uint64_t cs[257], ce[257];
@@ -68,10 +72,15 @@ struct Builder {
             Frame f = st.back(); st.pop_back();
             grow_to(f.p);
             size_t nch = 0;
+            uint64_t seen[4] = {0, 0, 0, 0};
             for (uint64_t k = f.lo; k < f.hi; ++k) {
                 size_t len = (size_t)(koff[k + 1] - koff[k]);
                 uint8_t c = f.depth < len ? keys[koff[k] + f.depth] : 0;  // TERMINATOR
-                if (nch == 0 || ch[nch - 1] != c) { ch[nch] = c; cs[nch] = k; ++nch; }
+                if (nch == 0 || ch[nch - 1] != c) {
+                    if (seen[c >> 6] & (1ull << (c & 63))) return false;
+                    seen[c >> 6] |= 1ull << (c & 63);
+                    ch[nch] = c; cs[nch] = k; ++nch;
+                }
                 ce[nch - 1] = k + 1;
             }
             size_t left = seek(ch, nch);
@@ -87,6 +96,7 @@ struct Builder {
                 st.push_back({left + ch[c], f.depth + 1, cs[c], ce[c]});
             }
         }
+        return true;
     }
 };
 
@@ -115,13 +125,6 @@ extern "C" int kgpu_index_build(const uint8_t *keys, const uint64_t *key_offsets
                 else dup.push_back({first, 1});
                 continue;
             }
-            // the reference assumes sorted input; enforce it (byte-wise String order)
-            size_t m = (size_t)std::min(pe - ps, e - s);
-            int c = std::memcmp(keys + ps, keys + s, m);
-            if (c > 0 || (c == 0 && pe - ps > e - s)) {
-                kgpu::set_error("kgpu_index_build: keywords are not sorted");
-                return KGPU_ERR_INVALID_ARG;
-            }
         }
         ustart.push_back(s); uend.push_back(e); ids.push_back((int64_t)i + 1);
     }
@@ -135,7 +138,10 @@ extern "C" int kgpu_index_build(const uint8_t *keys, const uint64_t *key_offsets
     koff.push_back(packed.size());
 
     Builder b((const uint8_t *)packed.data(), koff, ids);
-    b.build(ustart.size());
+    if (!b.build(ustart.size())) {
+        kgpu::set_error("kgpu_index_build: keywords are not grouped by prefix (sort them; the reference panics here, da.rs:106)");
+        return KGPU_ERR_INVALID_ARG;
+    }
     size_t len = b.a.size();  // truncate (da.rs:29-35)
     while (len > 1 && b.a[len - 1].check == 0) --len;
 

@@ -46,7 +46,7 @@ struct Control {
     unsigned int arena_overflow;      // a slab request did not fit
     unsigned int tok_overflow;        // staging tokens did not fit token_capacity
     unsigned long long n_tokens;      // dense token count (written by the scan kernel)
-    unsigned long long pad[2];
+    unsigned long long work[7];       // kgpu_work, only when BatchArgs::count_work
 };
 
 struct BatchArgs {
@@ -61,6 +61,7 @@ struct BatchArgs {
     uint8_t *status;              // n
     kgpu_token *out;  uint64_t out_cap;      // dense output
     uint64_t *tok_offsets;        // n+1
+    uint32_t count_work;          // accumulate kgpu_work into ctl->work (slow; off in timed runs)
 };
 
 // Launchers (kgpu_kernels.hip).  `stream` is a hipStream_t.

@@ -81,13 +81,14 @@ __device__ __forceinline__ bool slab_ensure(Slab &s, uint64_t need, const BatchA
 // F(id, byte_len_so_far_chars, morph_of_first) is invoked per match in
 // ascending byte length.  Returns nothing; `matched` is set by the callback.
 template <class F>
-__device__ __forceinline__ void da_walk(const DictView &d, const uint8_t *text, uint32_t k, uint32_t B,
-                                        int32_t base_root, F &&on_match) {
+__device__ __forceinline__ uint32_t da_walk(const DictView &d, const uint8_t *text, uint32_t k, uint32_t B,
+                                            int32_t base_root, F &&on_match) {
     int32_t p = 1;  // ROOT_ID
     int32_t bp = base_root;
-    uint32_t nch = 0;
+    uint32_t nch = 0, steps = 0;
     for (; k < B; ++k) {
         uint32_t c = text[k];
+        ++steps;
         int32_t q = bp + (int32_t)c;
         if ((uint32_t)q >= d.da_len) break;  // negative or past the end: "None" (da.rs:162)
         DaNode nd = d.da[q];
@@ -101,6 +102,7 @@ __device__ __forceinline__ void da_walk(const DictView &d, const uint8_t *text, 
             if (t.check == p && t.base < 0) on_match((uint32_t)(-t.base), nch);
         }
     }
+    return steps;
 }
 
 }  // namespace
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         // ---- phase 1: count ----------------------------------------------------
         const int nchunks = (int)((C + 63) / 64);
         uint32_t carry_end = C;
+        uint32_t wT = 0, wE = 0;  // work counters (only reduced when a.count_work)
         for (int ch = nchunks - 1; ch >= 0; --ch) {
             const uint32_t i = (uint32_t)ch * 64 + lane;
             const bool active = i < C;
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             carry_end = bcast32(run_end);
             if (active) {
                 uint32_t cnt = 0;
-                da_walk(d, text, cbyte[i], B, base_root, [&](uint32_t id, uint32_t nch) {
+                wT += da_walk(d, text, cbyte[i], B, base_root, [&](uint32_t id, uint32_t nch) {
                     uint32_t nrec = 1u + d.morph[id - 1].dup;  // index.rs:46-51
                     cnt += nrec;
                     atomicAdd(&boff[i + nch], nrec);
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         for (uint32_t q = 0; q <= C; ++q) {
             const uint32_t t1 = nb[q + 1], p1 = boff[q + 1];
             const uint32_t P = p1 - p0;
+            wE += (lane == 0) ? P * (t1 - t0) : 0;
             for (uint32_t t = t0 + lane; t < t1; t += 64) {
                 const uint4 na_ = nodeA[t];
                 const int16_t *col = d.conn + (size_t)d.conn_rows * (na_.x & 0xFFFFu);
@@ -337,6 +341,15 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             atomicExch(&a.ctl->tok_overflow, 1u);
         }
         if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; a.tok_start[s] = ts; }
+        if (a.count_work) {
+            wT = wave_sum(wT);
+            if (lane == 0) {
+                unsigned long long *w = a.ctl->work;
+                atomicAdd(&w[0], 1ull); atomicAdd(&w[1], (unsigned long long)B); atomicAdd(&w[2], (unsigned long long)C);
+                atomicAdd(&w[3], (unsigned long long)wT); atomicAdd(&w[4], (unsigned long long)(N - 1));
+                atomicAdd(&w[5], (unsigned long long)wE); atomicAdd(&w[6], (unsigned long long)K);
+            }
+        }
         __syncthreads();
     }
 }

@@ -1,0 +1,60 @@
+"""Device-resident entry points (include/kanpyo_gpu.h: kgpu_ctx_*, kgpu_tokenize_device).
+
+Inputs already in HBM, outputs left in HBM: what bench.py times and what the
+multi-GPU gather (kanpyo_amd/dist.py) consumes.  Pointers cross as plain
+integers (e.g. torch.Tensor.data_ptr()); torch itself is not imported here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import _lib
+
+PROFILE_OFF, PROFILE_EVENTS, PROFILE_WORK = 0, 1, 2
+
+
+class DeviceContext:
+    """One HIP stream + scratch arena; not thread-safe, make one per thread / per queue slot."""
+
+    def __init__(self, tokenizer, stream_ptr: int | None = None):
+        self._tok = tokenizer  # keeps the dictionary alive
+        h = C.c_void_p()
+        _lib.check(_lib.lib().kgpu_ctx_create(tokenizer.handle, C.c_void_p(stream_ptr) if stream_ptr else None, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().kgpu_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def tokenize(self, d_utf8: int, d_offsets: int, n: int, total_bytes: int, d_tokens: int, token_capacity: int,
+                 d_tok_offsets: int, d_status: int):
+        """Enqueue one batch (asynchronous)."""
+        _lib.check(_lib.lib().kgpu_tokenize_device(
+            self._h, C.c_void_p(d_utf8), C.c_void_p(d_offsets), n, total_bytes, C.c_void_p(d_tokens), token_capacity,
+            C.c_void_p(d_tok_offsets), C.c_void_p(d_status)))
+
+    def sync(self) -> int:
+        """Wait for the enqueued batch; returns its dense token count."""
+        n = C.c_uint64(0)
+        _lib.check(_lib.lib().kgpu_ctx_sync(self._h, C.byref(n)))
+        return int(n.value)
+
+    def set_profiling(self, mode: int):
+        _lib.check(_lib.lib().kgpu_ctx_set_profiling(self._h, int(mode)))
+
+    def profile(self, reset: bool = True) -> dict:
+        p = _lib.Profile()
+        _lib.check(_lib.lib().kgpu_ctx_get_profile(self._h, C.byref(p), int(reset)))
+        return {"launches": int(p.launches), "tokenize_ms": float(p.tokenize_ms), "aux_ms": float(p.aux_ms)}
+
+    def work(self, reset: bool = True) -> dict:
+        w = _lib.Work()
+        _lib.check(_lib.lib().kgpu_ctx_get_work(self._h, C.byref(w), int(reset)))
+        return {n: int(getattr(w, n)) for n, _ in w._fields_}

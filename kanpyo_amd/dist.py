@@ -1,0 +1,96 @@
+"""Multi-GPU sharding and the result gather.
+
+Sentences are independent (Tokenizer::tokenize takes &self and a single &str,
+reference src/tokenizer.rs:16), so the path shards with no data-path exchange:
+sentence i goes to rank i mod G, the dictionary is replicated per GPU.  The only
+communication is one variable-length gather of the 24-byte token records to
+rank 0: every peer has its own direct xGMI link to the root, so a flat
+gatherv (grouped send/recv, RCCL's ncclSend/ncclRecv under torch.distributed's
+"nccl" backend) uses all links in parallel -- no ring, no all-reduce.
+A sentence is never split across GPUs (Viterbi is serial along the sentence).
+torch is imported lazily: it is plumbing (device memory, process group), not
+part of the tokenizer.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+
+
+def shard_indices(n: int, rank: int, world: int) -> np.ndarray:
+    """Round-robin: the sentences rank `rank` owns."""
+    return np.arange(rank, n, world, dtype=np.int64)
+
+
+def unshard_order(n: int, world: int) -> np.ndarray:
+    """Position in the rank-major gathered stream of each original sentence:
+    gathered = [rank0's sentences..., rank1's..., ...]; returns perm with
+    gathered[perm[i]] == sentence i."""
+    sizes = [(n - r + world - 1) // world for r in range(world)]
+    starts = np.concatenate([[0], np.cumsum(sizes)])[:-1]
+    i = np.arange(n, dtype=np.int64)
+    return starts[i % world] + i // world
+
+
+def gather_tokens(tokens, counts, dst: int = 0, group=None):
+    """Flat gatherv of token records and per-sentence counts to rank `dst`.
+
+    tokens: [T, 6] int32 tensor (kgpu_token rows) on this rank's device (or CPU
+    for the gloo tests); counts: [n_local] int64 tokens per local sentence.
+    Returns (tokens_all, counts_all, sizes) on dst -- rank-major concatenation --
+    and (None, None, sizes) elsewhere.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    meta = torch.tensor([tokens.shape[0], counts.shape[0]], dtype=torch.int64, device=tokens.device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    sizes = [(int(m[0]), int(m[1])) for m in metas]
+    if rank == dst:
+        tok_all = torch.empty((sum(s[0] for s in sizes), 6), dtype=tokens.dtype, device=tokens.device)
+        cnt_all = torch.empty(sum(s[1] for s in sizes), dtype=counts.dtype, device=counts.device)
+        ops, t0, c0 = [], 0, 0
+        for r, (nt, nc) in enumerate(sizes):
+            tv, cv = tok_all[t0 : t0 + nt], cnt_all[c0 : c0 + nc]
+            if r == dst:
+                tv.copy_(tokens)
+                cv.copy_(counts)
+            else:
+                if nt:
+                    ops.append(dist.P2POp(dist.irecv, tv, r, group))
+                if nc:
+                    ops.append(dist.P2POp(dist.irecv, cv, r, group))
+            t0 += nt
+            c0 += nc
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return tok_all, cnt_all, sizes
+    ops = []
+    if tokens.shape[0]:
+        ops.append(dist.P2POp(dist.isend, tokens.contiguous(), dst, group))
+    if counts.shape[0]:
+        ops.append(dist.P2POp(dist.isend, counts.contiguous(), dst, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return None, None, sizes
+
+
+def reassemble(tok_all: np.ndarray, cnt_all: np.ndarray, n: int, world: int):
+    """Rank-major gathered stream -> original sentence order (host side).
+    Returns (tokens [T,6], tok_offsets [n+1])."""
+    perm = unshard_order(n, world)
+    off_g = np.concatenate([[0], np.cumsum(cnt_all)]).astype(np.int64)
+    cnt = cnt_all[perm]
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    out = np.empty_like(tok_all)
+    src_start = off_g[perm]
+    # vectorised segment copy
+    idx = np.repeat(src_start - off[:-1], cnt) + np.arange(off[-1])
+    out[:] = tok_all[idx]
+    return out, off

@@ -581,13 +581,20 @@ static size_t key_len(const dab_t *b, uint64_t k) { return (size_t)(b->koff[k + 
 /* da.rs:80-131 DoubleArray::add.  `branches` of the reference is always a
  * contiguous run [lo,hi) of the sorted unique keyword list (all keys sharing
  * the first i bytes), so the Vec<KeywordID> is carried as a range. */
-static void dab_add(dab_t *b, size_t p, size_t i, uint64_t lo, uint64_t hi) {
+static int dab_add(dab_t *b, size_t p, size_t i, uint64_t lo, uint64_t hi) {
     while (p >= b->len) dab_expand(b);
     uint8_t chars[257]; uint64_t cstart[257], cend[257]; size_t nch = 0;
+    uint8_t seen[256]; memset(seen, 0, sizeof seen);
     for (uint64_t k = lo; k < hi; k++) {
         const uint8_t *s = b->keys + b->koff[k];
         uint8_t ch = i < key_len(b, k) ? s[i] : 0; /* *str.get(i).unwrap_or(&TERMINATOR) */
-        if (nch == 0 || chars[nch - 1] != ch) { chars[nch] = ch; cstart[nch] = k; cend[nch] = k; nch++; }
+        if (nch == 0 || chars[nch - 1] != ch) {
+            /* a byte re-appearing in a second run makes char_bytes hold it twice and the
+             * assert at da.rs:106-111 fire; sorted keyword lists never do this */
+            if (seen[ch]) return -1;
+            seen[ch] = 1;
+            chars[nch] = ch; cstart[nch] = k; cend[nch] = k; nch++;
+        }
         cend[nch - 1] = k + 1;
     }
     size_t left = dab_seek(b, chars, nch);
@@ -600,8 +607,9 @@ static void dab_add(dab_t *b, size_t p, size_t i, uint64_t lo, uint64_t hi) {
     for (size_t c = 0; c < nch; c++) {
         if (chars[c] == 0) continue; /* TERMINATOR has no child branches */
         int32_t q = b->a[p].base + (int32_t)chars[c];
-        dab_add(b, (size_t)q, i + 1, cstart[c], cend[c]);
+        if (dab_add(b, (size_t)q, i + 1, cstart[c], cend[c])) return -1;
     }
+    return 0;
 }
 
 /* index.rs:16-38 IndexTable::build + da.rs:205-217 build_with_ids + da.rs:29-35
@@ -637,7 +645,11 @@ uint8_t *korc_index_build(const uint8_t *keys, const uint64_t *key_offsets, uint
     b.a = (da_node *)calloc(b.len, sizeof(da_node));
     b.a[0].base = 1 + 1; /* ROOT_ID + 1, da.rs:25 */
     b.keys = ukeys; b.koff = ukoff; b.ids = ids;
-    dab_add(&b, 1, 0, 0, nu);
+    if (dab_add(&b, 1, 0, 0, nu)) {
+        set_err("panic: keywords not grouped by prefix (assert at da.rs:106)");
+        free(b.a); free(ukoff); free(ukeys); free(ids); free(dk); free(dv);
+        return NULL;
+    }
     size_t len = b.len; /* truncate da.rs:29-35 */
     while (len > 1 && b.a[len - 1].check == 0) len--;
 

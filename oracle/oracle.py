@@ -89,6 +89,8 @@ def index_build(sorted_keywords) -> bytes:
     p, _, keep = _buf(cat if cat else b"\0")
     out_len = C.c_size_t(0)
     ptr = lib().korc_index_build(p, offs.ctypes.data, len(enc), C.byref(out_len))
+    if not ptr:
+        raise RuntimeError("oracle: reference would panic: " + lib().korc_last_error().decode())
     blob = C.string_at(ptr, out_len.value)
     lib().korc_free(ptr)
     return blob

@@ -1,0 +1,232 @@
+"""GPU parity: the HIP path (through the C ABI) must be bit-exact against the CPU
+oracle on the same inputs.  Integer/byte work => exact equality, no tolerance.
+Run on the GPU box with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from conftest import fixture_dict_parts, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def libs():
+    from kanpyo_amd import _lib
+
+    assert _lib.lib().kgpu_device_count() > 0, "no HIP device: the gpu tests need an MI355X"
+    from oracle import oracle
+
+    oracle.build()
+    return _lib, oracle
+
+
+@pytest.fixture(scope="module")
+def small(libs):
+    """20k-record synthetic dictionary: GPU tokenizer + oracle over the same blobs."""
+    from kanpyo_amd import Tokenizer, synth
+
+    _, oracle = libs
+    sd = synth.build_dict(20000, seed=11)
+    return sd, Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
+
+
+@pytest.fixture(scope="module")
+def full(libs):
+    """The 392k-record IPADIC-shaped dictionary of BASELINE.json's configs."""
+    from kanpyo_amd import Tokenizer, synth
+
+    _, oracle = libs
+    sd = synth.build_dict()
+    return sd, Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
+
+
+def assert_same(tok, orc, sentences, nthreads=8):
+    from kanpyo_amd.tokenizer import pack_sentences
+
+    utf8, offs = pack_sentences(sentences)
+    got_t, got_off, status = tok.tokenize_packed(utf8, offs)
+    exp = orc.tokenize_batch(utf8, offs, nthreads)
+    assert np.array_equal(status, np.zeros(len(sentences), dtype=np.uint8))
+    assert np.array_equal(got_off, exp.offsets), "per-sentence token counts differ"
+    if not np.array_equal(got_t, exp.tokens):
+        bad = np.nonzero(got_t != exp.tokens)[0][0]
+        s = int(np.searchsorted(exp.offsets, bad, side="right") - 1)
+        raise AssertionError(f"token {bad} (sentence {s}: {sentences[s]!r}) differs: gpu {got_t[bad]} oracle {exp.tokens[bad]}")
+    return exp
+
+
+def test_fixture_vectors(libs):
+    """cfg 1 plumbing: the reference's own fixture dictionary + App. C vectors."""
+    from kanpyo_amd import Dict, Tokenizer
+
+    tok = Tokenizer(Dict.from_parts(**fixture_dict_parts()))
+    for case in load_golden("fixture_tokens.json")["cases"]:
+        got = tok.tokenize(case["input"])
+        assert [[t.id, int(t.class_), t.position, t.start, t.end, t.surface] for t in got] == case["tokens"], case["input"]
+    # the reference's own assertions (src/tests.rs:110-171)
+    toks = tok.tokenize("テスト")
+    assert toks and any(t.class_ != 0 for t in toks)
+    assert all(t.start <= t.end <= 3 for t in toks if t.class_ != 0)
+    assert tok.tokenize("") and tok.tokenize("あいうえお")
+
+
+def test_cfg1_literal_sentence(full):
+    sd, tok, orc = full
+    s = "すもももももももものうち"
+    exp = assert_same(tok, orc, [s])
+    toks = tok.tokenize(s)
+    assert toks[-1].surface == "EOS" and toks[-1].position == 36 and toks[-1].start == 12 and toks[-1].end == 15
+    assert "".join(t.surface for t in toks[:-1]) == s  # hiragana: every char is a word in the synthetic lexicon
+
+
+def test_small_dict_corpora(small):
+    from kanpyo_amd import synth
+
+    sd, tok, orc = small
+    assert_same(tok, orc, synth.make_corpus(sd, 3000, 1, "cfg2"))
+    assert_same(tok, orc, synth.make_corpus(sd, 600, 2, "cfg3"))
+    assert_same(tok, orc, synth.make_corpus(sd, 6, 5, "cfg5"))
+
+
+def test_cfg2_full_dict(full):
+    from kanpyo_amd import synth
+
+    sd, tok, orc = full
+    exp = assert_same(tok, orc, synth.make_corpus(sd, 20000, 1, "cfg2"))
+    assert exp.counters["K"] > 20000
+
+
+def test_cfg3_mixed_lengths_unknown_heavy(full):
+    from kanpyo_amd import synth
+
+    sd, tok, orc = full
+    sents = synth.make_corpus(sd, 4000, 2, "cfg3")
+    assert any(any(ord(c) >= 0x10000 for c in s) for s in sents)  # non-BMP -> table[0]
+    assert_same(tok, orc, sents)
+
+
+def test_cfg5_long_documents(full):
+    from kanpyo_amd import synth
+
+    sd, tok, orc = full
+    sents = synth.make_corpus(sd, 24, 5, "cfg5")
+    assert all(len(s) == 2048 for s in sents)
+    assert_same(tok, orc, sents)
+
+
+def test_edge_cases(full):
+    sd, tok, orc = full
+    kata = "ア" * 1500  # one groupable run beyond MAXIMUM_UNKNOWN_WORD_LENGTH (lattice.rs:55,80)
+    cases = [
+        "", "あ", "ア", "a", "0", " ", "　", "𠮷", "𠮷野家", "a\x00b", "\x00", "アアア", kata, "1" * 1024, "1" * 1025,
+        "x" * 1023 + "あ", "漢" * 300, "あ" * 700, "ＡＢＣ１２３", "Ωμέγα", "привет", "東京都に住む。", "、。「」",
+        "あ𠮷" * 40, "\t\n", "é" * 50,
+    ]
+    assert_same(tok, orc, cases)
+    # ragged batch: empties interleaved, single sentence, repeated sentence
+    assert_same(tok, orc, ["", "", "すもも", "", "もも", ""])
+    assert_same(tok, orc, ["すもももももももものうち"] * 257)
+
+
+def test_invalid_utf8_is_flagged_not_tokenized(full):
+    from kanpyo_amd import _lib
+    from kanpyo_amd.tokenizer import pack_sentences
+
+    sd, tok, orc = full
+    sents = [b"ok", b"\xff", "あ".encode(), b"\xe3\x81", b"\x80abc", b"\xc0\xaf", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", "終".encode()]
+    utf8, offs = pack_sentences(sents)
+    t, toff, status = tok.tokenize_packed(utf8, offs)
+    assert status.tolist() == [0, 1, 0, 1, 1, 1, 1, 1, 0]
+    for i, s in enumerate(sents):
+        if status[i]:
+            assert toff[i + 1] == toff[i]
+            with pytest.raises(UnicodeDecodeError):
+                orc.tokenize(s)
+        else:
+            exp, _ = orc.tokenize(s)
+            assert np.array_equal(t[int(toff[i]) : int(toff[i + 1])], exp)
+    assert _lib.KGPU_SENT_INVALID_UTF8 == 1
+
+
+def test_unreachable_eos_and_dead_ends(libs):
+    """Viterbi quirks on hand-made dictionaries."""
+    from kanpyo_amd import Dict, Tokenizer
+
+    _, oracle = libs
+    p = fixture_dict_parts()
+    # negative connection cost lets an UNREACHABLE predecessor win (INF + cost + matrix < INF)
+    p["conn_data"] = [0, 100, 200, 100, -30000, 100, 200, 100, -30000]
+    p["morphs"] = [[0, 0, 1000], [1, 1, -20000], [2, 2, 1100]]
+    d = Dict.from_parts(**p)
+    tok, orc = Tokenizer(d), oracle.OracleTokenizer.from_dict(d)
+    assert_same(tok, orc, ["テ", "テあ", "テ辞書", "テ辞書形態素", "テスト辞書", "ト辞書あ", "辞書テ", "形態素テ形態素", "テテ辞書辞書"], nthreads=1)
+
+
+def test_duplicate_heavy_and_deep_prefix_dictionary(libs):
+    from kanpyo_amd import Dict, Tokenizer
+
+    _, oracle = libs
+    rng = np.random.default_rng(3)
+    kws = []
+    for k in range(1, 41):  # every prefix of a 40-char string is a word, each with many records
+        kws += ["あ" * k] * int(rng.integers(1, 30))
+    kws += ["い"] * 300
+    kws.sort(key=lambda s: s.encode())
+    morphs = np.stack([rng.integers(0, 8, len(kws)), rng.integers(0, 8, len(kws)), rng.integers(-500, 9000, len(kws))], axis=1)
+    p = fixture_dict_parts()
+    d = Dict.from_parts(kws, morphs, 8, 8, rng.integers(-800, 800, 64), p["char_class"], p["char_category"],
+                        p["invoke_list"], p["group_list"], {1: (1, 2), 2: (1, 2)}, [[0, 0, 3000], [1, 1, 3500]])
+    tok, orc = Tokenizer(d), oracle.OracleTokenizer.from_dict(d)
+    assert_same(tok, orc, ["あ" * n for n in (1, 2, 39, 40, 41, 100)] + ["い" * 70, "あいあいあ" * 30, "いあ" * 64], nthreads=1)
+
+
+def test_idempotent_and_order_independent(full):
+    from kanpyo_amd import synth
+    from kanpyo_amd.tokenizer import pack_sentences
+
+    sd, tok, orc = full
+    sents = synth.make_corpus(sd, 5000, 9, "cfg2")
+    a = tok.tokenize_packed(*pack_sentences(sents))
+    b = tok.tokenize_packed(*pack_sentences(sents))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    perm = np.random.default_rng(0).permutation(len(sents))
+    c = tok.tokenize_packed(*pack_sentences([sents[i] for i in perm]))
+    for new_i, old_i in enumerate(perm[:500]):
+        assert np.array_equal(c[0][int(c[1][new_i]) : int(c[1][new_i + 1])], a[0][int(a[1][old_i]) : int(a[1][old_i + 1])])
+
+
+def test_full_size_properties_cfg2(full):
+    """BASELINE configs[1] at full size (100k sentences, batches of 4096): size-
+    independent properties on all of it, oracle equality on a bounded sample."""
+    from kanpyo_amd import synth
+    from kanpyo_amd.tokenizer import pack_sentences
+
+    sd, tok, orc = full
+    sents = synth.make_corpus(sd, 100_000, 1, "cfg2")
+    checked = 0
+    for lo in range(0, len(sents), 4096):
+        chunk = sents[lo : lo + 4096]
+        utf8, offs = pack_sentences(chunk)
+        t, toff, status = tok.tokenize_packed(utf8, offs)
+        assert not status.any()
+        nb = (offs[1:] - offs[:-1]).astype(np.int64)
+        cnt = (toff[1:] - toff[:-1]).astype(np.int64)
+        assert (cnt >= 1).all()  # every category has an unk entry => EOS reachable
+        last = t[toff[1:].astype(np.int64) - 1]
+        assert (last["cls"] == 0).all() and (last["id"] == 0).all() and (last["byte_len"] == 0).all()
+        assert np.array_equal(last["position"].astype(np.int64), nb)  # EOS.position == B
+        assert np.array_equal(last["end"], last["start"] + 3)
+        # tokens tile the sentence: position[k+1] == position[k] + byte_len[k], first at 0
+        sent_of = np.repeat(np.arange(len(chunk)), cnt)
+        first = np.zeros(len(t), dtype=bool); first[toff[:-1].astype(np.int64)] = True
+        assert (t["position"][first] == 0).all() and (t["start"][first] == 0).all()
+        nxt = ~first
+        assert np.array_equal(t["position"][nxt], (t["position"] + t["byte_len"])[np.nonzero(nxt)[0] - 1])
+        words = t["cls"] != 0
+        assert np.array_equal(t["start"][nxt], t["end"][np.nonzero(nxt)[0] - 1])
+        assert (t["id"][words] >= 1).all() and sent_of.size == len(t)
+        if lo % (4096 * 6) == 0:  # oracle equality on every 6th batch
+            exp = orc.tokenize_batch(utf8, offs, 8)
+            assert np.array_equal(toff, exp.offsets) and np.array_equal(t, exp.tokens)
+            checked += 1
+    assert checked >= 4
