@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric: sentences/sec (+ input MiB/s) of
+Tokenizer::tokenize on MI355X, synthetic IPADIC-shaped dictionary.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch of 4096 sentences
+(BASELINE.json configs[1]: 100k synthetic ~40-char sentences, batch=4096), with
+the batch already resident in HBM and the dense token stream left in HBM.
+Multi-GPU is weak scaling: every rank owns its own 100k-sentence shard
+(sentences shard with no data-path collective); the only communication is one
+gatherv of the token records to rank 0 at the end of the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 4096
+N_SENT = 100_000
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(w):
+    """Stage A (lattice build) B+16T+C+16N, Stage B (Viterbi) 8E+14N,
+    Stage C (backtrace+emit) 28K -- all three run inside the one fused kernel."""
+    a = w["B"] + 16 * w["T"] + w["C"] + 16 * w["N"]
+    b = 8 * w["E"] + 14 * w["N"]
+    c = 28 * w["K"]
+    return a, b, c
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--queue", type=int, default=4, help="batches in flight (one ctx/stream each)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="lower bound of CPU-baseline work")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    assert torch.cuda.is_available(), "bench.py needs an MI355X: the HIP path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from kanpyo_amd import Tokenizer, synth
+    from kanpyo_amd.device import PROFILE_EVENTS, PROFILE_OFF, PROFILE_WORK, DeviceContext
+    from kanpyo_amd.dist import gather_tokens
+    from kanpyo_amd.tokenizer import pack_sentences
+
+    # ---- workload: dictionary replicated per GPU, one 100k-sentence shard per rank
+    sd = synth.build_dict()
+    corpus = synth.make_corpus(sd, N_SENT, seed=1 if world == 1 else 100 + rank, kind="cfg2")
+    tok = Tokenizer(sd.dict, device=local_rank)
+    batches = []
+    for lo in range(0, N_SENT - BATCH + 1, BATCH):  # the 24 full batches (the 1696-sentence tail is a parity-test case)
+        utf8, offs = pack_sentences(corpus[lo : lo + BATCH])
+        batches.append((torch.from_numpy(utf8.copy()).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev),
+                        int(offs[-1]), utf8, offs))
+    nb = len(batches)
+    cap = max(b[2] for b in batches) + BATCH  # always sufficient: tokens <= chars + 1 <= bytes + 1
+    K, W, Q = args.steps, args.warmup, max(1, args.queue)
+    ctxs = [DeviceContext(tok) for _ in range(Q)]
+    n_out = max(K, W, 1)
+    out_tok = [torch.empty((cap, 6), dtype=torch.int32, device=dev) for _ in range(min(n_out, 8) if world == 1 else n_out)]
+    out_off = [torch.empty(BATCH + 1, dtype=torch.int64, device=dev) for _ in range(len(out_tok))]
+    out_st = [torch.empty(BATCH, dtype=torch.uint8, device=dev) for _ in range(len(out_tok))]
+
+    def enqueue(i):
+        d_utf8, d_off, total, _, _ = batches[i % nb]
+        o = i % len(out_tok)
+        ctxs[i % Q].tokenize(d_utf8.data_ptr(), d_off.data_ptr(), BATCH, total, out_tok[o].data_ptr(), cap,
+                             out_off[o].data_ptr(), out_st[o].data_ptr())
+
+    def drain():
+        return [c.sync() for c in ctxs]
+
+    # ---- untimed: device-side work counters of every distinct batch (algorithmic bytes)
+    work = {k: 0 for k in ("sentences", "B", "C", "T", "N", "E", "K")}
+    ctxs[0].set_profiling(PROFILE_WORK)
+    for i in range(nb):
+        d_utf8, d_off, total, _, _ = batches[i]
+        ctxs[0].tokenize(d_utf8.data_ptr(), d_off.data_ptr(), BATCH, total, out_tok[0].data_ptr(), cap,
+                         out_off[0].data_ptr(), out_st[0].data_ptr())
+        ctxs[0].sync()
+    for k, v in ctxs[0].work().items():
+        work[k] += v
+    ctxs[0].set_profiling(PROFILE_OFF)
+    sample_tokens = None
+    if rank == 0:  # keep batch 0's GPU result for the bit-exact check in the cpu_baseline leg
+        d_utf8, d_off, total, _, _ = batches[0]
+        ctxs[0].tokenize(d_utf8.data_ptr(), d_off.data_ptr(), BATCH, total, out_tok[0].data_ptr(), cap,
+                         out_off[0].data_ptr(), out_st[0].data_ptr())
+        nt = ctxs[0].sync()
+        sample_tokens = (out_tok[0][:nt].cpu().numpy().copy(), out_off[0].cpu().numpy().copy())
+
+    # ---- warmup
+    for i in range(W):
+        enqueue(i)
+    drain()
+    for c in ctxs:
+        c.set_profiling(PROFILE_EVENTS)
+        c.profile(reset=True)
+
+    # ---- timed region: exactly K steps
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    counts = []
+    for i in range(K):
+        enqueue(i)
+    ntoks = drain()
+    if world > 1:  # the one result gather: token records of all K steps to rank 0 over xGMI
+        per_step = []
+        for i in range(K):
+            o = i % len(out_tok)
+            n_i = int(out_off[o][-1].item())
+            per_step.append(out_tok[o][:n_i])
+            counts.append(out_off[o][1:] - out_off[o][:-1])
+        gathered = gather_tokens(torch.cat(per_step), torch.cat(counts), dst=0)
+        if rank == 0:
+            assert gathered[0].shape[0] == sum(s[0] for s in gathered[2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    prof = {"launches": 0, "tokenize_ms": 0.0, "aux_ms": 0.0}
+    for c in ctxs:
+        p = c.profile(reset=True)
+        for k in prof:
+            prof[k] += p[k]
+        c.set_profiling(PROFILE_OFF)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    sentences = K * BATCH * world
+    bytes_in = sum(batches[i % nb][2] for i in range(K)) * world
+    a, b, c_ = algorithmic_bytes(work)
+    per_launch_bytes = (a + b + c_) / nb
+    avg_kernel_s = prof["tokenize_ms"] / max(prof["launches"], 1) / 1e3
+    achieved = per_launch_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from a separate rocprofv3 --pmc pass
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "sentences/sec", "value": sentences / elapsed, "unit": "sentences/s", "n_gpus": world,
+        "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: 100k synthetic ~40-char sentences per GPU, synthetic IPADIC-shaped "
+                        "dictionary (392k records, 1316x1316 i16 matrix, 11 categories, 40 unk rows), batch=4096 "
+                        "(the 24 full batches cycled), inputs resident in HBM, dense tokens left in HBM",
+            "batch": BATCH, "sentences_per_gpu": N_SENT, "batches_in_flight": Q,
+            "sharding": "sentences round-robin, dictionary replicated, one gatherv of token records to rank 0",
+        },
+        "input_MiB_per_s": bytes_in / elapsed / 2**20,
+        "work_per_sentence": {k: work[k] / work["sentences"] for k in ("B", "C", "T", "N", "E", "K")},
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "kernel": "k_tokenize (fused lattice build + Viterbi + backtrace)",
+            "algorithmic_bytes_per_launch": per_launch_bytes,
+            "stage_bytes_per_launch": {"A_lattice": a / nb, "B_viterbi": b / nb, "C_emit": c_ / nb},
+            "avg_kernel_ms": avg_kernel_s * 1e3, "launches_timed": prof["launches"],
+            "aux_kernels_avg_ms": prof["aux_ms"] / max(prof["launches"], 1),
+        },
+    }
+
+    # ---- CPU baseline (rank 0, N==1 only): the oracle restatement on the host cores
+    if world == 1 and not args.no_cpu:
+        from oracle import oracle
+
+        orc = oracle.OracleTokenizer.from_dict(sd.dict)
+        utf8, offs = pack_sentences(corpus)
+        done, t_cpu, exp0 = 0, 0.0, None
+        while t_cpu < args.cpu_seconds:
+            t1 = time.perf_counter()
+            r = orc.tokenize_batch(utf8, offs, 1)
+            t_cpu += time.perf_counter() - t1
+            done += len(corpus)
+            exp0 = r
+        ncores = os.cpu_count() or 1
+        t1 = time.perf_counter()
+        orc.tokenize_batch(utf8, offs, ncores)
+        t_all = time.perf_counter() - t1
+        # bit-exact check of the GPU's batch 0 against the same sentences from the oracle
+        n0 = int(exp0.offsets[BATCH])
+        g_tok, g_off = sample_tokens
+        exact = bool(np.array_equal(g_off.astype(np.uint64), exp0.offsets[: BATCH + 1])
+                     and np.array_equal(g_tok.reshape(-1), exp0.tokens[:n0].view(np.int32).reshape(-1).astype(np.int32)))
+        result["cpu_baseline"] = {
+            "value": done / t_cpu, "unit": "sentences/s", "cores": 1, "kind": "port",
+            "sample": f"the same 100k-sentence cfg2 corpus, {done // len(corpus)} pass(es), {t_cpu:.1f} s, "
+                      "oracle/kanpyo_oracle.c (CPU restatement of Kanpyo's algorithm, gcc -O2), single thread",
+            "all_cores": {"value": len(corpus) / t_all, "cores": ncores},
+            "gpu_batch0_bit_exact": exact,
+        }
+        result["speedup_vs_cpu_1thread"] = result["value"] / result["cpu_baseline"]["value"]
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,7 +91,8 @@ struct kgpu_ctx {
     // last enqueued batch (for the arena-overflow retry and for sync)
     BatchArgs last{};
     bool pending = false;
-    int n_wg_max = 2048;
+    TierPlan plan{};
+    DevBuf ovf;
     // profiling
     bool profiling = false;   // KGPU_PROFILE_EVENTS
     bool count_work = false;  // KGPU_PROFILE_WORK
@@ -317,7 +318,7 @@ extern "C" int kgpu_ctx_create(kgpu_dict *d, void *hip_stream, kgpu_ctx **out) {
         kgpu_ctx_destroy(c);
         return KGPU_ERR_HIP;
     }
-    c->n_wg_max = tokenize_max_workgroups(d->device);
+    c->plan = default_tier_plan(d->device);
     *out = c;
     return KGPU_OK;
 }
@@ -327,7 +328,7 @@ extern "C" void kgpu_ctx_destroy(kgpu_ctx *c) {
     (void)hipSetDevice(c->dict->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    c->arena.release(); c->stage.release(); c->tok_start.release(); c->tok_count.release();
+    c->arena.release(); c->ovf.release(); c->stage.release(); c->tok_start.release(); c->tok_count.release();
     c->in_utf8.release(); c->in_off.release(); c->out_tok.release(); c->out_off.release(); c->out_status.release();
     if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
@@ -354,8 +355,7 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
         HIPCHECK(hipEventRecord(e0, c->stream));
     }
     if (a.n) {
-        uint64_t wg = std::min<uint64_t>(a.n, (uint64_t)c->n_wg_max);
-        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, (int)wg, c->stream);
+        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, c->stream);
         if (e != hipSuccess) { set_error("k_tokenize launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     }
     if (c->profiling) HIPCHECK(hipEventRecord(e1, c->stream));
@@ -378,12 +378,14 @@ extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const ui
         set_error("kgpu_tokenize_device: null argument");
         return KGPU_ERR_INVALID_ARG;
     }
+    if (n >= (1ull << 32) - 1) { set_error("kgpu_tokenize_device: more than 2^32-2 sentences in one batch; split it"); return KGPU_ERR_INVALID_ARG; }
     if (total_bytes >= (1ull << 32)) { set_error("kgpu_tokenize_device: batch larger than 4 GiB; split it"); return KGPU_ERR_INVALID_ARG; }
     HIPCHECK(hipSetDevice(c->dict->device));
     int rc;
     if (c->pending && (rc = kgpu_ctx_sync(c, nullptr)) != KGPU_OK && rc != KGPU_ERR_CAPACITY) return rc;
     if ((rc = c->arena.ensure(ARENA_INITIAL)) || (rc = c->stage.ensure((size_t)token_capacity * sizeof(kgpu_token) + 64)) ||
-        (rc = c->tok_start.ensure((size_t)(n + 1) * 8)) || (rc = c->tok_count.ensure((size_t)(n + 1) * 4)))
+        (rc = c->tok_start.ensure((size_t)(n + 1) * 8)) || (rc = c->tok_count.ensure((size_t)(n + 1) * 4)) ||
+        (rc = c->ovf.ensure((size_t)(n + 1) * 4 * 3)))
         return rc;
     BatchArgs a{};
     a.utf8 = d_utf8; a.offsets = d_offsets; a.n = n; a.ctl = c->d_ctl;
@@ -392,6 +394,7 @@ extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const ui
     a.tok_start = (uint64_t *)c->tok_start.p; a.tok_count = (uint32_t *)c->tok_count.p;
     a.status = d_status; a.out = d_tokens; a.out_cap = token_capacity; a.tok_offsets = d_tok_offsets;
     a.count_work = c->count_work ? 1u : 0u;
+    for (int k = 0; k < 3; ++k) a.ovf[k] = (uint32_t *)c->ovf.p + (size_t)k * (n + 1);
     return enqueue(c, a);
 }
 

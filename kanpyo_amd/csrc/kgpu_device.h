@@ -1,0 +1,123 @@
+// kanpyo_amd/csrc/kgpu_device.h -- device-side helpers shared by the tokenize
+// kernels (general: kgpu_kernels.hip, LDS-resident: kgpu_lds.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kgpu_internal.h"
+
+namespace kgpu {
+namespace dev {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr int32_t INF = 1 << 30;               // lattice.rs:117
+constexpr uint32_t MAX_UNKNOWN_LEN = 1024;     // lattice.rs:55
+
+__device__ __forceinline__ uint32_t bcast32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t bcast64(uint64_t v) {
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t ld_l2(const uint32_t *p) {  // bypass the CU's L1
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+struct Slab {
+    uint8_t *ptr;
+    uint64_t size;
+};
+
+// Grow-only slab owned by this wavefront, carved from the ctx arena.
+__device__ __forceinline__ bool slab_ensure(Slab &s, uint64_t need, const BatchArgs &a, uint32_t lane) {
+    if (need <= s.size) return true;
+    uint64_t want = round_up(need + need / 2 + 256, 256);
+    uint64_t off = 0;
+    if (lane == 0) off = atomicAdd(&a.ctl->arena_cursor, (unsigned long long)want);
+    off = bcast64(off);
+    if (off + want > a.arena_bytes) {
+        if (lane == 0) atomicExch(&a.ctl->arena_overflow, 1u);
+        return false;
+    }
+    s.ptr = a.arena + off;
+    s.size = want;
+    return true;
+}
+
+// One double-array walk from byte k0 of the sentence (trie/da.rs:155-182).
+// F(id, byte_len_so_far_chars, morph_of_first) is invoked per match in
+// ascending byte length.  Returns nothing; `matched` is set by the callback.
+template <class F>
+__device__ __forceinline__ uint32_t da_walk(const DictView &d, const uint8_t *text, uint32_t k, uint32_t B,
+                                            int32_t base_root, F &&on_match) {
+    int32_t p = 1;  // ROOT_ID
+    int32_t bp = base_root;
+    uint32_t nch = 0, steps = 0;
+    for (; k < B; ++k) {
+        uint32_t c = text[k];
+        ++steps;
+        int32_t q = bp + (int32_t)c;
+        if ((uint32_t)q >= d.da_len) break;  // negative or past the end: "None" (da.rs:162)
+        DaNode nd = d.da[q];
+        if (nd.check != p) break;
+        p = q;
+        bp = nd.base;
+        nch += (c & 0xC0) != 0x80;
+        int32_t ah = bp;  // + TERMINATOR (da.rs:166)
+        if ((uint32_t)ah < d.da_len) {
+            DaNode t = d.da[ah];
+            if (t.check == p && t.base < 0) on_match((uint32_t)(-t.base), nch);
+        }
+    }
+    return steps;
+}
+
+
+// Work-list plumbing shared by the tier kernels: tier k pulls sentence ids from
+// list `in_list` (nullptr = identity over [0, n)) and pushes the ones whose
+// lattice does not fit its memory budget onto the next tier's list.
+struct TierIO {
+    const uint32_t *in_list;        // nullptr: sentence id == queue index
+    const unsigned int *in_count;   // nullptr: a.n
+    unsigned int *queue;            // dequeue cursor of this tier
+    uint32_t *out_list;             // overflow list for the next tier (nullptr: none)
+    unsigned int *out_count;
+};
+
+// Dequeue one work item for the whole wavefront.  There is deliberately no
+// `if (lane == 0) x = atomicAdd(..); x = readfirstlane(x);` here: hipcc (ROCm 7.2)
+// restructured the persistent loop around that pattern so that an early
+// `continue` re-ran the body with a stale index (hang on every deferral).
+// Instead every lane issues the add, lane 0 adding 1 and the others 0: lane 0's
+// return value is the ticket whether or not the atomic optimizer folds the wave's
+// adds into one.
+__device__ __forceinline__ bool tier_next(const TierIO &io, const BatchArgs &a, uint32_t lane, uint64_t &s) {
+    const uint32_t ticket = atomicAdd(io.queue, lane == 0 ? 1u : 0u);
+    const uint64_t i = bcast32(ticket);
+    const uint64_t n = io.in_count ? (uint64_t)bcast32(__hip_atomic_load(io.in_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : a.n;
+    if (i >= n) return false;
+    s = io.in_list ? (uint64_t)bcast32(io.in_list[i]) : i;
+    return true;
+}
+__device__ __forceinline__ void tier_defer(const TierIO &io, uint32_t lane, uint64_t s) {
+    if (lane == 0) {
+        unsigned int k = atomicAdd(io.out_count, 1u);
+        io.out_list[k] = (uint32_t)s;
+    }
+}
+
+}  // namespace dev
+}  // namespace kgpu

@@ -40,7 +40,8 @@ struct DictView {
 
 // ---- per-ctx control block in device memory (zeroed before every batch) ---
 struct Control {
-    unsigned long long queue_head;    // next sentence index to dequeue
+    unsigned int queue_head[4];       // per-tier dequeue cursors (a batch has < 2^32 sentences)
+    unsigned int ovf_count[4];        // sentences deferred from tier k to tier k+1
     unsigned long long arena_cursor;  // bump allocator over the scratch arena (bytes)
     unsigned long long tok_cursor;    // bump allocator over the staging tokens
     unsigned int arena_overflow;      // a slab request did not fit
@@ -62,11 +63,23 @@ struct BatchArgs {
     kgpu_token *out;  uint64_t out_cap;      // dense output
     uint64_t *tok_offsets;        // n+1
     uint32_t count_work;          // accumulate kgpu_work into ctl->work (slow; off in timed runs)
+    uint32_t *ovf[3];             // n entries each: work lists of tiers 1.. (filled by the tier before)
+};
+
+// Memory tiers of the fused tokenize kernel: tier k keeps the whole lattice of a
+// sentence in `lds_bytes` of LDS (one 64-lane workgroup per sentence); what does
+// not fit is deferred to the next tier; the last tier is the general kernel
+// whose lattice lives in HBM scratch.
+struct TierPlan {
+    int n_lds_tiers;
+    uint32_t lds_bytes[3];
+    int workgroups[3];       // persistent grid per LDS tier
+    int general_workgroups;
 };
 
 // Launchers (kgpu_kernels.hip).  `stream` is a hipStream_t.
-int launch_tokenize(const DictView &d, const BatchArgs &a, int n_workgroups, void *stream);
+int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan, void *stream);
 int launch_scan_compact(const BatchArgs &a, void *stream);
-int tokenize_max_workgroups(int device);
+TierPlan default_tier_plan(int device);
 
 }  // namespace kgpu

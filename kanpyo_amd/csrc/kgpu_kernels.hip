@@ -22,101 +22,22 @@
 // bump-allocated HBM scratch slab, so any sentence length / lattice size works.
 #include <hip/hip_runtime.h>
 
-#include "kgpu_internal.h"
+#include <cstdlib>
+
+#include "kgpu_device.h"
 
 namespace kgpu {
 
-namespace {
+using namespace dev;
 
-constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr int32_t INF = 1 << 30;               // lattice.rs:117
-constexpr uint32_t MAX_UNKNOWN_LEN = 1024;     // lattice.rs:55
-
-__device__ __forceinline__ uint32_t bcast32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint64_t bcast64(uint64_t v) {
-    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= (uint32_t)d) v += t;
-    }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-__device__ __forceinline__ uint32_t ld_l2(const uint32_t *p) {  // bypass the CU's L1
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
-
-struct Slab {
-    uint8_t *ptr;
-    uint64_t size;
-};
-
-// Grow-only slab owned by this wavefront, carved from the ctx arena.
-__device__ __forceinline__ bool slab_ensure(Slab &s, uint64_t need, const BatchArgs &a, uint32_t lane) {
-    if (need <= s.size) return true;
-    uint64_t want = round_up(need + need / 2 + 256, 256);
-    uint64_t off = 0;
-    if (lane == 0) off = atomicAdd(&a.ctl->arena_cursor, (unsigned long long)want);
-    off = bcast64(off);
-    if (off + want > a.arena_bytes) {
-        if (lane == 0) atomicExch(&a.ctl->arena_overflow, 1u);
-        return false;
-    }
-    s.ptr = a.arena + off;
-    s.size = want;
-    return true;
-}
-
-// One double-array walk from byte k0 of the sentence (trie/da.rs:155-182).
-// F(id, byte_len_so_far_chars, morph_of_first) is invoked per match in
-// ascending byte length.  Returns nothing; `matched` is set by the callback.
-template <class F>
-__device__ __forceinline__ uint32_t da_walk(const DictView &d, const uint8_t *text, uint32_t k, uint32_t B,
-                                            int32_t base_root, F &&on_match) {
-    int32_t p = 1;  // ROOT_ID
-    int32_t bp = base_root;
-    uint32_t nch = 0, steps = 0;
-    for (; k < B; ++k) {
-        uint32_t c = text[k];
-        ++steps;
-        int32_t q = bp + (int32_t)c;
-        if ((uint32_t)q >= d.da_len) break;  // negative or past the end: "None" (da.rs:162)
-        DaNode nd = d.da[q];
-        if (nd.check != p) break;
-        p = q;
-        bp = nd.base;
-        nch += (c & 0xC0) != 0x80;
-        int32_t ah = bp;  // + TERMINATOR (da.rs:166)
-        if ((uint32_t)ah < d.da_len) {
-            DaNode t = d.da[ah];
-            if (t.check == p && t.base < 0) on_match((uint32_t)(-t.base), nch);
-        }
-    }
-    return steps;
-}
-
-}  // namespace
-
-__global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a) {
+__global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a, TierIO io) {
     const uint32_t lane = threadIdx.x;
     Slab sa{nullptr, 0}, sn{nullptr, 0};
     const int32_t base_root = d.da[1].base;
 
     for (;;) {
         uint64_t s = 0;
-        if (lane == 0) s = atomicAdd(&a.ctl->queue_head, 1ull);
-        s = bcast64(s);
-        if (s >= a.n) break;
+        if (!tier_next(io, a, lane, s)) break;
 
         const uint64_t b0 = a.offsets[s];
         const uint32_t B = (uint32_t)(a.offsets[s + 1] - b0);
@@ -166,7 +87,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             }
             C += __popcll(m);
         }
-        lensum = wave_sum(lensum);
+        lensum = bcast32(wave_sum(lensum));  // keep every early exit wave-uniform (SGPR) for the compiler
         if (__ballot(bad != 0) != 0 || lensum != B) {  // stray continuation bytes leave lensum < B
             if (lane == 0) { a.status[s] = KGPU_SENT_INVALID_UTF8; a.tok_count[s] = 0; a.tok_start[s] = 0; }
             continue;
@@ -229,7 +150,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             ncarry += __shfl(vs, 63, 64);
             bcarry += __shfl(ws, 63, 64);
         }
-        const uint32_t N = ncarry;  // BOS + words + EOS
+        const uint32_t N = bcast32(ncarry);  // BOS + words + EOS (scalarised: the slab test must be wave-uniform)
         __syncthreads();
 
         // ---- slab N: per-node arrays -----------------------------------------------
@@ -314,7 +235,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         uint32_t K = 0;
         if (lane == 0) {
             uint32_t pos = N - 1, pr;
-            while ((pr = pre[pos]) != NONE) { path[K++] = pos; pos = pr; }
+            while ((pr = pre[pos]) != NONE && K <= C) { path[K++] = pos; pos = pr; }  // K <= C + 1 always; bound the walk anyway
         }
         K = bcast32(K);
         uint64_t ts = 0;
@@ -399,12 +320,34 @@ __global__ __launch_bounds__(256) void k_compact(BatchArgs a) {
     }
 }
 
-int launch_tokenize(const DictView &d, const BatchArgs &a, int n_workgroups, void *stream) {
-    hipLaunchKernelGGL(k_tokenize_general, dim3(n_workgroups), dim3(64), 0, (hipStream_t)stream, d, a);
+int launch_tokenize_lds(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t lds_bytes, int n_workgroups,
+                        void *stream);  // kgpu_lds.hip
+
+// Tier chain: LDS tiers in ascending LDS size, then the general (HBM scratch)
+// kernel.  Every launch is a persistent grid pulling from its tier's work list.
+int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan, void *stream) {
+    Control *ctl = a.ctl;
+    const uint32_t *in_list = nullptr;
+    const unsigned int *in_count = nullptr;
+    for (int k = 0; k < plan.n_lds_tiers; ++k) {
+        TierIO io{in_list, in_count, &ctl->queue_head[k], a.ovf[k], &ctl->ovf_count[k]};
+        uint64_t wg = plan.workgroups[k];
+        if (k == 0 && a.n < wg) wg = a.n;
+        int e = launch_tokenize_lds(d, a, io, plan.lds_bytes[k], (int)(wg ? wg : 1), stream);
+        if (e) return e;
+        in_list = a.ovf[k];
+        in_count = &ctl->ovf_count[k];
+    }
+    if (getenv("KGPU_DEBUG_SKIP_GENERAL")) return 0;
+    TierIO io{in_list, in_count, &ctl->queue_head[plan.n_lds_tiers], nullptr, nullptr};
+    uint64_t wg = plan.general_workgroups;
+    if (plan.n_lds_tiers == 0 && a.n < wg) wg = a.n;
+    hipLaunchKernelGGL(k_tokenize_general, dim3((unsigned)(wg ? wg : 1)), dim3(64), 0, (hipStream_t)stream, d, a, io);
     return (int)hipGetLastError();
 }
 
 int launch_scan_compact(const BatchArgs &a, void *stream) {
+    if (getenv("KGPU_DEBUG_SKIP_AUX")) return 0;
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     uint64_t blocks = (a.n + 3) / 4;
     if (blocks > 2048) blocks = 2048;
@@ -413,10 +356,31 @@ int launch_scan_compact(const BatchArgs &a, void *stream) {
     return (int)hipGetLastError();
 }
 
-int tokenize_max_workgroups(int device) {
+TierPlan default_tier_plan(int device) {
     hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, device) != hipSuccess) return 2048;
-    return p.multiProcessorCount * 16;  // 16 single-wave workgroups per CU
+    int cus = 256;
+    if (hipGetDeviceProperties(&p, device) == hipSuccess) cus = p.multiProcessorCount;
+    TierPlan t{};
+    t.n_lds_tiers = 2;
+    t.lds_bytes[0] = 20 * 1024;   t.workgroups[0] = cus * 8;  // 8 sentences per CU in flight (160 KB / 20 KB)
+    t.lds_bytes[1] = 160 * 1024;  t.workgroups[1] = cus;      // one long sentence owns a CU's whole LDS
+    t.general_workgroups = cus * 8;
+    if (const char *e = getenv("KGPU_TIERS")) {  // e.g. "20,64,160" (KiB) or "0" for the general kernel only
+        t.n_lds_tiers = 0;
+        const char *q = e;
+        while (*q && t.n_lds_tiers < 3) {
+            int kib = atoi(q);
+            if (kib > 0 && kib <= 160) {
+                t.lds_bytes[t.n_lds_tiers] = (uint32_t)kib * 1024;
+                t.workgroups[t.n_lds_tiers] = cus * (160 / kib);
+                ++t.n_lds_tiers;
+            }
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
+    if (const char *e = getenv("KGPU_GENERAL_WG")) { int v = atoi(e); if (v > 0) t.general_workgroups = v; }
+    return t;
 }
 
 }  // namespace kgpu

@@ -1,0 +1,407 @@
+// kanpyo_amd/csrc/kgpu_lds.hip -- LDS-resident fused tokenize kernel (gfx950).
+//
+// Same algorithm and phase structure as the general kernel (kgpu_kernels.hip),
+// but the whole lattice of a sentence lives in the CU's LDS (160 KB per CU on
+// MI355X) and the Viterbi dependency chain touches nothing but LDS and
+// registers:
+//
+//   * one double-array walk per start position; its matches (trie id, char
+//     length) are parked in an LDS match buffer so the emit phase re-walks
+//     nothing (trie/da.rs:155-182 once per position);
+//   * every connection cost the sweep will need -- M[right(j)][left(t)] for each
+//     (target t, predecessor j) pair, connection.rs:12-14 -- depends only on the
+//     morph ids, not on the DP values, so all of them are gathered from HBM/L2
+//     into an LDS pair table in ONE parallel pass before the sweep ("the
+//     connection matrix tiled through LDS"); the sweep itself then runs at LDS
+//     latency;
+//   * per position the (target, predecessor) pairs are spread across the 64
+//     lanes, each target owning an aligned power-of-two lane group, and the
+//     strict-'<' first-minimum of lattice.rs:125-139 is a DPP butterfly
+//     min-reduction on the 64-bit key (total ^ signbit, predecessor node index).
+//
+// One 64-lane workgroup per sentence, so no s_barrier anywhere; occupancy is
+// set by the dynamic LDS size of the tier (see TierPlan).  A sentence that does
+// not fit the tier's LDS (or has > MAXM dictionary prefixes at one position) is
+// deferred, untouched, to the next tier.
+#include "kgpu_device.h"
+
+namespace kgpu {
+
+using namespace dev;
+
+namespace {
+
+constexpr uint32_t MAXM = 8;         // trie matches buffered per start position
+constexpr uint32_t NONE16 = 0xFFFFu;
+
+// ---- DPP butterfly: min over aligned groups of 2^lg lanes, every lane gets it.
+template <int CTRL>
+__device__ __forceinline__ void dpp_min_step(uint32_t &hi, uint32_t &lo) {
+    const uint32_t oh = (uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xF, 0xF, false);
+    const uint32_t ol = (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xF, 0xF, false);
+    if (oh < hi || (oh == hi && ol < lo)) { hi = oh; lo = ol; }
+}
+__device__ __forceinline__ void shfl_min_step(uint32_t &hi, uint32_t &lo, int d) {
+    const uint32_t oh = (uint32_t)__shfl_xor((int)hi, d, 64);
+    const uint32_t ol = (uint32_t)__shfl_xor((int)lo, d, 64);
+    if (oh < hi || (oh == hi && ol < lo)) { hi = oh; lo = ol; }
+}
+__device__ __forceinline__ void group_min(uint32_t &hi, uint32_t &lo, uint32_t lg) {  // lg wave-uniform
+    if (lg >= 1) dpp_min_step<0xB1>(hi, lo);   // quad_perm [1,0,3,2]
+    if (lg >= 2) dpp_min_step<0x4E>(hi, lo);   // quad_perm [2,3,0,1]
+    if (lg >= 3) dpp_min_step<0x141>(hi, lo);  // row_half_mirror
+    if (lg >= 4) dpp_min_step<0x140>(hi, lo);  // row_mirror
+    if (lg >= 5) shfl_min_step(hi, lo, 16);
+    if (lg >= 6) shfl_min_step(hi, lo, 32);
+}
+
+__device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, TierIO io, uint32_t lds_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t lane = threadIdx.x;
+    const int32_t base_root = d.da[1].base;
+
+    for (;;) {
+        uint64_t s = 0;
+        if (!tier_next(io, a, lane, s)) break;
+        const uint64_t b0 = a.offsets[s];
+        const uint64_t Bl = a.offsets[s + 1] - b0;
+        if (Bl + 64 > lds_bytes || Bl > 0xFFF0) { tier_defer(io, lane, s); continue; }
+        const uint32_t B = (uint32_t)Bl;
+        const uint8_t *gtext = a.utf8 + b0;
+
+        // ---- phase 0a: stage the sentence in LDS, count chars -----------------
+        uint8_t *text = smem;
+        uint32_t C = 0;
+        for (uint32_t k0 = 0; k0 < B + 4; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const uint32_t b = k < B ? gtext[k] : 0x80u;
+            if (k < B + 4) text[k] = (uint8_t)b;
+            C += __popcll(__ballot(k < B && (b & 0xC0) != 0x80));
+        }
+        // ---- LDS carve: per-char arrays from the bottom, match buffer from the top
+        uint32_t off = align_up(B + 4, 4);
+        uint32_t *nb = (uint32_t *)(smem + off);    off += 4 * (C + 2);  // node count -> first node index
+        uint32_t *boff = (uint32_t *)(smem + off);  off += 4 * (C + 2);  // bucket count -> offset (edges[e])
+        uint32_t *bfill = (uint32_t *)(smem + off); off += 4 * (C + 2);  // bucket fill cursor
+        uint32_t *ebase = (uint32_t *)(smem + off); off += 4 * (C + 2);  // first pair index per position
+        uint16_t *cbyte = (uint16_t *)(smem + off); off += 2 * (C + 2);  // char -> byte offset
+        uint16_t *uspan = (uint16_t *)(smem + off); off += 2 * (C + 2);  // unknown span (0 = none)
+        uint16_t *path = (uint16_t *)(smem + off);  off += 2 * (C + 2);  // backtrace
+        uint8_t *ccat = smem + off;                 off += align_up(C + 2, 4);
+        uint8_t *mcnt = smem + off;                 off += align_up(C + 2, 4);
+        const uint32_t mbytes = align_up(C * MAXM * 5, 16);
+        if (off + mbytes > lds_bytes) { tier_defer(io, lane, s); continue; }
+        const uint32_t moff = (lds_bytes - mbytes) & ~15u;
+        uint32_t *mid = (uint32_t *)(smem + moff);           // [C][MAXM] trie ids
+        uint8_t *mnch = smem + moff + 4 * C * MAXM;          // [C][MAXM] match length in chars
+        __syncthreads();
+
+        // ---- phase 0b: decode + validate + category --------------------------------
+        uint32_t cb = 0, bad = 0, lensum = 0;
+        for (uint32_t k0 = 0; k0 < B; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const uint32_t b = k < B ? text[k] : 0x80u;
+            const bool start = k < B && (b & 0xC0) != 0x80;
+            const uint64_t m = __ballot(start);
+            const uint32_t ci = cb + __popcll(m & ((1ull << lane) - 1));
+            if (start) {
+                uint32_t l, cp;
+                if (b < 0x80) { l = 1; cp = b; }
+                else if (b >= 0xC2 && b <= 0xDF) { l = 2; cp = b & 0x1F; }
+                else if ((b & 0xF0) == 0xE0) { l = 3; cp = b & 0x0F; }
+                else if (b >= 0xF0 && b <= 0xF4) { l = 4; cp = b & 0x07; }
+                else { l = 1; cp = 0; bad = 1; }
+                if (k + l > B) { bad = 1; l = 1; }
+                for (uint32_t j = 1; j < l; ++j) {
+                    const uint32_t bb = text[k + j];
+                    if ((bb & 0xC0) != 0x80) bad = 1;
+                    cp = (cp << 6) | (bb & 0x3F);
+                }
+                if (l == 3 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) bad = 1;
+                if (l == 4 && (cp < 0x10000 || cp > 0x10FFFF)) bad = 1;
+                lensum += l;
+                cbyte[ci] = (uint16_t)k;
+                ccat[ci] = bad ? 0 : (cp < d.cat_len ? d.cat[cp] : d.cat[0]);  // char_category_def.rs:33-38
+            }
+            cb += __popcll(m);
+        }
+        lensum = bcast32(wave_sum(lensum));  // keep every early exit wave-uniform (SGPR) for the compiler
+        if (__ballot(bad != 0) != 0 || lensum != B) {
+            if (lane == 0) { a.status[s] = KGPU_SENT_INVALID_UTF8; a.tok_count[s] = 0; a.tok_start[s] = 0; }
+            continue;
+        }
+        if (lane == 0) cbyte[C] = (uint16_t)B;
+        for (uint32_t e = lane; e < C + 2; e += 64) { boff[e] = 0; bfill[e] = 0; }
+        __syncthreads();
+
+        // ---- phase 1: one trie walk per start position; count + park matches ------
+        uint32_t wT = 0, ovf = 0;
+        {
+            const int nchunks = (int)((C + 63) / 64);
+            uint32_t carry_end = C;
+            for (int ch = nchunks - 1; ch >= 0; --ch) {
+                const uint32_t i = (uint32_t)ch * 64 + lane;
+                const bool active = i < C;
+                const uint32_t cat = active ? ccat[i] : 0x1FFu;
+                const uint32_t ncat = (i + 1 < C) ? ccat[i + 1] : 0x2FFu;
+                const uint64_t bm = __ballot(active && ncat != cat);
+                const uint64_t rest = bm >> lane;
+                const uint32_t run_end = rest ? i + (uint32_t)__ffsll((unsigned long long)rest) : carry_end;
+                carry_end = bcast32(run_end);
+                if (active) {
+                    uint32_t cnt = 0, m = 0;
+                    wT += da_walk(d, text, cbyte[i], B, base_root, [&](uint32_t id, uint32_t nch) {
+                        if (m < MAXM && nch < 256) { mid[i * MAXM + m] = id; mnch[i * MAXM + m] = (uint8_t)nch; }
+                        else ovf = 1;
+                        ++m;
+                        const uint32_t nrec = 1u + d.morph[id - 1].dup;  // index.rs:46-51
+                        cnt += nrec;
+                        atomicAdd(&boff[i + nch], nrec);
+                    });
+                    mcnt[i] = (uint8_t)(m < MAXM ? m : MAXM);
+                    const CatInfo ci = d.cinfo[cat];
+                    uint32_t span = 0;
+                    if ((cnt == 0 || (ci.flags & CAT_INVOKE)) && (ci.flags & CAT_HAS_UNK) && ci.unk_count) {  // lattice.rs:54,87-92
+                        span = 1;
+                        if (ci.flags & CAT_GROUP) {  // lattice.rs:66-84
+                            const uint32_t r = run_end - i;
+                            span = r < MAX_UNKNOWN_LEN ? r : MAX_UNKNOWN_LEN;
+                        }
+                        cnt += ci.unk_count;
+                        atomicAdd(&boff[i + span], ci.unk_count);
+                    }
+                    uspan[i] = (uint16_t)span;
+                    nb[i] = cnt;
+                }
+            }
+        }
+        if (__ballot(ovf != 0) != 0) { tier_defer(io, lane, s); continue; }
+        if (lane == 0) {
+            nb[C] = 1;       // EOS starts at C (lattice.rs:165-175)
+            nb[C + 1] = 0;
+            atomicAdd(&boff[0], 1u);  // BOS ends at 0 (lattice.rs:156-164)
+        }
+        __syncthreads();
+
+        // ---- phase 2: prefix sums: node numbering, bucket offsets, pair offsets ------
+        uint32_t ncarry = 1, bcarry = 0, ecarry = 0, maxpairs = 0;
+        for (uint32_t i0 = 0; i0 < C + 2; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const uint32_t v = i < C + 2 ? nb[i] : 0;    // targets starting at i
+            const uint32_t w = i < C + 2 ? boff[i] : 0;  // predecessors ending at i
+            const uint32_t x = v * w;                    // relaxations at i (lattice.rs:122-125)
+            const uint32_t vs = wave_incl_scan(v, lane), ws = wave_incl_scan(w, lane), xs = wave_incl_scan(x, lane);
+            if (i < C + 2) { nb[i] = ncarry + vs - v; boff[i] = bcarry + ws - w; ebase[i] = ecarry + xs - x; }
+            ncarry += __shfl(vs, 63, 64);
+            bcarry += __shfl(ws, 63, 64);
+            ecarry += __shfl(xs, 63, 64);
+            maxpairs = max(maxpairs, x);
+        }
+#pragma unroll
+        for (int dd = 32; dd > 0; dd >>= 1) maxpairs = max(maxpairs, (uint32_t)__shfl_xor((int)maxpairs, dd, 64));
+        // scalarise: the carve and the fit test below must be wave-uniform branches
+        const uint32_t N = bcast32(ncarry), Nb = bcast32(bcarry), E = bcast32(ecarry);
+        maxpairs = bcast32(maxpairs);
+
+        // ---- LDS carve, part 2: node arrays, buckets, pair table ---------------------
+        uint32_t *nLR = (uint32_t *)(smem + off);   off += 4 * N;   // left | right << 16
+        int32_t *nSid = (int32_t *)(smem + off);    off += 4 * N;   // +id known, -id unknown, 0 dummy
+        uint32_t *bri = (uint32_t *)(smem + off);   off += 4 * Nb;  // bucket: right | node << 16
+        int16_t *nCost = (int16_t *)(smem + off);   off += 2 * N;
+        uint16_t *nSlot = (uint16_t *)(smem + off); off += 2 * N;   // bucket slot of the node
+        uint16_t *nStart = (uint16_t *)(smem + off); off += 2 * N;
+        uint16_t *nEnd = (uint16_t *)(smem + off);  off += 2 * N;
+        off = align_up(off, 4);
+        const uint32_t off_emit_end = off;                          // everything above is written by emit
+        int32_t *bdp = (int32_t *)(smem + off);     off += 4 * Nb;  // bucket: dp (may overlay the match buffer)
+        uint16_t *pre = (uint16_t *)(smem + off);   off += align_up(2 * N, 4);
+        int16_t *mpair = (int16_t *)(smem + off);
+        const uint32_t mcap = off < lds_bytes ? (lds_bytes - off) / 2 : 0;
+        if (N > 0xFFFF || off_emit_end > moff || off > lds_bytes || mcap < maxpairs) {
+            tier_defer(io, lane, s);
+            continue;
+        }
+        __syncthreads();
+
+        // ---- phase 3: emit nodes from the parked matches --------------------------------
+        for (uint32_t i = lane; i < C; i += 64) {
+            uint32_t t = nb[i];
+            const uint32_t nm = mcnt[i];
+            for (uint32_t m = 0; m < nm; ++m) {
+                const uint32_t id = mid[i * MAXM + m];
+                const uint32_t end = i + mnch[i * MAXM + m];
+                const uint32_t nrec = 1u + d.morph[id - 1].dup;
+                for (uint32_t r = 0; r < nrec; ++r) {  // lattice.rs:177-188
+                    const Morph8 mm = d.morph[id - 1 + r];
+                    const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
+                    nLR[t] = (uint16_t)mm.left | ((uint32_t)(uint16_t)mm.right << 16);
+                    nCost[t] = mm.cost; nSlot[t] = (uint16_t)slot; nStart[t] = (uint16_t)i; nEnd[t] = (uint16_t)end;
+                    nSid[t] = (int32_t)(id + r);
+                    bri[slot] = (uint32_t)(uint16_t)mm.right | (t << 16);
+                    ++t;
+                }
+            }
+            const uint32_t span = uspan[i];
+            if (span) {  // lattice.rs:87-97,190-201
+                const CatInfo ci = d.cinfo[ccat[i]];
+                const uint32_t end = i + span;
+                for (uint32_t r = 0; r < ci.unk_count; ++r) {
+                    const Morph8 mm = d.unk_morph[ci.unk_first - 1 + (int32_t)r];
+                    const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
+                    nLR[t] = (uint16_t)mm.left | ((uint32_t)(uint16_t)mm.right << 16);
+                    nCost[t] = mm.cost; nSlot[t] = (uint16_t)slot; nStart[t] = (uint16_t)i; nEnd[t] = (uint16_t)end;
+                    nSid[t] = -(ci.unk_first + (int32_t)r);
+                    bri[slot] = (uint32_t)(uint16_t)mm.right | (t << 16);
+                    ++t;
+                }
+            }
+        }
+        if (lane == 0) {
+            nLR[N - 1] = 0; nCost[N - 1] = 0; nSlot[N - 1] = NONE16;  // EOS: Morph(0,0,0)
+            nStart[N - 1] = (uint16_t)C; nEnd[N - 1] = (uint16_t)C; nSid[N - 1] = 0;
+            bri[0] = 0;  // BOS: right_id 0, node 0
+        }
+        __syncthreads();
+        if (lane == 0) { bdp[0] = 0; pre[0] = NONE16; }  // BOS: dp None -> 0 (lattice.rs:127)
+
+        // ---- phases 3b + 4, per block of positions whose pairs fit the pair table ----
+        uint32_t qa = 0;
+        while (qa <= C) {
+            uint32_t qb;
+            if (E - ebase[qa] <= mcap) qb = C + 1;
+            else {  // largest qb with ebase[qb] - ebase[qa] <= mcap (ebase is non-decreasing)
+                uint32_t lo = qa + 1, hi = C + 1;  // invariant: ebase[lo] - ebase[qa] <= mcap (a single position fits)
+                while (lo < hi) {
+                    const uint32_t mid_ = (lo + hi + 1) / 2;
+                    if (ebase[mid_] - ebase[qa] <= mcap) lo = mid_; else hi = mid_ - 1;
+                }
+                qb = lo;
+            }
+            const uint32_t eb0 = ebase[qa];
+            // -- 3b: gather every connection cost of the block into LDS (connection.rs:12-14)
+            const uint32_t ta = nb[qa], tb = nb[qb];
+            for (uint32_t t = ta + lane; t < tb; t += 64) {
+                const uint32_t q = nStart[t];
+                const uint32_t p0 = boff[q], P = boff[q + 1] - p0;
+                const uint32_t base = ebase[q] - eb0 + (t - nb[q]) * P;
+                const int16_t *col = d.conn + (size_t)d.conn_rows * (nLR[t] & 0xFFFFu);
+                uint32_t j = 0;
+                for (; j + 4 <= P; j += 4) {  // 4 independent gathers in flight per lane
+                    const uint32_t r0 = bri[p0 + j] & 0xFFFFu, r1 = bri[p0 + j + 1] & 0xFFFFu;
+                    const uint32_t r2 = bri[p0 + j + 2] & 0xFFFFu, r3 = bri[p0 + j + 3] & 0xFFFFu;
+                    const int16_t c0 = col[r0], c1 = col[r1], c2 = col[r2], c3 = col[r3];
+                    mpair[base + j] = c0; mpair[base + j + 1] = c1; mpair[base + j + 2] = c2; mpair[base + j + 3] = c3;
+                }
+                for (; j < P; ++j) mpair[base + j] = col[bri[p0 + j] & 0xFFFFu];
+            }
+            __syncthreads();
+
+            // -- 4: Viterbi sweep over the block (lattice.rs:116-142), LDS only
+            uint32_t t0 = ta, p0 = boff[qa];
+            for (uint32_t q = qa; q < qb; ++q) {
+                const uint32_t t1 = nb[q + 1], p1 = boff[q + 1];
+                const uint32_t T = t1 - t0, P = p1 - p0;
+                const uint32_t eb = ebase[q] - eb0;
+                if (P == 0) {  // nothing ends here: every target stays at INF with no predecessor
+                    for (uint32_t t = t0 + lane; t < t1; t += 64) {
+                        pre[t] = NONE16;
+                        const uint32_t sl = nSlot[t];
+                        if (sl != NONE16) bdp[sl] = INF;
+                    }
+                } else if (T) {
+                    uint32_t lg = 32 - __clz(P - 1);  // ceil(log2 P), 0 for P == 1
+                    if (P == 1) lg = 0;
+                    if (lg > 6) lg = 6;
+                    const uint32_t j = lane & ((1u << lg) - 1), tl = lane >> lg, TG = 64u >> lg;
+                    for (uint32_t tbase = 0; tbase < T; tbase += TG) {
+                        const uint32_t ti = tbase + tl;
+                        const bool tvalid = ti < T;
+                        uint32_t khi = 0xFFFFFFFFu, klo = 0xFFFFFFFFu;
+                        for (uint32_t jc = 0; jc < P; jc += 64) {
+                            const uint32_t jj = jc + j;
+                            uint32_t chi = 0xFFFFFFFFu, clo = 0xFFFFFFFFu;
+                            if (tvalid && jj < P) {
+                                const int32_t v = bdp[p0 + jj] + (int32_t)mpair[eb + ti * P + jj];
+                                chi = (uint32_t)v ^ 0x80000000u;
+                                clo = bri[p0 + jj] >> 16;
+                            }
+                            group_min(chi, clo, lg);
+                            if (chi < khi || (chi == khi && clo < klo)) { khi = chi; klo = clo; }
+                        }
+                        if (tvalid && j == 0) {
+                            const uint32_t t = t0 + ti;
+                            const int32_t tot = (int32_t)(khi ^ 0x80000000u) + (int32_t)nCost[t];
+                            int32_t dpv = INF;
+                            uint32_t prv = NONE16;
+                            if (tot < INF) { dpv = tot; prv = klo; }  // .min(INF) then strict '<' (lattice.rs:135-136)
+                            pre[t] = (uint16_t)prv;
+                            const uint32_t sl = nSlot[t];
+                            if (sl != NONE16) bdp[sl] = dpv;
+                        }
+                    }
+                }
+                t0 = t1;
+                p0 = p1;
+                __syncthreads();
+            }
+            qa = qb;
+        }
+
+        // ---- phase 5: backtrace (lattice.rs:144-153) + Node -> Token (tokenizer.rs:22-43)
+        uint32_t K = 0;
+        if (lane == 0) {
+            uint32_t pos = N - 1, pr;
+            while ((pr = pre[pos]) != NONE16 && K <= C) { path[K++] = (uint16_t)pos; pos = pr; }  // K <= C + 1 always; bound the walk anyway
+        }
+        K = bcast32(K);
+        uint64_t ts = 0;
+        if (lane == 0) ts = atomicAdd(&a.ctl->tok_cursor, (unsigned long long)K);
+        ts = bcast64(ts);
+        __syncthreads();
+        if (ts + K <= a.stage_cap) {
+            for (uint32_t k = lane; k < K; k += 64) {
+                const uint32_t t = path[K - 1 - k];
+                const int32_t sid = nSid[t];
+                kgpu_token tk;
+                if (sid == 0) {  // Dummy -> "EOS" (tokenizer.rs:27-28,34)
+                    tk.id = 0; tk.cls = KGPU_CLASS_DUMMY; tk.position = B; tk.start = C; tk.end = C + 3; tk.byte_len = 0;
+                } else {
+                    const uint32_t st = nStart[t], en = nEnd[t], bs = cbyte[st];
+                    tk.id = sid > 0 ? sid : -sid;
+                    tk.cls = sid > 0 ? KGPU_CLASS_KNOWN : KGPU_CLASS_UNKNOWN;
+                    tk.position = bs; tk.start = st; tk.end = en; tk.byte_len = cbyte[en] - bs;
+                }
+                a.stage[ts + k] = tk;
+            }
+        } else if (lane == 0) {
+            atomicExch(&a.ctl->tok_overflow, 1u);
+        }
+        if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; a.tok_start[s] = ts; }
+        if (a.count_work) {
+            wT = wave_sum(wT);
+            if (lane == 0) {
+                unsigned long long *w = a.ctl->work;
+                atomicAdd(&w[0], 1ull); atomicAdd(&w[1], (unsigned long long)B); atomicAdd(&w[2], (unsigned long long)C);
+                atomicAdd(&w[3], (unsigned long long)wT); atomicAdd(&w[4], (unsigned long long)(N - 1));
+                atomicAdd(&w[5], (unsigned long long)E); atomicAdd(&w[6], (unsigned long long)K);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int launch_tokenize_lds(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t lds_bytes, int n_workgroups,
+                        void *stream) {
+    if (lds_bytes > 64 * 1024) {  // beyond the default dynamic-LDS cap the kernel has to opt in
+        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k_tokenize_lds, dim3(n_workgroups), dim3(64), lds_bytes, (hipStream_t)stream, d, a, io, lds_bytes);
+    return (int)hipGetLastError();
+}
+
+}  // namespace kgpu

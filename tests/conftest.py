@@ -5,6 +5,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # torch ships its own libamdhip64: load it BEFORE libkanpyo_gpu.so so the process has one HIP runtime
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -230,3 +230,54 @@ def test_full_size_properties_cfg2(full):
             assert np.array_equal(toff, exp.offsets) and np.array_equal(t, exp.tokens)
             checked += 1
     assert checked >= 4
+
+
+def _device_run(tok, sentences, mode):
+    """Drive the device-resident C ABI (kgpu_ctx_*) with torch-owned HBM buffers."""
+    import torch
+
+    from kanpyo_amd.device import DeviceContext
+    from kanpyo_amd.tokenizer import pack_sentences
+
+    utf8, offs = pack_sentences(sentences)
+    dev = torch.device("cuda", 0)
+    d_utf8 = torch.from_numpy(utf8.copy()).to(dev) if utf8.size else torch.zeros(1, dtype=torch.uint8, device=dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    n, cap = len(sentences), int(offs[-1]) + len(sentences)
+    d_tok = torch.empty((cap, 6), dtype=torch.int32, device=dev)
+    d_toff = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    d_st = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+    ctx = DeviceContext(tok)
+    ctx.set_profiling(mode)
+    ctx.tokenize(d_utf8.data_ptr(), d_off.data_ptr(), n, int(offs[-1]), d_tok.data_ptr(), cap, d_toff.data_ptr(), d_st.data_ptr())
+    nt = ctx.sync()
+    return ctx, d_tok[:nt].cpu().numpy(), d_toff.cpu().numpy(), utf8, offs
+
+
+def test_device_api_and_work_counters(full):
+    """The device-side work counters (B, C, T, N, E, K) equal the oracle's."""
+    from kanpyo_amd import synth
+    from kanpyo_amd.device import PROFILE_EVENTS, PROFILE_WORK
+
+    sd, tok, orc = full
+    sents = synth.make_corpus(sd, 4096, 1, "cfg2") + synth.make_corpus(sd, 200, 2, "cfg3") + synth.make_corpus(sd, 3, 5, "cfg5")
+    ctx, t, toff, utf8, offs = _device_run(tok, sents, PROFILE_WORK | PROFILE_EVENTS)
+    exp = orc.tokenize_batch(utf8, offs, 8)
+    assert np.array_equal(toff.astype(np.uint64), exp.offsets)
+    assert np.array_equal(t.reshape(-1), exp.tokens.view(np.int32).reshape(-1))
+    assert ctx.work() == exp.counters
+    p = ctx.profile()
+    assert p["launches"] == 1 and p["tokenize_ms"] > 0
+
+
+@pytest.mark.parametrize("tiers", ["0", "8", "4,24", "20,64,160", "160"])
+def test_every_memory_tier_is_bit_exact(libs, tiers, monkeypatch):
+    """Force sentences through each tier chain (LDS sizes in KiB; '0' = HBM-scratch kernel only)."""
+    from kanpyo_amd import Tokenizer, synth
+
+    _, oracle = libs
+    monkeypatch.setenv("KGPU_TIERS", tiers)
+    sd = synth.build_dict(20000, seed=11)
+    tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
+    sents = synth.make_corpus(sd, 1500, 3, "cfg2") + synth.make_corpus(sd, 300, 4, "cfg3") + synth.make_corpus(sd, 2, 6, "cfg5") + ["", "あ", "ア" * 1500]
+    assert_same(tok, orc, sents)
