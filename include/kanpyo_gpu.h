@@ -152,6 +152,10 @@ int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens);
 int kgpu_ctx_set_profiling(kgpu_ctx *c, int mode /* KGPU_PROFILE_* bit mask */);
 int kgpu_ctx_get_profile(kgpu_ctx *c, kgpu_profile *out, int reset);
 int kgpu_ctx_get_work(kgpu_ctx *c, kgpu_work *out, int reset);
+/* Sum over sentences of shader-clock cycles spent per phase of the LDS-resident
+ * kernel (KGPU_PROFILE_WORK runs only): load, decode, walk, scan, emit, gather,
+ * sweep, backtrace+tokens, [8] = sentences counted, [9] spare. */
+int kgpu_ctx_get_phase_cycles(kgpu_ctx *c, uint64_t out[10], int reset);
 
 /* IndexTable::build + write_dict (kanpyo-dict/src/index.rs:16-38,75-84 over
  * trie/da.rs:22-131,191-217): sorted keywords (duplicates adjacent) -> the

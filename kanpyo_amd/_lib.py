@@ -21,7 +21,7 @@ KGPU_SENT_INVALID_UTF8 = 1
 SYMBOLS = [
     "kgpu_last_error", "kgpu_device_count", "kgpu_dict_create", "kgpu_dict_destroy", "kgpu_dict_get_info",
     "kgpu_tokenize_batch", "kgpu_ctx_create", "kgpu_ctx_destroy", "kgpu_tokenize_device", "kgpu_ctx_sync",
-    "kgpu_ctx_set_profiling", "kgpu_ctx_get_profile", "kgpu_ctx_get_work", "kgpu_index_build", "kgpu_free",
+    "kgpu_ctx_set_profiling", "kgpu_ctx_get_profile", "kgpu_ctx_get_work", "kgpu_ctx_get_phase_cycles", "kgpu_index_build", "kgpu_free",
 ]
 
 
@@ -84,6 +84,7 @@ def lib():
         L.kgpu_ctx_set_profiling.argtypes = [vp, C.c_int]
         L.kgpu_ctx_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
         L.kgpu_ctx_get_work.argtypes = [vp, C.POINTER(Work), C.c_int]
+        L.kgpu_ctx_get_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64 * 10), C.c_int]
         L.kgpu_index_build.argtypes = [vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.kgpu_free.argtypes = [vp]
         L.kgpu_free.restype = None

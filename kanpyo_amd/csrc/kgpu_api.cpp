@@ -85,7 +85,7 @@ struct kgpu_ctx {
     bool own_stream = false;
     Control *d_ctl = nullptr;
     Control *h_ctl = nullptr;  // pinned
-    DevBuf arena, stage, tok_start, tok_count;
+    DevBuf arena, stage, tok_count;
     // host-buffer path staging
     DevBuf in_utf8, in_off, out_tok, out_off, out_status;
     // last enqueued batch (for the arena-overflow retry and for sync)
@@ -97,6 +97,7 @@ struct kgpu_ctx {
     bool profiling = false;   // KGPU_PROFILE_EVENTS
     bool count_work = false;  // KGPU_PROFILE_WORK
     kgpu_work work{};
+    uint64_t phase[10] = {0};
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     kgpu_profile prof{};
@@ -328,7 +329,7 @@ extern "C" void kgpu_ctx_destroy(kgpu_ctx *c) {
     (void)hipSetDevice(c->dict->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    c->arena.release(); c->ovf.release(); c->stage.release(); c->tok_start.release(); c->tok_count.release();
+    c->arena.release(); c->ovf.release(); c->stage.release(); c->tok_count.release();
     c->in_utf8.release(); c->in_off.release(); c->out_tok.release(); c->out_off.release(); c->out_status.release();
     if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
@@ -383,15 +384,15 @@ extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const ui
     HIPCHECK(hipSetDevice(c->dict->device));
     int rc;
     if (c->pending && (rc = kgpu_ctx_sync(c, nullptr)) != KGPU_OK && rc != KGPU_ERR_CAPACITY) return rc;
-    if ((rc = c->arena.ensure(ARENA_INITIAL)) || (rc = c->stage.ensure((size_t)token_capacity * sizeof(kgpu_token) + 64)) ||
-        (rc = c->tok_start.ensure((size_t)(n + 1) * 8)) || (rc = c->tok_count.ensure((size_t)(n + 1) * 4)) ||
+    if ((rc = c->arena.ensure(ARENA_INITIAL)) || (rc = c->stage.ensure((size_t)(total_bytes + n + 1) * sizeof(kgpu_token) + 64)) ||
+        (rc = c->tok_count.ensure((size_t)(n + 1) * 4)) ||
         (rc = c->ovf.ensure((size_t)(n + 1) * 4 * 3)))
         return rc;
     BatchArgs a{};
     a.utf8 = d_utf8; a.offsets = d_offsets; a.n = n; a.ctl = c->d_ctl;
     a.arena = (uint8_t *)c->arena.p; a.arena_bytes = c->arena.bytes;
-    a.stage = (kgpu_token *)c->stage.p; a.stage_cap = token_capacity;
-    a.tok_start = (uint64_t *)c->tok_start.p; a.tok_count = (uint32_t *)c->tok_count.p;
+    a.stage = (kgpu_token *)c->stage.p;
+    a.tok_count = (uint32_t *)c->tok_count.p;
     a.status = d_status; a.out = d_tokens; a.out_cap = token_capacity; a.tok_offsets = d_tok_offsets;
     a.count_work = c->count_work ? 1u : 0u;
     for (int k = 0; k < 3; ++k) a.ovf[k] = (uint32_t *)c->ovf.p + (size_t)k * (n + 1);
@@ -432,10 +433,11 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
         const unsigned long long *w = c->h_ctl->work;
         c->work.sentences += w[0]; c->work.B += w[1]; c->work.C += w[2]; c->work.T += w[3];
         c->work.N += w[4]; c->work.E += w[5]; c->work.K += w[6];
+        for (int k = 0; k < 10; ++k) c->phase[k] += c->h_ctl->phase[k];
     }
-    uint64_t need = c->h_ctl->tok_overflow ? c->h_ctl->tok_cursor : c->h_ctl->n_tokens;
+    uint64_t need = c->h_ctl->n_tokens;
     if (n_tokens) *n_tokens = need;
-    if (c->h_ctl->tok_overflow || c->h_ctl->n_tokens > c->last.out_cap) {
+    if (c->h_ctl->n_tokens > c->last.out_cap) {
         set_error("token buffer too small: need %llu, capacity %llu", (unsigned long long)need, (unsigned long long)c->last.out_cap);
         return KGPU_ERR_CAPACITY;
     }
@@ -446,6 +448,12 @@ extern "C" int kgpu_ctx_set_profiling(kgpu_ctx *c, int mode) {
     if (!c) { set_error("kgpu_ctx_set_profiling: null ctx"); return KGPU_ERR_INVALID_ARG; }
     c->profiling = (mode & KGPU_PROFILE_EVENTS) != 0;
     c->count_work = (mode & KGPU_PROFILE_WORK) != 0;
+    return KGPU_OK;
+}
+
+extern "C" int kgpu_ctx_get_phase_cycles(kgpu_ctx *c, uint64_t out[10], int reset) {
+    if (!c || !out) { set_error("kgpu_ctx_get_phase_cycles: null argument"); return KGPU_ERR_INVALID_ARG; }
+    for (int k = 0; k < 10; ++k) { out[k] = c->phase[k]; if (reset) c->phase[k] = 0; }
     return KGPU_OK;
 }
 

@@ -97,19 +97,23 @@ struct TierIO {
     unsigned int *out_count;
 };
 
-// Dequeue one work item for the whole wavefront.  There is deliberately no
+// Next work item for the whole wavefront.  For the dynamic lists there is deliberately no
 // `if (lane == 0) x = atomicAdd(..); x = readfirstlane(x);` here: hipcc (ROCm 7.2)
 // restructured the persistent loop around that pattern so that an early
 // `continue` re-ran the body with a stale index (hang on every deferral).
 // Instead every lane issues the add, lane 0 adding 1 and the others 0: lane 0's
 // return value is the ticket whether or not the atomic optimizer folds the wave's
 // adds into one.
-__device__ __forceinline__ bool tier_next(const TierIO &io, const BatchArgs &a, uint32_t lane, uint64_t &s) {
+__device__ __forceinline__ bool tier_next(const TierIO &io, const BatchArgs &a, uint32_t lane, uint32_t iter, uint64_t &s) {
+    if (!io.in_list) {  // first tier: sentence ids are a static grid-stride (no hot dequeue word)
+        s = (uint64_t)blockIdx.x + (uint64_t)iter * gridDim.x;
+        return s < a.n;
+    }
     const uint32_t ticket = atomicAdd(io.queue, lane == 0 ? 1u : 0u);
     const uint64_t i = bcast32(ticket);
-    const uint64_t n = io.in_count ? (uint64_t)bcast32(__hip_atomic_load(io.in_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : a.n;
+    const uint64_t n = (uint64_t)bcast32(__hip_atomic_load(io.in_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (i >= n) return false;
-    s = io.in_list ? (uint64_t)bcast32(io.in_list[i]) : i;
+    s = (uint64_t)bcast32(io.in_list[i]);
     return true;
 }
 __device__ __forceinline__ void tier_defer(const TierIO &io, uint32_t lane, uint64_t s) {

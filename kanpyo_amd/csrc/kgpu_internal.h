@@ -43,11 +43,11 @@ struct Control {
     unsigned int queue_head[4];       // per-tier dequeue cursors (a batch has < 2^32 sentences)
     unsigned int ovf_count[4];        // sentences deferred from tier k to tier k+1
     unsigned long long arena_cursor;  // bump allocator over the scratch arena (bytes)
-    unsigned long long tok_cursor;    // bump allocator over the staging tokens
     unsigned int arena_overflow;      // a slab request did not fit
-    unsigned int tok_overflow;        // staging tokens did not fit token_capacity
+    unsigned int pad0;
     unsigned long long n_tokens;      // dense token count (written by the scan kernel)
     unsigned long long work[7];       // kgpu_work, only when BatchArgs::count_work
+    unsigned long long phase[10];     // shader-clock cycles per phase of the LDS kernel (count_work only)
 };
 
 struct BatchArgs {
@@ -56,8 +56,7 @@ struct BatchArgs {
     uint64_t n;
     Control *ctl;
     uint8_t *arena;  uint64_t arena_bytes;
-    kgpu_token *stage;  uint64_t stage_cap;  // staging tokens (bump-allocated per sentence)
-    uint64_t *tok_start;          // n: staging index of sentence's first token
+    kgpu_token *stage;            // staging tokens: sentence s owns slots [off[s]-off[0]+s, +B_s+1)
     uint32_t *tok_count;          // n
     uint8_t *status;              // n
     kgpu_token *out;  uint64_t out_cap;      // dense output

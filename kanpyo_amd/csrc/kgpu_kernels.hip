@@ -34,10 +34,11 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
     const uint32_t lane = threadIdx.x;
     Slab sa{nullptr, 0}, sn{nullptr, 0};
     const int32_t base_root = d.da[1].base;
+    uint64_t accW[7] = {0, 0, 0, 0, 0, 0, 0};  // work counters of this workgroup, flushed once at exit
 
-    for (;;) {
+    for (uint32_t iter = 0;; ++iter) {
         uint64_t s = 0;
-        if (!tier_next(io, a, lane, s)) break;
+        if (!tier_next(io, a, lane, iter, s)) break;
 
         const uint64_t b0 = a.offsets[s];
         const uint32_t B = (uint32_t)(a.offsets[s + 1] - b0);
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         // ---- slab A: per-char arrays (C <= B) --------------------------------
         const uint64_t na = (uint64_t)B + 4;
         if (!slab_ensure(sa, na * 25 + 64, a, lane)) {
-            if (lane == 0) { a.status[s] = 2; a.tok_count[s] = 0; a.tok_start[s] = 0; }
+            if (lane == 0) { a.status[s] = 2; a.tok_count[s] = 0; }
             continue;
         }
         uint32_t *cbyte = (uint32_t *)sa.ptr;  // char -> byte offset, [C] = B
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         }
         lensum = bcast32(wave_sum(lensum));  // keep every early exit wave-uniform (SGPR) for the compiler
         if (__ballot(bad != 0) != 0 || lensum != B) {  // stray continuation bytes leave lensum < B
-            if (lane == 0) { a.status[s] = KGPU_SENT_INVALID_UTF8; a.tok_count[s] = 0; a.tok_start[s] = 0; }
+            if (lane == 0) { a.status[s] = KGPU_SENT_INVALID_UTF8; a.tok_count[s] = 0; }
             continue;
         }
         if (lane == 0) cbyte[C] = B;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
 
         // ---- slab N: per-node arrays -----------------------------------------------
         if (!slab_ensure(sn, (uint64_t)N * 44 + 64, a, lane)) {
-            if (lane == 0) { a.status[s] = 2; a.tok_count[s] = 0; a.tok_start[s] = 0; }
+            if (lane == 0) { a.status[s] = 2; a.tok_count[s] = 0; }
             continue;
         }
         uint4 *nodeA = (uint4 *)sn.ptr;   // {left | right << 16, cost, bucket slot, signed id}
@@ -238,11 +239,11 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             while ((pr = pre[pos]) != NONE && K <= C) { path[K++] = pos; pos = pr; }  // K <= C + 1 always; bound the walk anyway
         }
         K = bcast32(K);
-        uint64_t ts = 0;
-        if (lane == 0) ts = atomicAdd(&a.ctl->tok_cursor, (unsigned long long)K);
-        ts = bcast64(ts);
+        // staging slot of the sentence: K <= C + 1 <= B + 1 tokens always fit at b0 + s
+        // (no cursor atomics: a single hot word serialises ~90 sentences/us chip-wide)
+        const uint64_t ts = b0 - a.offsets[0] + s;
         __syncthreads();
-        if (ts + K <= a.stage_cap) {
+        {
             for (uint32_t k = lane; k < K; k += 64) {
                 const uint32_t t = path[K - 1 - k];
                 const int32_t sid = (int32_t)nodeA[t].w;
@@ -258,21 +259,16 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                 }
                 a.stage[ts + k] = tk;
             }
-        } else if (lane == 0) {
-            atomicExch(&a.ctl->tok_overflow, 1u);
         }
-        if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; a.tok_start[s] = ts; }
+        if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; }
         if (a.count_work) {
             wT = wave_sum(wT);
-            if (lane == 0) {
-                unsigned long long *w = a.ctl->work;
-                atomicAdd(&w[0], 1ull); atomicAdd(&w[1], (unsigned long long)B); atomicAdd(&w[2], (unsigned long long)C);
-                atomicAdd(&w[3], (unsigned long long)wT); atomicAdd(&w[4], (unsigned long long)(N - 1));
-                atomicAdd(&w[5], (unsigned long long)wE); atomicAdd(&w[6], (unsigned long long)K);
-            }
+            accW[0] += 1; accW[1] += B; accW[2] += C; accW[3] += wT; accW[4] += N - 1; accW[5] += bcast32(wE); accW[6] += K;
         }
         __syncthreads();
     }
+    if (a.count_work && lane == 0)
+        for (int k = 0; k < 7; ++k) atomicAdd(&a.ctl->work[k], (unsigned long long)accW[k]);
 }
 
 // Exclusive scan of per-sentence token counts -> tok_offsets (single workgroup;
@@ -306,7 +302,6 @@ __global__ __launch_bounds__(1024) void k_scan_counts(BatchArgs a) {
 // Staging (dequeue order) -> dense sentence order.  One wavefront per sentence,
 // dword-granular coalesced copy.
 __global__ __launch_bounds__(256) void k_compact(BatchArgs a) {
-    if (a.ctl->tok_overflow) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
@@ -314,7 +309,7 @@ __global__ __launch_bounds__(256) void k_compact(BatchArgs a) {
         const uint32_t cnt = a.tok_count[s];
         const uint64_t dst = a.tok_offsets[s];
         if (dst + cnt > a.out_cap) continue;
-        const uint32_t *src = (const uint32_t *)(a.stage + a.tok_start[s]);
+        const uint32_t *src = (const uint32_t *)(a.stage + (a.offsets[s] - a.offsets[0] + s));
         uint32_t *out = (uint32_t *)(a.out + dst);
         for (uint32_t w = lane; w < cnt * 6; w += 64) out[w] = src[w];
     }

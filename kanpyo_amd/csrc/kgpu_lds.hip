@@ -63,16 +63,23 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x;
     const int32_t base_root = d.da[1].base;
+    // profiling accumulators of this workgroup (flushed once at exit: per-sentence
+    // atomics on a handful of hot words distort what they measure)
+    uint64_t accW[7] = {0, 0, 0, 0, 0, 0, 0}, accP[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-    for (;;) {
+    for (uint32_t iter = 0;; ++iter) {
         uint64_t s = 0;
-        if (!tier_next(io, a, lane, s)) break;
+        if (!tier_next(io, a, lane, iter, s)) break;
         const uint64_t b0 = a.offsets[s];
         const uint64_t Bl = a.offsets[s + 1] - b0;
         if (Bl + 64 > lds_bytes || Bl > 0xFFF0) { tier_defer(io, lane, s); continue; }
         const uint32_t B = (uint32_t)Bl;
         const uint8_t *gtext = a.utf8 + b0;
 
+        uint64_t tick[9];
+        const bool prof = a.count_work != 0;
+#define KGPU_TICK(k) do { if (prof) tick[k] = __builtin_amdgcn_s_memtime(); } while (0)
+        KGPU_TICK(0);
         // ---- phase 0a: stage the sentence in LDS, count chars -----------------
         uint8_t *text = smem;
         uint32_t C = 0;
@@ -99,6 +106,7 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
         uint32_t *mid = (uint32_t *)(smem + moff);           // [C][MAXM] trie ids
         uint8_t *mnch = smem + moff + 4 * C * MAXM;          // [C][MAXM] match length in chars
         __syncthreads();
+        KGPU_TICK(1);
 
         // ---- phase 0b: decode + validate + category --------------------------------
         uint32_t cb = 0, bad = 0, lensum = 0;
@@ -131,13 +139,14 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
         }
         lensum = bcast32(wave_sum(lensum));  // keep every early exit wave-uniform (SGPR) for the compiler
         if (__ballot(bad != 0) != 0 || lensum != B) {
-            if (lane == 0) { a.status[s] = KGPU_SENT_INVALID_UTF8; a.tok_count[s] = 0; a.tok_start[s] = 0; }
+            if (lane == 0) { a.status[s] = KGPU_SENT_INVALID_UTF8; a.tok_count[s] = 0; }
             continue;
         }
         if (lane == 0) cbyte[C] = (uint16_t)B;
         for (uint32_t e = lane; e < C + 2; e += 64) { boff[e] = 0; bfill[e] = 0; }
         __syncthreads();
 
+        KGPU_TICK(2);
         // ---- phase 1: one trie walk per start position; count + park matches ------
         uint32_t wT = 0, ovf = 0;
         {
@@ -187,6 +196,7 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
         }
         __syncthreads();
 
+        KGPU_TICK(3);
         // ---- phase 2: prefix sums: node numbering, bucket offsets, pair offsets ------
         uint32_t ncarry = 1, bcarry = 0, ecarry = 0, maxpairs = 0;
         for (uint32_t i0 = 0; i0 < C + 2; i0 += 64) {
@@ -227,6 +237,7 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
         }
         __syncthreads();
 
+        KGPU_TICK(4);
         // ---- phase 3: emit nodes from the parked matches --------------------------------
         for (uint32_t i = lane; i < C; i += 64) {
             uint32_t t = nb[i];
@@ -268,6 +279,8 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
         __syncthreads();
         if (lane == 0) { bdp[0] = 0; pre[0] = NONE16; }  // BOS: dp None -> 0 (lattice.rs:127)
 
+        KGPU_TICK(5);
+        uint64_t cyc_gather = 0;
         // ---- phases 3b + 4, per block of positions whose pairs fit the pair table ----
         uint32_t qa = 0;
         while (qa <= C) {
@@ -282,6 +295,7 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
                 qb = lo;
             }
             const uint32_t eb0 = ebase[qa];
+            const uint64_t tg0 = prof ? __builtin_amdgcn_s_memtime() : 0;
             // -- 3b: gather every connection cost of the block into LDS (connection.rs:12-14)
             const uint32_t ta = nb[qa], tb = nb[qb];
             for (uint32_t t = ta + lane; t < tb; t += 64) {
@@ -299,6 +313,7 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
                 for (; j < P; ++j) mpair[base + j] = col[bri[p0 + j] & 0xFFFFu];
             }
             __syncthreads();
+            if (prof) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
 
             // -- 4: Viterbi sweep over the block (lattice.rs:116-142), LDS only
             uint32_t t0 = ta, p0 = boff[qa];
@@ -351,6 +366,7 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
             qa = qb;
         }
 
+        KGPU_TICK(6);
         // ---- phase 5: backtrace (lattice.rs:144-153) + Node -> Token (tokenizer.rs:22-43)
         uint32_t K = 0;
         if (lane == 0) {
@@ -358,11 +374,11 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
             while ((pr = pre[pos]) != NONE16 && K <= C) { path[K++] = (uint16_t)pos; pos = pr; }  // K <= C + 1 always; bound the walk anyway
         }
         K = bcast32(K);
-        uint64_t ts = 0;
-        if (lane == 0) ts = atomicAdd(&a.ctl->tok_cursor, (unsigned long long)K);
-        ts = bcast64(ts);
+        // staging slot of the sentence: K <= C + 1 <= B + 1 tokens always fit at b0 + s
+        // (no cursor atomics: a single hot word serialises ~90 sentences/us chip-wide)
+        const uint64_t ts = b0 - a.offsets[0] + s;
         __syncthreads();
-        if (ts + K <= a.stage_cap) {
+        {
             for (uint32_t k = lane; k < K; k += 64) {
                 const uint32_t t = path[K - 1 - k];
                 const int32_t sid = nSid[t];
@@ -377,20 +393,21 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
                 }
                 a.stage[ts + k] = tk;
             }
-        } else if (lane == 0) {
-            atomicExch(&a.ctl->tok_overflow, 1u);
         }
-        if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; a.tok_start[s] = ts; }
+        if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; }
         if (a.count_work) {
             wT = wave_sum(wT);
-            if (lane == 0) {
-                unsigned long long *w = a.ctl->work;
-                atomicAdd(&w[0], 1ull); atomicAdd(&w[1], (unsigned long long)B); atomicAdd(&w[2], (unsigned long long)C);
-                atomicAdd(&w[3], (unsigned long long)wT); atomicAdd(&w[4], (unsigned long long)(N - 1));
-                atomicAdd(&w[5], (unsigned long long)E); atomicAdd(&w[6], (unsigned long long)K);
-            }
+            const uint64_t t7 = __builtin_amdgcn_s_memtime();
+            accW[0] += 1; accW[1] += B; accW[2] += C; accW[3] += wT; accW[4] += N - 1; accW[5] += E; accW[6] += K;
+            accP[0] += tick[1] - tick[0]; accP[1] += tick[2] - tick[1]; accP[2] += tick[3] - tick[2];
+            accP[3] += tick[4] - tick[3]; accP[4] += tick[5] - tick[4]; accP[5] += cyc_gather;
+            accP[6] += tick[6] - tick[5] - cyc_gather; accP[7] += t7 - tick[6]; accP[8] += 1;
         }
         __syncthreads();
+    }
+    if (a.count_work && lane == 0) {
+        for (int k = 0; k < 7; ++k) atomicAdd(&a.ctl->work[k], (unsigned long long)accW[k]);
+        for (int k = 0; k < 9; ++k) atomicAdd(&a.ctl->phase[k], (unsigned long long)accP[k]);
     }
 }
 

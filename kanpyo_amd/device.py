@@ -58,3 +58,10 @@ class DeviceContext:
         w = _lib.Work()
         _lib.check(_lib.lib().kgpu_ctx_get_work(self._h, C.byref(w), int(reset)))
         return {n: int(getattr(w, n)) for n, _ in w._fields_}
+
+    def phase_cycles(self, reset: bool = True) -> dict:
+        """Per-phase shader-clock cycles of the LDS kernel, summed over sentences (PROFILE_WORK runs)."""
+        arr = (C.c_uint64 * 10)()
+        _lib.check(_lib.lib().kgpu_ctx_get_phase_cycles(self._h, C.byref(arr), int(reset)))
+        names = ["load", "decode", "walk", "scan", "emit", "gather", "sweep", "backtrace_tokens", "sentences", "spare"]
+        return {n: int(arr[i]) for i, n in enumerate(names)}
