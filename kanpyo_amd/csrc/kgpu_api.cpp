@@ -92,7 +92,7 @@ struct kgpu_ctx {
     BatchArgs last{};
     bool pending = false;
     TierPlan plan{};
-    DevBuf ovf;
+    DevBuf ovf, ninfo[3];
     // profiling
     bool profiling = false;   // KGPU_PROFILE_EVENTS
     bool count_work = false;  // KGPU_PROFILE_WORK
@@ -320,6 +320,10 @@ extern "C" int kgpu_ctx_create(kgpu_dict *d, void *hip_stream, kgpu_ctx **out) {
         return KGPU_ERR_HIP;
     }
     c->plan = default_tier_plan(d->device);
+    for (int k = 0; k < c->plan.n_lds_tiers; ++k) {
+        int rc = c->ninfo[k].ensure((size_t)c->plan.workgroups[k] * tier_node_cap(c->plan.lds_bytes[k]) * 8);
+        if (rc) { kgpu_ctx_destroy(c); return rc; }
+    }
     *out = c;
     return KGPU_OK;
 }
@@ -329,7 +333,7 @@ extern "C" void kgpu_ctx_destroy(kgpu_ctx *c) {
     (void)hipSetDevice(c->dict->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    c->arena.release(); c->ovf.release(); c->stage.release(); c->tok_count.release();
+    c->arena.release(); c->ovf.release(); for (auto &b : c->ninfo) b.release(); c->stage.release(); c->tok_count.release();
     c->in_utf8.release(); c->in_off.release(); c->out_tok.release(); c->out_off.release(); c->out_status.release();
     if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
@@ -395,7 +399,7 @@ extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const ui
     a.tok_count = (uint32_t *)c->tok_count.p;
     a.status = d_status; a.out = d_tokens; a.out_cap = token_capacity; a.tok_offsets = d_tok_offsets;
     a.count_work = c->count_work ? 1u : 0u;
-    for (int k = 0; k < 3; ++k) a.ovf[k] = (uint32_t *)c->ovf.p + (size_t)k * (n + 1);
+    for (int k = 0; k < 3; ++k) { a.ovf[k] = (uint32_t *)c->ovf.p + (size_t)k * (n + 1); a.ninfo[k] = c->ninfo[k].p; }
     return enqueue(c, a);
 }
 

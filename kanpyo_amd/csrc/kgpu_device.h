@@ -86,31 +86,23 @@ __device__ __forceinline__ uint32_t da_walk(const DictView &d, const uint8_t *te
 }
 
 
-// Work-list plumbing shared by the tier kernels: tier k pulls sentence ids from
-// list `in_list` (nullptr = identity over [0, n)) and pushes the ones whose
-// lattice does not fit its memory budget onto the next tier's list.
+// Work-list plumbing shared by the tier kernels: tier k takes its sentence ids
+// from list `in_list` (nullptr = identity over [0, n)) and pushes the ones whose
+// lattice does not fit its memory budget onto the next tier's list.  Work is a
+// static grid-stride over the list: the list length is final when the tier's
+// kernel starts (same stream), and there is no hot dequeue word -- a single
+// contended atomic serialises at ~90 ops/us chip-wide, which is most of a
+// 4096-sentence batch.
 struct TierIO {
-    const uint32_t *in_list;        // nullptr: sentence id == queue index
+    const uint32_t *in_list;        // nullptr: sentence id == work index
     const unsigned int *in_count;   // nullptr: a.n
-    unsigned int *queue;            // dequeue cursor of this tier
     uint32_t *out_list;             // overflow list for the next tier (nullptr: none)
     unsigned int *out_count;
 };
 
-// Next work item for the whole wavefront.  For the dynamic lists there is deliberately no
-// `if (lane == 0) x = atomicAdd(..); x = readfirstlane(x);` here: hipcc (ROCm 7.2)
-// restructured the persistent loop around that pattern so that an early
-// `continue` re-ran the body with a stale index (hang on every deferral).
-// Instead every lane issues the add, lane 0 adding 1 and the others 0: lane 0's
-// return value is the ticket whether or not the atomic optimizer folds the wave's
-// adds into one.
-__device__ __forceinline__ bool tier_next(const TierIO &io, const BatchArgs &a, uint32_t lane, uint32_t iter, uint64_t &s) {
-    if (!io.in_list) {  // first tier: sentence ids are a static grid-stride (no hot dequeue word)
-        s = (uint64_t)blockIdx.x + (uint64_t)iter * gridDim.x;
-        return s < a.n;
-    }
-    const uint32_t ticket = atomicAdd(io.queue, lane == 0 ? 1u : 0u);
-    const uint64_t i = bcast32(ticket);
+__device__ __forceinline__ bool tier_next(const TierIO &io, const BatchArgs &a, uint32_t iter, uint64_t &s) {
+    const uint64_t i = (uint64_t)blockIdx.x + (uint64_t)iter * gridDim.x;
+    if (!io.in_list) { s = i; return i < a.n; }
     const uint64_t n = (uint64_t)bcast32(__hip_atomic_load(io.in_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (i >= n) return false;
     s = (uint64_t)bcast32(io.in_list[i]);

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
 
     for (uint32_t iter = 0;; ++iter) {
         uint64_t s = 0;
-        if (!tier_next(io, a, lane, iter, s)) break;
+        if (!tier_next(io, a, iter, s)) break;
 
         const uint64_t b0 = a.offsets[s];
         const uint32_t B = (uint32_t)(a.offsets[s + 1] - b0);
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_compact(BatchArgs a) {
 }
 
 int launch_tokenize_lds(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t lds_bytes, int n_workgroups,
-                        void *stream);  // kgpu_lds.hip
+                        void *ninfo, uint32_t ncap, void *stream);  // kgpu_lds.hip
 
 // Tier chain: LDS tiers in ascending LDS size, then the general (HBM scratch)
 // kernel.  Every launch is a persistent grid pulling from its tier's work list.
@@ -325,16 +325,16 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan,
     const uint32_t *in_list = nullptr;
     const unsigned int *in_count = nullptr;
     for (int k = 0; k < plan.n_lds_tiers; ++k) {
-        TierIO io{in_list, in_count, &ctl->queue_head[k], a.ovf[k], &ctl->ovf_count[k]};
+        TierIO io{in_list, in_count, a.ovf[k], &ctl->ovf_count[k]};
         uint64_t wg = plan.workgroups[k];
         if (k == 0 && a.n < wg) wg = a.n;
-        int e = launch_tokenize_lds(d, a, io, plan.lds_bytes[k], (int)(wg ? wg : 1), stream);
+        int e = launch_tokenize_lds(d, a, io, plan.lds_bytes[k], (int)(wg ? wg : 1), a.ninfo[k], tier_node_cap(plan.lds_bytes[k]), stream);
         if (e) return e;
         in_list = a.ovf[k];
         in_count = &ctl->ovf_count[k];
     }
     if (getenv("KGPU_DEBUG_SKIP_GENERAL")) return 0;
-    TierIO io{in_list, in_count, &ctl->queue_head[plan.n_lds_tiers], nullptr, nullptr};
+    TierIO io{in_list, in_count, nullptr, nullptr};
     uint64_t wg = plan.general_workgroups;
     if (plan.n_lds_tiers == 0 && a.n < wg) wg = a.n;
     hipLaunchKernelGGL(k_tokenize_general, dim3((unsigned)(wg ? wg : 1)), dim3(64), 0, (hipStream_t)stream, d, a, io);
@@ -356,9 +356,10 @@ TierPlan default_tier_plan(int device) {
     int cus = 256;
     if (hipGetDeviceProperties(&p, device) == hipSuccess) cus = p.multiProcessorCount;
     TierPlan t{};
-    t.n_lds_tiers = 2;
-    t.lds_bytes[0] = 20 * 1024;   t.workgroups[0] = cus * 8;  // 8 sentences per CU in flight (160 KB / 20 KB)
-    t.lds_bytes[1] = 160 * 1024;  t.workgroups[1] = cus;      // one long sentence owns a CU's whole LDS
+    t.n_lds_tiers = 3;
+    t.lds_bytes[0] = 10 * 1024;   t.workgroups[0] = cus * 16;  // 16 sentences per CU in flight (160 KB / 10 KB)
+    t.lds_bytes[1] = 20 * 1024;   t.workgroups[1] = cus * 8;
+    t.lds_bytes[2] = 160 * 1024;  t.workgroups[2] = cus;       // one long sentence owns a CU's whole LDS
     t.general_workgroups = cus * 8;
     if (const char *e = getenv("KGPU_TIERS")) {  // e.g. "20,64,160" (KiB) or "0" for the general kernel only
         t.n_lds_tiers = 0;

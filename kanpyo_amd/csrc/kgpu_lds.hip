@@ -35,41 +35,50 @@ constexpr uint32_t MAXM = 8;         // trie matches buffered per start position
 constexpr uint32_t NONE16 = 0xFFFFu;
 
 // ---- DPP butterfly: min over aligned groups of 2^lg lanes, every lane gets it.
+// The key is one u64 (total ^ signbit) << 32 | predecessor node index, so one
+// v_cmp_lt_u64 + two v_cndmask per step, no branches.
 template <int CTRL>
-__device__ __forceinline__ void dpp_min_step(uint32_t &hi, uint32_t &lo) {
-    const uint32_t oh = (uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xF, 0xF, false);
-    const uint32_t ol = (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xF, 0xF, false);
-    if (oh < hi || (oh == hi && ol < lo)) { hi = oh; lo = ol; }
+__device__ __forceinline__ uint64_t dpp_min_step(uint64_t k) {
+    const uint32_t oh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), CTRL, 0xF, 0xF, false);
+    const uint32_t ol = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, CTRL, 0xF, 0xF, false);
+    const uint64_t o = ((uint64_t)oh << 32) | ol;
+    return o < k ? o : k;
 }
-__device__ __forceinline__ void shfl_min_step(uint32_t &hi, uint32_t &lo, int d) {
-    const uint32_t oh = (uint32_t)__shfl_xor((int)hi, d, 64);
-    const uint32_t ol = (uint32_t)__shfl_xor((int)lo, d, 64);
-    if (oh < hi || (oh == hi && ol < lo)) { hi = oh; lo = ol; }
+__device__ __forceinline__ uint64_t shfl_min_step(uint64_t k, int d) {
+    const uint32_t oh = (uint32_t)__shfl_xor((int)(uint32_t)(k >> 32), d, 64);
+    const uint32_t ol = (uint32_t)__shfl_xor((int)(uint32_t)k, d, 64);
+    const uint64_t o = ((uint64_t)oh << 32) | ol;
+    return o < k ? o : k;
 }
-__device__ __forceinline__ void group_min(uint32_t &hi, uint32_t &lo, uint32_t lg) {  // lg wave-uniform
-    if (lg >= 1) dpp_min_step<0xB1>(hi, lo);   // quad_perm [1,0,3,2]
-    if (lg >= 2) dpp_min_step<0x4E>(hi, lo);   // quad_perm [2,3,0,1]
-    if (lg >= 3) dpp_min_step<0x141>(hi, lo);  // row_half_mirror
-    if (lg >= 4) dpp_min_step<0x140>(hi, lo);  // row_mirror
-    if (lg >= 5) shfl_min_step(hi, lo, 16);
-    if (lg >= 6) shfl_min_step(hi, lo, 32);
+__device__ __forceinline__ uint64_t group_min(uint64_t k, uint32_t lg) {  // lg wave-uniform
+    if (lg >= 1) k = dpp_min_step<0xB1>(k);   // quad_perm [1,0,3,2]
+    if (lg >= 2) k = dpp_min_step<0x4E>(k);   // quad_perm [2,3,0,1]
+    if (lg >= 3) k = dpp_min_step<0x141>(k);  // row_half_mirror
+    if (lg >= 4) k = dpp_min_step<0x140>(k);  // row_mirror
+    if (lg >= 5) k = shfl_min_step(k, 16);
+    if (lg >= 6) k = shfl_min_step(k, 32);
+    return k;
 }
 
 __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, TierIO io, uint32_t lds_bytes) {
+__global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, TierIO io, uint32_t lds_bytes,
+                                                      uint2 *ninfo_base, uint32_t ncap) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x;
     const int32_t base_root = d.da[1].base;
+    // {signed id, start | end << 16} per node: only the K nodes on the best path are ever
+    // read back, so this lives in a per-workgroup HBM slab, not in LDS
+    uint2 *ninfo = ninfo_base + (size_t)blockIdx.x * ncap;
     // profiling accumulators of this workgroup (flushed once at exit: per-sentence
     // atomics on a handful of hot words distort what they measure)
     uint64_t accW[7] = {0, 0, 0, 0, 0, 0, 0}, accP[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     for (uint32_t iter = 0;; ++iter) {
         uint64_t s = 0;
-        if (!tier_next(io, a, lane, iter, s)) break;
+        if (!tier_next(io, a, iter, s)) break;
         const uint64_t b0 = a.offsets[s];
         const uint64_t Bl = a.offsets[s + 1] - b0;
         if (Bl + 64 > lds_bytes || Bl > 0xFFF0) { tier_defer(io, lane, s); continue; }
@@ -219,19 +228,17 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
 
         // ---- LDS carve, part 2: node arrays, buckets, pair table ---------------------
         uint32_t *nLR = (uint32_t *)(smem + off);   off += 4 * N;   // left | right << 16
-        int32_t *nSid = (int32_t *)(smem + off);    off += 4 * N;   // +id known, -id unknown, 0 dummy
         uint32_t *bri = (uint32_t *)(smem + off);   off += 4 * Nb;  // bucket: right | node << 16
         int16_t *nCost = (int16_t *)(smem + off);   off += 2 * N;
         uint16_t *nSlot = (uint16_t *)(smem + off); off += 2 * N;   // bucket slot of the node
         uint16_t *nStart = (uint16_t *)(smem + off); off += 2 * N;
-        uint16_t *nEnd = (uint16_t *)(smem + off);  off += 2 * N;
         off = align_up(off, 4);
         const uint32_t off_emit_end = off;                          // everything above is written by emit
         int32_t *bdp = (int32_t *)(smem + off);     off += 4 * Nb;  // bucket: dp (may overlay the match buffer)
         uint16_t *pre = (uint16_t *)(smem + off);   off += align_up(2 * N, 4);
         int16_t *mpair = (int16_t *)(smem + off);
         const uint32_t mcap = off < lds_bytes ? (lds_bytes - off) / 2 : 0;
-        if (N > 0xFFFF || off_emit_end > moff || off > lds_bytes || mcap < maxpairs) {
+        if (N > 0xFFFF || N > ncap || off_emit_end > moff || off > lds_bytes || mcap < maxpairs) {
             tier_defer(io, lane, s);
             continue;
         }
@@ -250,8 +257,8 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
                     const Morph8 mm = d.morph[id - 1 + r];
                     const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
                     nLR[t] = (uint16_t)mm.left | ((uint32_t)(uint16_t)mm.right << 16);
-                    nCost[t] = mm.cost; nSlot[t] = (uint16_t)slot; nStart[t] = (uint16_t)i; nEnd[t] = (uint16_t)end;
-                    nSid[t] = (int32_t)(id + r);
+                    nCost[t] = mm.cost; nSlot[t] = (uint16_t)slot; nStart[t] = (uint16_t)i;
+                    ninfo[t] = make_uint2(id + r, i | (end << 16));
                     bri[slot] = (uint32_t)(uint16_t)mm.right | (t << 16);
                     ++t;
                 }
@@ -264,8 +271,8 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
                     const Morph8 mm = d.unk_morph[ci.unk_first - 1 + (int32_t)r];
                     const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
                     nLR[t] = (uint16_t)mm.left | ((uint32_t)(uint16_t)mm.right << 16);
-                    nCost[t] = mm.cost; nSlot[t] = (uint16_t)slot; nStart[t] = (uint16_t)i; nEnd[t] = (uint16_t)end;
-                    nSid[t] = -(ci.unk_first + (int32_t)r);
+                    nCost[t] = mm.cost; nSlot[t] = (uint16_t)slot; nStart[t] = (uint16_t)i;
+                    ninfo[t] = make_uint2((uint32_t)(-(ci.unk_first + (int32_t)r)), i | (end << 16));
                     bri[slot] = (uint32_t)(uint16_t)mm.right | (t << 16);
                     ++t;
                 }
@@ -273,7 +280,8 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
         }
         if (lane == 0) {
             nLR[N - 1] = 0; nCost[N - 1] = 0; nSlot[N - 1] = NONE16;  // EOS: Morph(0,0,0)
-            nStart[N - 1] = (uint16_t)C; nEnd[N - 1] = (uint16_t)C; nSid[N - 1] = 0;
+            nStart[N - 1] = (uint16_t)C;
+            ninfo[N - 1] = make_uint2(0u, C | (C << 16));
             bri[0] = 0;  // BOS: right_id 0, node 0
         }
         __syncthreads();
@@ -335,24 +343,23 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
                     for (uint32_t tbase = 0; tbase < T; tbase += TG) {
                         const uint32_t ti = tbase + tl;
                         const bool tvalid = ti < T;
-                        uint32_t khi = 0xFFFFFFFFu, klo = 0xFFFFFFFFu;
+                        uint64_t key = ~0ull;
                         for (uint32_t jc = 0; jc < P; jc += 64) {
                             const uint32_t jj = jc + j;
-                            uint32_t chi = 0xFFFFFFFFu, clo = 0xFFFFFFFFu;
+                            uint64_t ck = ~0ull;
                             if (tvalid && jj < P) {
                                 const int32_t v = bdp[p0 + jj] + (int32_t)mpair[eb + ti * P + jj];
-                                chi = (uint32_t)v ^ 0x80000000u;
-                                clo = bri[p0 + jj] >> 16;
+                                ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (bri[p0 + jj] >> 16);
                             }
-                            group_min(chi, clo, lg);
-                            if (chi < khi || (chi == khi && clo < klo)) { khi = chi; klo = clo; }
+                            ck = group_min(ck, lg);
+                            key = ck < key ? ck : key;
                         }
                         if (tvalid && j == 0) {
                             const uint32_t t = t0 + ti;
-                            const int32_t tot = (int32_t)(khi ^ 0x80000000u) + (int32_t)nCost[t];
+                            const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + (int32_t)nCost[t];
                             int32_t dpv = INF;
                             uint32_t prv = NONE16;
-                            if (tot < INF) { dpv = tot; prv = klo; }  // .min(INF) then strict '<' (lattice.rs:135-136)
+                            if (tot < INF) { dpv = tot; prv = (uint32_t)key & 0xFFFFu; }  // .min(INF) then strict '<' (lattice.rs:135-136)
                             pre[t] = (uint16_t)prv;
                             const uint32_t sl = nSlot[t];
                             if (sl != NONE16) bdp[sl] = dpv;
@@ -381,12 +388,13 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
         {
             for (uint32_t k = lane; k < K; k += 64) {
                 const uint32_t t = path[K - 1 - k];
-                const int32_t sid = nSid[t];
+                const uint2 ni = ninfo[t];
+                const int32_t sid = (int32_t)ni.x;
                 kgpu_token tk;
                 if (sid == 0) {  // Dummy -> "EOS" (tokenizer.rs:27-28,34)
                     tk.id = 0; tk.cls = KGPU_CLASS_DUMMY; tk.position = B; tk.start = C; tk.end = C + 3; tk.byte_len = 0;
                 } else {
-                    const uint32_t st = nStart[t], en = nEnd[t], bs = cbyte[st];
+                    const uint32_t st = ni.y & 0xFFFFu, en = ni.y >> 16, bs = cbyte[st];
                     tk.id = sid > 0 ? sid : -sid;
                     tk.cls = sid > 0 ? KGPU_CLASS_KNOWN : KGPU_CLASS_UNKNOWN;
                     tk.position = bs; tk.start = st; tk.end = en; tk.byte_len = cbyte[en] - bs;
@@ -412,12 +420,13 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
 }
 
 int launch_tokenize_lds(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t lds_bytes, int n_workgroups,
-                        void *stream) {
+                        void *ninfo, uint32_t ncap, void *stream) {
     if (lds_bytes > 64 * 1024) {  // beyond the default dynamic-LDS cap the kernel has to opt in
         hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k_tokenize_lds, dim3(n_workgroups), dim3(64), lds_bytes, (hipStream_t)stream, d, a, io, lds_bytes);
+    hipLaunchKernelGGL(k_tokenize_lds, dim3(n_workgroups), dim3(64), lds_bytes, (hipStream_t)stream, d, a, io, lds_bytes,
+                       (uint2 *)ninfo, ncap);
     return (int)hipGetLastError();
 }
 
