@@ -92,7 +92,8 @@ struct kgpu_ctx {
     BatchArgs last{};
     bool pending = false;
     TierPlan plan{};
-    DevBuf ovf, ninfo[3];
+    uint32_t est_q8 = 64 * 256;  // LDS bytes per input byte, adapted after every batch
+    DevBuf ovf;
     // profiling
     bool profiling = false;   // KGPU_PROFILE_EVENTS
     bool count_work = false;  // KGPU_PROFILE_WORK
@@ -320,10 +321,6 @@ extern "C" int kgpu_ctx_create(kgpu_dict *d, void *hip_stream, kgpu_ctx **out) {
         return KGPU_ERR_HIP;
     }
     c->plan = default_tier_plan(d->device);
-    for (int k = 0; k < c->plan.n_lds_tiers; ++k) {
-        int rc = c->ninfo[k].ensure((size_t)c->plan.workgroups[k] * tier_node_cap(c->plan.lds_bytes[k]) * 8);
-        if (rc) { kgpu_ctx_destroy(c); return rc; }
-    }
     *out = c;
     return KGPU_OK;
 }
@@ -333,7 +330,7 @@ extern "C" void kgpu_ctx_destroy(kgpu_ctx *c) {
     (void)hipSetDevice(c->dict->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    c->arena.release(); c->ovf.release(); for (auto &b : c->ninfo) b.release(); c->stage.release(); c->tok_count.release();
+    c->arena.release(); c->ovf.release(); c->stage.release(); c->tok_count.release();
     c->in_utf8.release(); c->in_off.release(); c->out_tok.release(); c->out_off.release(); c->out_status.release();
     if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
@@ -399,7 +396,8 @@ extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const ui
     a.tok_count = (uint32_t *)c->tok_count.p;
     a.status = d_status; a.out = d_tokens; a.out_cap = token_capacity; a.tok_offsets = d_tok_offsets;
     a.count_work = c->count_work ? 1u : 0u;
-    for (int k = 0; k < 3; ++k) { a.ovf[k] = (uint32_t *)c->ovf.p + (size_t)k * (n + 1); a.ninfo[k] = c->ninfo[k].p; }
+    a.est_q8 = c->est_q8;
+    for (int k = 0; k < 3; ++k) a.ovf[k] = (uint32_t *)c->ovf.p + (size_t)k * (n + 1);
     return enqueue(c, a);
 }
 
@@ -423,6 +421,15 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
         break;
     }
     c->pending = false;
+    if (c->last.n && c->plan.n_lds_tiers > 1) {
+        // adapt the early-routing estimate: late deferrals (walk paid twice) push it up,
+        // early deferrals with no late ones let it drift back down
+        const unsigned late = c->h_ctl->late_count[0], all = c->h_ctl->ovf_count[0];
+        if ((uint64_t)late * 50 > c->last.n) c->est_q8 += c->est_q8 / 8;
+        else if (late == 0 && all > 0) c->est_q8 -= c->est_q8 / 64;
+        if (c->est_q8 < 16 * 256) c->est_q8 = 16 * 256;
+        if (c->est_q8 > 1024 * 256) c->est_q8 = 1024 * 256;
+    }
     if (c->profiling) {
         for (size_t i = 0; i + 3 <= c->ev_used; i += 3) {
             float t01 = 0, t12 = 0;

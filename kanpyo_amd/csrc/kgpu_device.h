@@ -98,6 +98,7 @@ struct TierIO {
     const unsigned int *in_count;   // nullptr: a.n
     uint32_t *out_list;             // overflow list for the next tier (nullptr: none)
     unsigned int *out_count;
+    unsigned int *late_count;       // deferrals that happened after the walk (feeds the routing estimate)
 };
 
 __device__ __forceinline__ bool tier_next(const TierIO &io, const BatchArgs &a, uint32_t iter, uint64_t &s) {

@@ -41,6 +41,7 @@ struct DictView {
 // ---- per-ctx control block in device memory (zeroed before every batch) ---
 struct Control {
     unsigned int ovf_count[4];        // sentences deferred from tier k to tier k+1
+    unsigned int late_count[4];       // ... of which only after the trie walk had been paid for
     unsigned long long arena_cursor;  // bump allocator over the scratch arena (bytes)
     unsigned int arena_overflow;      // a slab request did not fit
     unsigned int pad0;
@@ -62,7 +63,7 @@ struct BatchArgs {
     uint64_t *tok_offsets;        // n+1
     uint32_t count_work;          // accumulate kgpu_work into ctl->work (slow; off in timed runs)
     uint32_t *ovf[3];             // n entries each: work lists of tiers 1.. (filled by the tier before)
-    void *ninfo[3];               // per LDS tier: workgroups x tier_node_cap x 8 B node-info slabs
+    uint32_t est_q8;              // expected LDS bytes per input byte (x256): early tier routing
 };
 
 // Memory tiers of the fused tokenize kernel: tier k keeps the whole lattice of a
@@ -77,9 +78,6 @@ struct TierPlan {
 };
 
 // Launchers (kgpu_kernels.hip).  `stream` is a hipStream_t.
-// Nodes an LDS tier can hold at most (14 B of LDS per node are written by emit).
-inline uint32_t tier_node_cap(uint32_t lds_bytes) { return lds_bytes / 14; }
-
 int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan, void *stream);
 int launch_scan_compact(const BatchArgs &a, void *stream);
 TierPlan default_tier_plan(int device);

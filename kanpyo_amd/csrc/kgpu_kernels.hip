@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_compact(BatchArgs a) {
 }
 
 int launch_tokenize_lds(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t lds_bytes, int n_workgroups,
-                        void *ninfo, uint32_t ncap, void *stream);  // kgpu_lds.hip
+                        void *stream);  // kgpu_lds.hip
 
 // Tier chain: LDS tiers in ascending LDS size, then the general (HBM scratch)
 // kernel.  Every launch is a persistent grid pulling from its tier's work list.
@@ -325,16 +325,16 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan,
     const uint32_t *in_list = nullptr;
     const unsigned int *in_count = nullptr;
     for (int k = 0; k < plan.n_lds_tiers; ++k) {
-        TierIO io{in_list, in_count, a.ovf[k], &ctl->ovf_count[k]};
+        TierIO io{in_list, in_count, a.ovf[k], &ctl->ovf_count[k], &ctl->late_count[k]};
         uint64_t wg = plan.workgroups[k];
         if (k == 0 && a.n < wg) wg = a.n;
-        int e = launch_tokenize_lds(d, a, io, plan.lds_bytes[k], (int)(wg ? wg : 1), a.ninfo[k], tier_node_cap(plan.lds_bytes[k]), stream);
+        int e = launch_tokenize_lds(d, a, io, plan.lds_bytes[k], (int)(wg ? wg : 1), stream);
         if (e) return e;
         in_list = a.ovf[k];
         in_count = &ctl->ovf_count[k];
     }
     if (getenv("KGPU_DEBUG_SKIP_GENERAL")) return 0;
-    TierIO io{in_list, in_count, nullptr, nullptr};
+    TierIO io{in_list, in_count, nullptr, nullptr, nullptr};
     uint64_t wg = plan.general_workgroups;
     if (plan.n_lds_tiers == 0 && a.n < wg) wg = a.n;
     hipLaunchKernelGGL(k_tokenize_general, dim3((unsigned)(wg ? wg : 1)), dim3(64), 0, (hipStream_t)stream, d, a, io);

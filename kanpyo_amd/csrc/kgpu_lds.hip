@@ -23,6 +23,8 @@
 // set by the dynamic LDS size of the tier (see TierPlan).  A sentence that does
 // not fit the tier's LDS (or has > MAXM dictionary prefixes at one position) is
 // deferred, untouched, to the next tier.
+#include <cstdlib>
+
 #include "kgpu_device.h"
 
 namespace kgpu {
@@ -33,6 +35,7 @@ namespace {
 
 constexpr uint32_t MAXM = 8;         // trie matches buffered per start position
 constexpr uint32_t NONE16 = 0xFFFFu;
+constexpr uint32_t LEAN_MAXP = 16;   // positions with at most this many predecessors are swept lane-per-target
 
 // ---- DPP butterfly: min over aligned groups of 2^lg lanes, every lane gets it.
 // The key is one u64 (total ^ signbit) << 32 | predecessor node index, so one
@@ -65,13 +68,10 @@ __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v
 }  // namespace
 
 __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, TierIO io, uint32_t lds_bytes,
-                                                      uint2 *ninfo_base, uint32_t ncap) {
+                                                      uint32_t stop_after /* ablation timing only; 0 = run everything */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x;
     const int32_t base_root = d.da[1].base;
-    // {signed id, start | end << 16} per node: only the K nodes on the best path are ever
-    // read back, so this lives in a per-workgroup HBM slab, not in LDS
-    uint2 *ninfo = ninfo_base + (size_t)blockIdx.x * ncap;
     // profiling accumulators of this workgroup (flushed once at exit: per-sentence
     // atomics on a handful of hot words distort what they measure)
     uint64_t accW[7] = {0, 0, 0, 0, 0, 0, 0}, accP[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -81,13 +81,16 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
         if (!tier_next(io, a, iter, s)) break;
         const uint64_t b0 = a.offsets[s];
         const uint64_t Bl = a.offsets[s + 1] - b0;
-        if (Bl + 64 > lds_bytes || Bl > 0xFFF0) { tier_defer(io, lane, s); continue; }
+        // early routing: a sentence this long will not fit this tier's LDS (estimate adapted by
+        // the host from the previous batches) -- do not pay for a trie walk that is thrown away
+        if (Bl + 64 > lds_bytes || Bl > 0xFFF0 || ((Bl * a.est_q8) >> 8) + 768 > lds_bytes) { tier_defer(io, lane, s); continue; }
         const uint32_t B = (uint32_t)Bl;
         const uint8_t *gtext = a.utf8 + b0;
 
         uint64_t tick[9];
         const bool prof = a.count_work != 0;
 #define KGPU_TICK(k) do { if (prof) tick[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define KGPU_STOP(k) if (stop_after == (k)) { if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = 0; } continue; }
         KGPU_TICK(0);
         // ---- phase 0a: stage the sentence in LDS, count chars -----------------
         uint8_t *text = smem;
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
         uint8_t *mnch = smem + moff + 4 * C * MAXM;          // [C][MAXM] match length in chars
         __syncthreads();
         KGPU_TICK(1);
+        KGPU_STOP(1)
 
         // ---- phase 0b: decode + validate + category --------------------------------
         uint32_t cb = 0, bad = 0, lensum = 0;
@@ -156,6 +160,7 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
         __syncthreads();
 
         KGPU_TICK(2);
+        KGPU_STOP(2)
         // ---- phase 1: one trie walk per start position; count + park matches ------
         uint32_t wT = 0, ovf = 0;
         {
@@ -206,6 +211,7 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
         __syncthreads();
 
         KGPU_TICK(3);
+        KGPU_STOP(3)
         // ---- phase 2: prefix sums: node numbering, bucket offsets, pair offsets ------
         uint32_t ncarry = 1, bcarry = 0, ecarry = 0, maxpairs = 0;
         for (uint32_t i0 = 0; i0 < C + 2; i0 += 64) {
@@ -227,24 +233,27 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
         maxpairs = bcast32(maxpairs);
 
         // ---- LDS carve, part 2: node arrays, buckets, pair table ---------------------
-        uint32_t *nLR = (uint32_t *)(smem + off);   off += 4 * N;   // left | right << 16
-        uint32_t *bri = (uint32_t *)(smem + off);   off += 4 * Nb;  // bucket: right | node << 16
+        off = align_up(off, 8);
+        uint2 *bk = (uint2 *)(smem + off);          off += 8 * Nb;  // bucket (= edges[e]): {dp, right | node << 16}
+        int32_t *nSid = (int32_t *)(smem + off);    off += 4 * N;   // +id known, -id unknown, 0 dummy
+        uint16_t *nLeft = (uint16_t *)(smem + off); off += 2 * N;
         int16_t *nCost = (int16_t *)(smem + off);   off += 2 * N;
         uint16_t *nSlot = (uint16_t *)(smem + off); off += 2 * N;   // bucket slot of the node
         uint16_t *nStart = (uint16_t *)(smem + off); off += 2 * N;
         off = align_up(off, 4);
         const uint32_t off_emit_end = off;                          // everything above is written by emit
-        int32_t *bdp = (int32_t *)(smem + off);     off += 4 * Nb;  // bucket: dp (may overlay the match buffer)
-        uint16_t *pre = (uint16_t *)(smem + off);   off += align_up(2 * N, 4);
+        uint16_t *pre = (uint16_t *)(smem + off);   off += align_up(2 * N, 4);  // may overlay the match buffer
         int16_t *mpair = (int16_t *)(smem + off);
         const uint32_t mcap = off < lds_bytes ? (lds_bytes - off) / 2 : 0;
-        if (N > 0xFFFF || N > ncap || off_emit_end > moff || off > lds_bytes || mcap < maxpairs) {
+        if (N > 0xFFFF || off_emit_end > moff || off > lds_bytes || mcap < maxpairs) {
             tier_defer(io, lane, s);
+            if (lane == 0) atomicAdd(io.late_count, 1u);
             continue;
         }
         __syncthreads();
 
         KGPU_TICK(4);
+        KGPU_STOP(4)
         // ---- phase 3: emit nodes from the parked matches --------------------------------
         for (uint32_t i = lane; i < C; i += 64) {
             uint32_t t = nb[i];
@@ -256,10 +265,9 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
                 for (uint32_t r = 0; r < nrec; ++r) {  // lattice.rs:177-188
                     const Morph8 mm = d.morph[id - 1 + r];
                     const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
-                    nLR[t] = (uint16_t)mm.left | ((uint32_t)(uint16_t)mm.right << 16);
-                    nCost[t] = mm.cost; nSlot[t] = (uint16_t)slot; nStart[t] = (uint16_t)i;
-                    ninfo[t] = make_uint2(id + r, i | (end << 16));
-                    bri[slot] = (uint32_t)(uint16_t)mm.right | (t << 16);
+                    nLeft[t] = (uint16_t)mm.left; nCost[t] = mm.cost; nSlot[t] = (uint16_t)slot; nStart[t] = (uint16_t)i;
+                    nSid[t] = (int32_t)(id + r);
+                    bk[slot].y = (uint32_t)(uint16_t)mm.right | (t << 16);
                     ++t;
                 }
             }
@@ -270,24 +278,22 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
                 for (uint32_t r = 0; r < ci.unk_count; ++r) {
                     const Morph8 mm = d.unk_morph[ci.unk_first - 1 + (int32_t)r];
                     const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
-                    nLR[t] = (uint16_t)mm.left | ((uint32_t)(uint16_t)mm.right << 16);
-                    nCost[t] = mm.cost; nSlot[t] = (uint16_t)slot; nStart[t] = (uint16_t)i;
-                    ninfo[t] = make_uint2((uint32_t)(-(ci.unk_first + (int32_t)r)), i | (end << 16));
-                    bri[slot] = (uint32_t)(uint16_t)mm.right | (t << 16);
+                    nLeft[t] = (uint16_t)mm.left; nCost[t] = mm.cost; nSlot[t] = (uint16_t)slot; nStart[t] = (uint16_t)i;
+                    nSid[t] = -(ci.unk_first + (int32_t)r);
+                    bk[slot].y = (uint32_t)(uint16_t)mm.right | (t << 16);
                     ++t;
                 }
             }
         }
         if (lane == 0) {
-            nLR[N - 1] = 0; nCost[N - 1] = 0; nSlot[N - 1] = NONE16;  // EOS: Morph(0,0,0)
-            nStart[N - 1] = (uint16_t)C;
-            ninfo[N - 1] = make_uint2(0u, C | (C << 16));
-            bri[0] = 0;  // BOS: right_id 0, node 0
+            nLeft[N - 1] = 0; nCost[N - 1] = 0; nSlot[N - 1] = NONE16;  // EOS: Morph(0,0,0)
+            nStart[N - 1] = (uint16_t)C; nSid[N - 1] = 0;
+            bk[0] = make_uint2(0u, 0u);  // BOS: dp None -> 0 (lattice.rs:127), right_id 0, node 0
         }
         __syncthreads();
-        if (lane == 0) { bdp[0] = 0; pre[0] = NONE16; }  // BOS: dp None -> 0 (lattice.rs:127)
-
+        if (lane == 0) pre[0] = NONE16;
         KGPU_TICK(5);
+        KGPU_STOP(5)
         uint64_t cyc_gather = 0;
         // ---- phases 3b + 4, per block of positions whose pairs fit the pair table ----
         uint32_t qa = 0;
@@ -309,31 +315,66 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
             for (uint32_t t = ta + lane; t < tb; t += 64) {
                 const uint32_t q = nStart[t];
                 const uint32_t p0 = boff[q], P = boff[q + 1] - p0;
-                const uint32_t base = ebase[q] - eb0 + (t - nb[q]) * P;
-                const int16_t *col = d.conn + (size_t)d.conn_rows * (nLR[t] & 0xFFFFu);
+                const uint32_t tq0 = nb[q], T = nb[q + 1] - tq0, ti = t - tq0;
+                // pair (ti, j) lives at ti*P + j, or transposed at j*T + ti for the lean sweep
+                // (lane == target there, so lanes read consecutive i16)
+                const bool lean = P <= LEAN_MAXP && T <= 64;
+                const uint32_t base = ebase[q] - eb0 + (lean ? ti : ti * P), stride = lean ? T : 1u;
+                const int16_t *col = d.conn + (size_t)d.conn_rows * nLeft[t];
                 uint32_t j = 0;
                 for (; j + 4 <= P; j += 4) {  // 4 independent gathers in flight per lane
-                    const uint32_t r0 = bri[p0 + j] & 0xFFFFu, r1 = bri[p0 + j + 1] & 0xFFFFu;
-                    const uint32_t r2 = bri[p0 + j + 2] & 0xFFFFu, r3 = bri[p0 + j + 3] & 0xFFFFu;
+                    const uint32_t r0 = bk[p0 + j].y & 0xFFFFu, r1 = bk[p0 + j + 1].y & 0xFFFFu;
+                    const uint32_t r2 = bk[p0 + j + 2].y & 0xFFFFu, r3 = bk[p0 + j + 3].y & 0xFFFFu;
                     const int16_t c0 = col[r0], c1 = col[r1], c2 = col[r2], c3 = col[r3];
-                    mpair[base + j] = c0; mpair[base + j + 1] = c1; mpair[base + j + 2] = c2; mpair[base + j + 3] = c3;
+                    mpair[base + j * stride] = c0; mpair[base + (j + 1) * stride] = c1;
+                    mpair[base + (j + 2) * stride] = c2; mpair[base + (j + 3) * stride] = c3;
                 }
-                for (; j < P; ++j) mpair[base + j] = col[bri[p0 + j] & 0xFFFFu];
+                for (; j < P; ++j) mpair[base + j * stride] = col[bk[p0 + j].y & 0xFFFFu];
             }
             __syncthreads();
             if (prof) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
+            if (stop_after == 6) break;
 
             // -- 4: Viterbi sweep over the block (lattice.rs:116-142), LDS only
             uint32_t t0 = ta, p0 = boff[qa];
+            uint32_t t1n = nb[qa + 1], p1n = boff[qa + 1], ebn = eb0;  // position descriptors run one step ahead
             for (uint32_t q = qa; q < qb; ++q) {
-                const uint32_t t1 = nb[q + 1], p1 = boff[q + 1];
+                const uint32_t t1 = t1n, p1 = p1n;
                 const uint32_t T = t1 - t0, P = p1 - p0;
-                const uint32_t eb = ebase[q] - eb0;
+                const uint32_t eb = ebn - eb0;
+                if (q + 1 < qb) { t1n = nb[q + 2]; p1n = boff[q + 2]; ebn = ebase[q + 1]; }
                 if (P == 0) {  // nothing ends here: every target stays at INF with no predecessor
                     for (uint32_t t = t0 + lane; t < t1; t += 64) {
                         pre[t] = NONE16;
                         const uint32_t sl = nSlot[t];
-                        if (sl != NONE16) bdp[sl] = INF;
+                        if (sl != NONE16) bk[sl].x = (uint32_t)INF;
+                    }
+                } else if (P <= LEAN_MAXP && T <= 64) {
+                    // lean path (the common case): lane == target; the bucket is read four entries
+                    // per LDS round trip (same address in every lane: broadcast), the first-minimum
+                    // rule of lattice.rs:125-139 is the u64 min of (total ^ signbit, node index).
+                    if (lane < T) {
+                        const uint32_t t = t0 + lane;
+                        const int32_t cost = (int32_t)nCost[t];
+                        const uint32_t sl = nSlot[t];
+                        const int16_t *mp = mpair + eb + lane;
+                        uint64_t key = ~0ull;
+                        for (uint32_t j = 0; j < P; j += 4) {
+                            const uint32_t j1 = min(j + 1, P - 1), j2 = min(j + 2, P - 1), j3 = min(j + 3, P - 1);
+                            const uint2 e0 = bk[p0 + j], e1 = bk[p0 + j1], e2 = bk[p0 + j2], e3 = bk[p0 + j3];
+                            const int32_t m0 = mp[j * T], m1 = mp[j1 * T], m2 = mp[j2 * T], m3 = mp[j3 * T];
+                            const uint64_t k0 = ((uint64_t)((uint32_t)((int32_t)e0.x + m0) ^ 0x80000000u) << 32) | e0.y;
+                            const uint64_t k1 = ((uint64_t)((uint32_t)((int32_t)e1.x + m1) ^ 0x80000000u) << 32) | e1.y;
+                            const uint64_t k2 = ((uint64_t)((uint32_t)((int32_t)e2.x + m2) ^ 0x80000000u) << 32) | e2.y;
+                            const uint64_t k3 = ((uint64_t)((uint32_t)((int32_t)e3.x + m3) ^ 0x80000000u) << 32) | e3.y;
+                            const uint64_t ka = k0 < k1 ? k0 : k1, kb = k2 < k3 ? k2 : k3;
+                            const uint64_t kc = ka < kb ? ka : kb;
+                            key = kc < key ? kc : key;
+                        }
+                        const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + cost;
+                        const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
+                        pre[t] = (uint16_t)(ok ? ((uint32_t)key >> 16) : NONE16);
+                        if (sl != NONE16) bk[sl].x = (uint32_t)(ok ? tot : INF);
                     }
                 } else if (T) {
                     uint32_t lg = 32 - __clz(P - 1);  // ceil(log2 P), 0 for P == 1
@@ -343,26 +384,26 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
                     for (uint32_t tbase = 0; tbase < T; tbase += TG) {
                         const uint32_t ti = tbase + tl;
                         const bool tvalid = ti < T;
+                        // the group leader's finalisation operands ride in the same LDS round trip
+                        const int32_t cost = tvalid ? (int32_t)nCost[t0 + ti] : 0;
+                        const uint32_t sl = tvalid ? (uint32_t)nSlot[t0 + ti] : NONE16;
                         uint64_t key = ~0ull;
                         for (uint32_t jc = 0; jc < P; jc += 64) {
                             const uint32_t jj = jc + j;
                             uint64_t ck = ~0ull;
                             if (tvalid && jj < P) {
-                                const int32_t v = bdp[p0 + jj] + (int32_t)mpair[eb + ti * P + jj];
-                                ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (bri[p0 + jj] >> 16);
+                                const uint2 e = bk[p0 + jj];
+                                const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + ti * P + jj];
+                                ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (e.y >> 16);
                             }
                             ck = group_min(ck, lg);
                             key = ck < key ? ck : key;
                         }
                         if (tvalid && j == 0) {
-                            const uint32_t t = t0 + ti;
-                            const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + (int32_t)nCost[t];
-                            int32_t dpv = INF;
-                            uint32_t prv = NONE16;
-                            if (tot < INF) { dpv = tot; prv = (uint32_t)key & 0xFFFFu; }  // .min(INF) then strict '<' (lattice.rs:135-136)
-                            pre[t] = (uint16_t)prv;
-                            const uint32_t sl = nSlot[t];
-                            if (sl != NONE16) bdp[sl] = dpv;
+                            const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + cost;
+                            const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
+                            pre[t0 + ti] = (uint16_t)(ok ? ((uint32_t)key & 0xFFFFu) : NONE16);
+                            if (sl != NONE16) bk[sl].x = (uint32_t)(ok ? tot : INF);
                         }
                     }
                 }
@@ -374,6 +415,8 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
         }
 
         KGPU_TICK(6);
+        KGPU_STOP(6)
+        KGPU_STOP(7)
         // ---- phase 5: backtrace (lattice.rs:144-153) + Node -> Token (tokenizer.rs:22-43)
         uint32_t K = 0;
         if (lane == 0) {
@@ -388,13 +431,13 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
         {
             for (uint32_t k = lane; k < K; k += 64) {
                 const uint32_t t = path[K - 1 - k];
-                const uint2 ni = ninfo[t];
-                const int32_t sid = (int32_t)ni.x;
+                const int32_t sid = nSid[t];
                 kgpu_token tk;
                 if (sid == 0) {  // Dummy -> "EOS" (tokenizer.rs:27-28,34)
                     tk.id = 0; tk.cls = KGPU_CLASS_DUMMY; tk.position = B; tk.start = C; tk.end = C + 3; tk.byte_len = 0;
                 } else {
-                    const uint32_t st = ni.y & 0xFFFFu, en = ni.y >> 16, bs = cbyte[st];
+                    // a word is never last on the path (EOS is): it ends where its successor starts
+                    const uint32_t st = nStart[t], en = nStart[path[K - 2 - k]], bs = cbyte[st];
                     tk.id = sid > 0 ? sid : -sid;
                     tk.cls = sid > 0 ? KGPU_CLASS_KNOWN : KGPU_CLASS_UNKNOWN;
                     tk.position = bs; tk.start = st; tk.end = en; tk.byte_len = cbyte[en] - bs;
@@ -420,13 +463,13 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
 }
 
 int launch_tokenize_lds(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t lds_bytes, int n_workgroups,
-                        void *ninfo, uint32_t ncap, void *stream) {
+                        void *stream) {
+    static const uint32_t stop_after = getenv("KGPU_DEBUG_STOP") ? (uint32_t)atoi(getenv("KGPU_DEBUG_STOP")) : 0u;
     if (lds_bytes > 64 * 1024) {  // beyond the default dynamic-LDS cap the kernel has to opt in
         hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k_tokenize_lds, dim3(n_workgroups), dim3(64), lds_bytes, (hipStream_t)stream, d, a, io, lds_bytes,
-                       (uint2 *)ninfo, ncap);
+    hipLaunchKernelGGL(k_tokenize_lds, dim3(n_workgroups), dim3(64), lds_bytes, (hipStream_t)stream, d, a, io, lds_bytes, stop_after);
     return (int)hipGetLastError();
 }
 
