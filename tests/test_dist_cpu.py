@@ -1,0 +1,64 @@
+"""Multi-GPU path on CPU: world_size-2 gloo run of the round-robin sharding and
+the flat gatherv of token records (kanpyo_amd/dist.py).  The per-rank tokens come
+from the oracle (no GPU here); the gathered + reassembled stream must equal the
+oracle's stream over the unsharded corpus."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from kanpyo_amd import synth
+    from kanpyo_amd.dist import gather_tokens, reassemble, shard_indices
+    from kanpyo_amd.tokenizer import pack_sentences
+    from oracle import oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sd = synth.build_dict(6000, seed=5)
+    corpus = synth.make_corpus(sd, 301, 3, "cfg2") + ["", "あ"]  # odd count: ragged shards
+    orc = oracle.OracleTokenizer.from_dict(sd.dict)
+    mine = shard_indices(len(corpus), rank, world)
+    utf8, offs = pack_sentences([corpus[i] for i in mine])
+    r = orc.tokenize_batch(utf8, offs, 1)
+    tok = torch.from_numpy(r.tokens.view(np.int32).reshape(-1, 6).copy())
+    cnt = torch.from_numpy((r.offsets[1:] - r.offsets[:-1]).astype(np.int64))
+    tok_all, cnt_all, sizes = gather_tokens(tok, cnt, dst=0)
+    if rank == 0:
+        assert [s[1] for s in sizes] == [len(shard_indices(len(corpus), k, world)) for k in range(world)]
+        got_t, got_off = reassemble(tok_all.numpy(), cnt_all.numpy(), len(corpus), world)
+        full = orc.tokenize_batch(*pack_sentences(corpus), 1)
+        ok = np.array_equal(got_off.astype(np.uint64), full.offsets) and np.array_equal(
+            got_t.reshape(-1), full.tokens.view(np.int32).reshape(-1))
+        open(os.path.join(tmpdir, "result"), "w").write("ok" if ok else "mismatch")
+    else:
+        assert tok_all is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_round_robin_shard_and_gather_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert open(tmp_path / "result").read() == "ok"
+
+
+def test_unshard_order_is_a_permutation():
+    from kanpyo_amd.dist import shard_indices, unshard_order
+
+    for n, w in ((0, 2), (1, 2), (7, 2), (8, 8), (100, 3)):
+        perm = unshard_order(n, w)
+        gathered = np.concatenate([shard_indices(n, r, w) for r in range(w)]) if n else np.zeros(0, dtype=np.int64)
+        assert np.array_equal(gathered[perm], np.arange(n))
