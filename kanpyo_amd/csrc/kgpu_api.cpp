@@ -265,7 +265,27 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
     d->device = device;
     std::vector<uint8_t> cat(b->char_category, b->char_category + b->char_category_len);
     int rc;
-    if ((rc = upload(d, da, &d->view.da)) || (rc = upload(d, morphs, &d->view.morph)) ||
+    // First-character jump table: the walk from every start position begins with a whole
+    // character, so the 1-3 dependent node loads of its UTF-8 bytes (trie/da.rs:159-165) are
+    // memoised per BMP code point.  Keys are UTF-8 strings, so no key ends inside a character.
+    std::vector<DaNode> first(65536);
+    for (uint32_t cp = 0; cp < 65536; ++cp) {
+        uint8_t b[3]; int len;
+        if (cp < 0x80) { b[0] = (uint8_t)cp; len = 1; }
+        else if (cp < 0x800) { b[0] = 0xC0 | (cp >> 6); b[1] = 0x80 | (cp & 0x3F); len = 2; }
+        else { b[0] = 0xE0 | (cp >> 12); b[1] = 0x80 | ((cp >> 6) & 0x3F); b[2] = 0x80 | (cp & 0x3F); len = 3; }
+        int32_t pp = 1, steps = 0;
+        bool ok = true;
+        for (int k = 0; k < len; ++k) {
+            ++steps;
+            const int64_t q = (int64_t)da[(size_t)pp].base + b[k];
+            if (q < 0 || q >= (int64_t)da.size() || da[(size_t)q].check != pp) { ok = false; break; }
+            pp = (int32_t)q;
+        }
+        first[cp] = ok ? DaNode{pp, da[(size_t)pp].base} : DaNode{0, steps};
+    }
+    if ((rc = upload(d, first, &d->view.first)) ||
+        (rc = upload(d, da, &d->view.da)) || (rc = upload(d, morphs, &d->view.morph)) ||
         (rc = upload(d, unk_morphs, &d->view.unk_morph)) || (rc = upload(d, conn, &d->view.conn)) ||
         (rc = upload(d, cat, &d->view.cat)) || (rc = upload(d, cinfo, &d->view.cinfo))) {
         kgpu_dict_destroy(d);

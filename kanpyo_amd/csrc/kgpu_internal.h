@@ -31,6 +31,8 @@ enum : uint32_t { CAT_INVOKE = 1u, CAT_GROUP = 2u, CAT_HAS_UNK = 4u };
 
 struct DictView {
     const DaNode *da;        uint32_t da_len;
+    const DaNode *first;     // [65536] per BMP code point: {node, base[node]} after walking its UTF-8 bytes from
+                             // the root, or {0, byte steps attempted before the walk failed}
     const Morph8 *morph;     uint32_t n_morph;
     const Morph8 *unk_morph; uint32_t n_unk_morph;
     const int16_t *conn;     uint32_t conn_rows;  // element (right,left) at left*rows+right

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
         uint16_t *cbyte = (uint16_t *)(smem + off); off += 2 * (C + 2);  // char -> byte offset
         uint16_t *uspan = (uint16_t *)(smem + off); off += 2 * (C + 2);  // unknown span (0 = none)
         uint16_t *path = (uint16_t *)(smem + off);  off += 2 * (C + 2);  // backtrace
+        uint16_t *cp16 = (uint16_t *)(smem + off);  off += 2 * (C + 2);  // BMP code point (0xFFFF: not BMP)
         uint8_t *ccat = smem + off;                 off += align_up(C + 2, 4);
         uint8_t *mcnt = smem + off;                 off += align_up(C + 2, 4);
         const uint32_t mbytes = align_up(C * MAXM * 5, 16);
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
                 if (l == 4 && (cp < 0x10000 || cp > 0x10FFFF)) bad = 1;
                 lensum += l;
                 cbyte[ci] = (uint16_t)k;
+                cp16[ci] = (uint16_t)(cp < 0xFFFFu ? cp : 0xFFFFu);
                 ccat[ci] = bad ? 0 : (cp < d.cat_len ? d.cat[cp] : d.cat[0]);  // char_category_def.rs:33-38
             }
             cb += __popcll(m);
@@ -177,14 +179,49 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
                 carry_end = bcast32(run_end);
                 if (active) {
                     uint32_t cnt = 0, m = 0;
-                    wT += da_walk(d, text, cbyte[i], B, base_root, [&](uint32_t id, uint32_t nch) {
+                    auto on_match = [&](uint32_t id, uint32_t nch) {
                         if (m < MAXM && nch < 256) { mid[i * MAXM + m] = id; mnch[i * MAXM + m] = (uint8_t)nch; }
                         else ovf = 1;
                         ++m;
                         const uint32_t nrec = 1u + d.morph[id - 1].dup;  // index.rs:46-51
                         cnt += nrec;
                         atomicAdd(&boff[i + nch], nrec);
-                    });
+                    };
+                    const uint32_t cp = cp16[i];
+                    if (cp == 0xFFFFu) {
+                        wT += da_walk(d, text, cbyte[i], B, base_root, on_match);  // non-BMP first char: byte-wise from the root
+                    } else {
+                        const DaNode f = d.first[cp];  // {.base = node, .check = base[node]} or {0, steps}
+                        if (f.base == 0) {
+                            wT += (uint32_t)f.check;  // the walk dies inside the first character
+                        } else {
+                            // Each iteration sits on node p at byte k and issues BOTH dependent-free loads
+                            // together: the terminator probe of p (only where a key can end: a character
+                            // boundary) and the child for the next byte -- one memory latency per byte.
+                            int32_t p = f.base, bp = f.check;
+                            uint32_t k = cbyte[i + 1], nstart = 1;
+                            wT += k - cbyte[i];
+                            for (;;) {
+                                const bool more = k < B;
+                                const uint32_t c = more ? text[k] : 0u;
+                                const bool boundary = !more || (c & 0xC0) != 0x80;
+                                const uint32_t q = (uint32_t)(bp + (int32_t)c);
+                                const bool doprobe = boundary && (uint32_t)bp < d.da_len;
+                                const bool donext = more && q < d.da_len;
+                                DaNode t{0, 0}, nx{0, 0};
+                                if (doprobe) t = d.da[bp];  // + TERMINATOR (da.rs:166)
+                                if (donext) nx = d.da[q];
+                                if (doprobe && t.check == p && t.base < 0) on_match((uint32_t)(-t.base), nstart);
+                                if (!more) break;
+                                ++wT;
+                                if (!donext || nx.check != p) break;  // da.rs:162-165
+                                p = (int32_t)q;
+                                bp = nx.base;
+                                nstart += boundary;
+                                ++k;
+                            }
+                        }
+                    }
                     mcnt[i] = (uint8_t)(m < MAXM ? m : MAXM);
                     const CatInfo ci = d.cinfo[cat];
                     uint32_t span = 0;
