@@ -407,7 +407,7 @@ extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const ui
     if (c->pending && (rc = kgpu_ctx_sync(c, nullptr)) != KGPU_OK && rc != KGPU_ERR_CAPACITY) return rc;
     if ((rc = c->arena.ensure(ARENA_INITIAL)) || (rc = c->stage.ensure((size_t)(total_bytes + n + 1) * sizeof(kgpu_token) + 64)) ||
         (rc = c->tok_count.ensure((size_t)(n + 1) * 4)) ||
-        (rc = c->ovf.ensure((size_t)(n + 1) * 4 * 3)))
+        (rc = c->ovf.ensure((size_t)(n + 1) * 4 * 4)))
         return rc;
     BatchArgs a{};
     a.utf8 = d_utf8; a.offsets = d_offsets; a.n = n; a.ctl = c->d_ctl;
@@ -417,7 +417,7 @@ extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const ui
     a.status = d_status; a.out = d_tokens; a.out_cap = token_capacity; a.tok_offsets = d_tok_offsets;
     a.count_work = c->count_work ? 1u : 0u;
     a.est_q8 = c->est_q8;
-    for (int k = 0; k < 3; ++k) a.ovf[k] = (uint32_t *)c->ovf.p + (size_t)k * (n + 1);
+    for (int k = 0; k < 4; ++k) a.ovf[k] = (uint32_t *)c->ovf.p + (size_t)k * (n + 1);
     return enqueue(c, a);
 }
 
@@ -441,7 +441,7 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
         break;
     }
     c->pending = false;
-    if (c->last.n && c->plan.n_lds_tiers > 1) {
+    if (c->last.n && (c->plan.n_lds_tiers > 1 || c->plan.pack_lds_bytes)) {
         // adapt the early-routing estimate: late deferrals (walk paid twice) push it up,
         // early deferrals with no late ones let it drift back down
         const unsigned late = c->h_ctl->late_count[0], all = c->h_ctl->ovf_count[0];

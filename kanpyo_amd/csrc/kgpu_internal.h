@@ -64,7 +64,7 @@ struct BatchArgs {
     kgpu_token *out;  uint64_t out_cap;      // dense output
     uint64_t *tok_offsets;        // n+1
     uint32_t count_work;          // accumulate kgpu_work into ctl->work (slow; off in timed runs)
-    uint32_t *ovf[3];             // n entries each: work lists of tiers 1.. (filled by the tier before)
+    uint32_t *ovf[4];             // n entries each: work lists of tiers 1.. (filled by the tier before)
     uint32_t est_q8;              // expected LDS bytes per input byte (x256): early tier routing
 };
 
@@ -73,6 +73,9 @@ struct BatchArgs {
 // not fit is deferred to the next tier; the last tier is the general kernel
 // whose lattice lives in HBM scratch.
 struct TierPlan {
+    uint32_t pack_lds_bytes;  // 0: no packed first tier (kgpu_pack.hip)
+    uint32_t pack_size;       // sentences per pack: 1, 2 or 4
+    int pack_workgroups;
     int n_lds_tiers;
     uint32_t lds_bytes[3];
     int workgroups[3];       // persistent grid per LDS tier

@@ -22,7 +22,9 @@
 // bump-allocated HBM scratch slab, so any sentence length / lattice size works.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "kgpu_device.h"
 
@@ -318,25 +320,40 @@ __global__ __launch_bounds__(256) void k_compact(BatchArgs a) {
 int launch_tokenize_lds(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t lds_bytes, int n_workgroups,
                         void *stream);  // kgpu_lds.hip
 
-// Tier chain: LDS tiers in ascending LDS size, then the general (HBM scratch)
-// kernel.  Every launch is a persistent grid pulling from its tier's work list.
+int launch_tokenize_pack(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t lds_bytes, uint32_t gpack,
+                         int n_workgroups, void *stream);  // kgpu_pack.hip
+
+// Tier chain: the packed kernel (several short sentences per wavefront), then the
+// per-sentence LDS tiers in ascending LDS size, then the general (HBM scratch)
+// kernel.  Every launch is a persistent grid over its tier's work list.
 int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan, void *stream) {
     Control *ctl = a.ctl;
     const uint32_t *in_list = nullptr;
     const unsigned int *in_count = nullptr;
-    for (int k = 0; k < plan.n_lds_tiers; ++k) {
-        TierIO io{in_list, in_count, a.ovf[k], &ctl->ovf_count[k], &ctl->late_count[k]};
+    int li = 0;  // next free work list
+    if (plan.pack_lds_bytes && a.n) {
+        TierIO io{nullptr, nullptr, a.ovf[li], &ctl->ovf_count[li], &ctl->late_count[li]};
+        uint64_t packs = (a.n + plan.pack_size - 1) / plan.pack_size;
+        uint64_t wg = std::min<uint64_t>((uint64_t)plan.pack_workgroups, packs);
+        int e = launch_tokenize_pack(d, a, io, plan.pack_lds_bytes, plan.pack_size, (int)(wg ? wg : 1), stream);
+        if (e) return e;
+        in_list = a.ovf[li];
+        in_count = &ctl->ovf_count[li];
+        ++li;
+    }
+    for (int k = 0; k < plan.n_lds_tiers; ++k, ++li) {
+        TierIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], &ctl->late_count[li]};
         uint64_t wg = plan.workgroups[k];
-        if (k == 0 && a.n < wg) wg = a.n;
+        if (!in_list && a.n < wg) wg = a.n;
         int e = launch_tokenize_lds(d, a, io, plan.lds_bytes[k], (int)(wg ? wg : 1), stream);
         if (e) return e;
-        in_list = a.ovf[k];
-        in_count = &ctl->ovf_count[k];
+        in_list = a.ovf[li];
+        in_count = &ctl->ovf_count[li];
     }
     if (getenv("KGPU_DEBUG_SKIP_GENERAL")) return 0;
     TierIO io{in_list, in_count, nullptr, nullptr, nullptr};
     uint64_t wg = plan.general_workgroups;
-    if (plan.n_lds_tiers == 0 && a.n < wg) wg = a.n;
+    if (!in_list && a.n < wg) wg = a.n;
     hipLaunchKernelGGL(k_tokenize_general, dim3((unsigned)(wg ? wg : 1)), dim3(64), 0, (hipStream_t)stream, d, a, io);
     return (int)hipGetLastError();
 }
@@ -356,15 +373,22 @@ TierPlan default_tier_plan(int device) {
     int cus = 256;
     if (hipGetDeviceProperties(&p, device) == hipSuccess) cus = p.multiProcessorCount;
     TierPlan t{};
-    t.n_lds_tiers = 3;
-    t.lds_bytes[0] = 10 * 1024;   t.workgroups[0] = cus * 16;  // 16 sentences per CU in flight (160 KB / 10 KB)
-    t.lds_bytes[1] = 20 * 1024;   t.workgroups[1] = cus * 8;
-    t.lds_bytes[2] = 160 * 1024;  t.workgroups[2] = cus;       // one long sentence owns a CU's whole LDS
+    t.pack_lds_bytes = 40 * 1024; t.pack_size = 4; t.pack_workgroups = cus * 4;  // 4 packs x 4 sentences per CU
+    t.n_lds_tiers = 2;
+    t.lds_bytes[0] = 20 * 1024;   t.workgroups[0] = cus * 8;   // one sentence per wavefront
+    t.lds_bytes[1] = 160 * 1024;  t.workgroups[1] = cus;       // one long sentence owns a CU's whole LDS
+    if (const char *e = getenv("KGPU_PACK")) {  // "<KiB>,<sentences per pack>" or "0"
+        int kib = atoi(e), g = 4;
+        if (const char *c = strchr(e, ',')) g = atoi(c + 1);
+        if (g != 1 && g != 2 && g != 4) g = 4;
+        if (kib <= 0 || kib > 160) { t.pack_lds_bytes = 0; }
+        else { t.pack_lds_bytes = (uint32_t)kib * 1024; t.pack_size = (uint32_t)g; t.pack_workgroups = cus * (160 / kib); }
+    }
     t.general_workgroups = cus * 8;
     if (const char *e = getenv("KGPU_TIERS")) {  // e.g. "20,64,160" (KiB) or "0" for the general kernel only
         t.n_lds_tiers = 0;
         const char *q = e;
-        while (*q && t.n_lds_tiers < 3) {
+        while (*q && t.n_lds_tiers < 2) {
             int kib = atoi(q);
             if (kib > 0 && kib <= 160) {
                 t.lds_bytes[t.n_lds_tiers] = (uint32_t)kib * 1024;

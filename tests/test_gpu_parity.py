@@ -270,14 +270,18 @@ def test_device_api_and_work_counters(full):
     assert p["launches"] == 1 and p["tokenize_ms"] > 0
 
 
-@pytest.mark.parametrize("tiers", ["0", "8", "4,24", "20,64,160", "160"])
-def test_every_memory_tier_is_bit_exact(libs, tiers, monkeypatch):
-    """Force sentences through each tier chain (LDS sizes in KiB; '0' = HBM-scratch kernel only)."""
+@pytest.mark.parametrize("pack,tiers", [("0", "0"), ("0", "8"), ("0", "4,24"), ("0", "20,160"), ("0", "160"),
+                                        ("40,4", "20,160"), ("8,4", "8,160"), ("24,2", "0"), ("16,1", "160"), ("160,4", "0")])
+def test_every_memory_tier_is_bit_exact(libs, pack, tiers, monkeypatch):
+    """Force sentences through each tier chain: packed kernel (KiB, sentences per pack; '0' = off),
+    per-sentence LDS tiers (KiB; '0' = none), HBM-scratch kernel last."""
     from kanpyo_amd import Tokenizer, synth
 
     _, oracle = libs
+    monkeypatch.setenv("KGPU_PACK", pack)
     monkeypatch.setenv("KGPU_TIERS", tiers)
     sd = synth.build_dict(20000, seed=11)
     tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
     sents = synth.make_corpus(sd, 1500, 3, "cfg2") + synth.make_corpus(sd, 300, 4, "cfg3") + synth.make_corpus(sd, 2, 6, "cfg5") + ["", "あ", "ア" * 1500]
     assert_same(tok, orc, sents)
+    assert_same(tok, orc, ["", "", "", "あ", "", "すもも", ""])  # packs made of empties / ragged tail
