@@ -253,6 +253,40 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
         }
     }
 
+    // ---- frequency-rank the context ids -------------------------------------------------
+    // Context ids are only ever used to index the connection matrix (they are not part of a
+    // Token), so they can be renumbered freely.  Ranking both id spaces by how many dictionary
+    // records carry them puts the ids the lattice meets most often at the low indices: for a
+    // target (one matrix row of 2.6 KB) all its frequent predecessors then sit in the row's first
+    // cache line, and the frequent rows' first lines stay L1-resident.  The sweep's dominant L2
+    // consumer is exactly this gather (connection.rs:12-14 once per relaxation).
+    uint32_t bos_right = 0, eos_left = 0;
+    {
+        bool in_range = true;  // remap only when every id is a plain (row, col) index
+        for (auto *v : {&morphs, &unk_morphs})
+            for (auto &m : *v) if ((uint64_t)m.right >= rows || (uint64_t)m.left >= cols) in_range = false;
+        if (in_range && rows && cols && rows < 65536 && cols < 65536) {
+            std::vector<uint64_t> fr(rows, 0), fl(cols, 0);
+            for (auto *v : {&morphs, &unk_morphs}) for (auto &m : *v) { fr[m.right]++; fl[m.left]++; }
+            fr[0] += morphs.size(); fl[0] += morphs.size();  // BOS/EOS take part in every sentence
+            auto rank = [](const std::vector<uint64_t> &f) {
+                std::vector<uint32_t> order(f.size()), map(f.size());
+                for (uint32_t i = 0; i < f.size(); ++i) order[i] = i;
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return f[x] > f[y]; });
+                for (uint32_t k = 0; k < order.size(); ++k) map[order[k]] = k;
+                return map;
+            };
+            const std::vector<uint32_t> rmap = rank(fr), lmap = rank(fl);
+            std::vector<int16_t> c2(conn.size());
+            for (uint64_t l = 0; l < cols; ++l)
+                for (uint64_t r = 0; r < rows; ++r) c2[(size_t)(lmap[l] * rows + rmap[r])] = conn[(size_t)(l * rows + r)];
+            conn.swap(c2);
+            for (auto *v : {&morphs, &unk_morphs})
+                for (auto &m : *v) { m.right = (int16_t)rmap[m.right]; m.left = (int16_t)lmap[m.left]; }
+            bos_right = rmap[0]; eos_left = lmap[0];
+        }
+    }
+
     // ---- upload once to HBM ----
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -295,6 +329,7 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
     d->view.n_morph = (uint32_t)morphs.size();
     d->view.n_unk_morph = (uint32_t)unk_morphs.size();
     d->view.conn_rows = (uint32_t)rows;
+    d->view.bos_right = bos_right; d->view.eos_left = eos_left;
     d->view.cat_len = (uint32_t)std::min<size_t>(cat.size(), 0x110000);
     d->info.da_len = da.size(); d->info.n_morphs = morphs.size(); d->info.n_unk_morphs = unk_morphs.size();
     d->info.conn_rows = rows; d->info.conn_cols = cols; d->info.device = device;

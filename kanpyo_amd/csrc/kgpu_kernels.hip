@@ -197,9 +197,9 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             }
         }
         if (lane == 0) {
-            nodeA[N - 1] = make_uint4(0, 0, NONE, 0);  // EOS: Morph(0,0,0), id 0
+            nodeA[N - 1] = make_uint4(d.eos_left, 0, NONE, 0);  // EOS: Morph(0,0,0), id 0 (context id 0 in its ranked numbering)
             nodeB[N - 1] = make_uint2(C, C);
-            bucket[0] = make_uint4(0, 0, 0, 0);        // BOS: dp None -> 0 (lattice.rs:127)
+            bucket[0] = make_uint4(0, d.bos_right, 0, 0);  // BOS: dp None -> 0 (lattice.rs:127)
             pre[0] = NONE;
         }
         __syncthreads();
@@ -373,9 +373,12 @@ TierPlan default_tier_plan(int device) {
     int cus = 256;
     if (hipGetDeviceProperties(&p, device) == hipSuccess) cus = p.multiProcessorCount;
     TierPlan t{};
-    t.pack_lds_bytes = 40 * 1024; t.pack_size = 4; t.pack_workgroups = cus * 4;  // 4 packs x 4 sentences per CU
+    // The packed first tier (kgpu_pack.hip) is OFF by default: it cuts VALU/SALU work per sentence
+    // by 2-3x but not the L1-miss traffic that bounds throughput, and it runs 4x fewer waves
+    // (measured 25 M vs 30 M sentences/s on cfg 2).  KGPU_PACK=40,4 turns it on.
+    t.pack_lds_bytes = 0; t.pack_size = 4; t.pack_workgroups = cus * 4;
     t.n_lds_tiers = 2;
-    t.lds_bytes[0] = 20 * 1024;   t.workgroups[0] = cus * 8;   // one sentence per wavefront
+    t.lds_bytes[0] = 16 * 1024;   t.workgroups[0] = cus * 10;  // one sentence per wavefront, 10 per CU
     t.lds_bytes[1] = 160 * 1024;  t.workgroups[1] = cus;       // one long sentence owns a CU's whole LDS
     if (const char *e = getenv("KGPU_PACK")) {  // "<KiB>,<sentences per pack>" or "0"
         int kib = atoi(e), g = 4;

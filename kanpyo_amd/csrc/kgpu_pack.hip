@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64) void k_tokenize_pack(DictView d, BatchArgs a, T
         for (uint32_t i = lane; i < P; i += 64) {
             uint32_t t = nb[i];
             if (i == send[i]) {  // EOS: Morph(0,0,0), id 0, never a predecessor
-                nLeft[t] = 0; nCost[t] = 0; nSlot[t] = NONE16; nStart[t] = (uint16_t)i; nSid[t] = 0;
+                nLeft[t] = (uint16_t)d.eos_left; nCost[t] = 0; nSlot[t] = NONE16; nStart[t] = (uint16_t)i; nSid[t] = 0;
                 continue;
             }
             const uint32_t nm = mcnt[i];
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64) void k_tokenize_pack(DictView d, BatchArgs a, T
         if (lane < G) {  // BOS of sentence `lane`: dp None -> 0 (lattice.rs:127), right_id 0
             const uint32_t g0 = stab[lane * 4 + 0];
             const uint32_t slot = boff[g0] + atomicAdd(&bfill[g0], 1u);
-            bk[slot] = make_uint2(0u, BOSMARK << 16);
+            bk[slot] = make_uint2(0u, (BOSMARK << 16) | d.bos_right);
         }
         __syncthreads();
 
