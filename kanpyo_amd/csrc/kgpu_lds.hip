@@ -323,9 +323,9 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
             }
         }
         if (lane == 0) {
-            nLeft[N - 1] = 0; nCost[N - 1] = 0; nSlot[N - 1] = NONE16;  // EOS: Morph(0,0,0)
+            nLeft[N - 1] = (uint16_t)d.eos_left; nCost[N - 1] = 0; nSlot[N - 1] = NONE16;  // EOS: Morph(0,0,0), ranked id
             nStart[N - 1] = (uint16_t)C; nSid[N - 1] = 0;
-            bk[0] = make_uint2(0u, 0u);  // BOS: dp None -> 0 (lattice.rs:127), right_id 0, node 0
+            bk[0] = make_uint2(0u, d.bos_right);  // BOS: dp None -> 0 (lattice.rs:127), right_id 0 (ranked), node 0
         }
         __syncthreads();
         if (lane == 0) pre[0] = NONE16;
