@@ -35,7 +35,6 @@ namespace {
 
 constexpr uint32_t MAXM = 8;         // trie matches buffered per start position
 constexpr uint32_t NONE16 = 0xFFFFu;
-constexpr uint32_t LEAN_MAXP = 16;   // positions with at most this many predecessors are swept lane-per-target
 
 // ---- DPP butterfly: min over aligned groups of 2^lg lanes, every lane gets it.
 // The key is one u64 (total ^ signbit) << 32 | predecessor node index, so one
@@ -352,11 +351,9 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
             for (uint32_t t = ta + lane; t < tb; t += 64) {
                 const uint32_t q = nStart[t];
                 const uint32_t p0 = boff[q], P = boff[q + 1] - p0;
-                const uint32_t tq0 = nb[q], T = nb[q + 1] - tq0, ti = t - tq0;
-                // pair (ti, j) lives at ti*P + j, or transposed at j*T + ti for the lean sweep
-                // (lane == target there, so lanes read consecutive i16)
-                const bool lean = P <= LEAN_MAXP && T <= 64;
-                const uint32_t base = ebase[q] - eb0 + (lean ? ti : ti * P), stride = lean ? T : 1u;
+                const uint32_t ti = t - nb[q];
+                const uint32_t base = ebase[q] - eb0 + ti * P;  // pair (ti, j) lives at ti*P + j
+                const uint32_t stride = 1u;
                 const int16_t *col = d.conn + (size_t)d.conn_rows * nLeft[t];
                 uint32_t j = 0;
                 for (; j + 4 <= P; j += 4) {  // 4 independent gathers in flight per lane
@@ -372,81 +369,87 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
             if (prof) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
             if (stop_after == 6) break;
 
-            // -- 4: Viterbi sweep over the block (lattice.rs:116-142), LDS only
-            uint32_t t0 = ta, p0 = boff[qa];
-            uint32_t t1n = nb[qa + 1], p1n = boff[qa + 1], ebn = eb0;  // position descriptors run one step ahead
-            for (uint32_t q = qa; q < qb; ++q) {
-                const uint32_t t1 = t1n, p1 = p1n;
-                const uint32_t T = t1 - t0, P = p1 - p0;
-                const uint32_t eb = ebn - eb0;
-                if (q + 1 < qb) { t1n = nb[q + 2]; p1n = boff[q + 2]; ebn = ebase[q + 1]; }
-                if (P == 0) {  // nothing ends here: every target stays at INF with no predecessor
-                    for (uint32_t t = t0 + lane; t < t1; t += 64) {
-                        pre[t] = NONE16;
-                        const uint32_t sl = nSlot[t];
-                        if (sl != NONE16) bk[sl].x = (uint32_t)INF;
-                    }
-                } else if (P <= LEAN_MAXP && T <= 64) {
-                    // lean path (the common case): lane == target; the bucket is read four entries
-                    // per LDS round trip (same address in every lane: broadcast), the first-minimum
-                    // rule of lattice.rs:125-139 is the u64 min of (total ^ signbit, node index).
-                    if (lane < T) {
-                        const uint32_t t = t0 + lane;
-                        const int32_t cost = (int32_t)nCost[t];
-                        const uint32_t sl = nSlot[t];
-                        const int16_t *mp = mpair + eb + lane;
-                        uint64_t key = ~0ull;
-                        for (uint32_t j = 0; j < P; j += 4) {
-                            const uint32_t j1 = min(j + 1, P - 1), j2 = min(j + 2, P - 1), j3 = min(j + 3, P - 1);
-                            const uint2 e0 = bk[p0 + j], e1 = bk[p0 + j1], e2 = bk[p0 + j2], e3 = bk[p0 + j3];
-                            const int32_t m0 = mp[j * T], m1 = mp[j1 * T], m2 = mp[j2 * T], m3 = mp[j3 * T];
-                            const uint64_t k0 = ((uint64_t)((uint32_t)((int32_t)e0.x + m0) ^ 0x80000000u) << 32) | e0.y;
-                            const uint64_t k1 = ((uint64_t)((uint32_t)((int32_t)e1.x + m1) ^ 0x80000000u) << 32) | e1.y;
-                            const uint64_t k2 = ((uint64_t)((uint32_t)((int32_t)e2.x + m2) ^ 0x80000000u) << 32) | e2.y;
-                            const uint64_t k3 = ((uint64_t)((uint32_t)((int32_t)e3.x + m3) ^ 0x80000000u) << 32) | e3.y;
-                            const uint64_t ka = k0 < k1 ? k0 : k1, kb = k2 < k3 ? k2 : k3;
-                            const uint64_t kc = ka < kb ? ka : kb;
-                            key = kc < key ? kc : key;
+            // -- 4: Viterbi sweep over the block (lattice.rs:116-142), LDS only.
+            // The sweep is one dependent chain per position, so what counts is the length of that
+            // chain, not arithmetic.  Position descriptors are therefore kept in VGPRs, one
+            // position per lane for 64 positions at a time, and broadcast with v_readlane (no LDS
+            // round trip, no wait); the common shape -- ceil_pow2(P) * T <= 64 lanes, P <= 16 --
+            // is straight-line code: pair (ti, j) on lane ti * Pp + j, one batch of LDS reads, a DPP
+            // butterfly min on the u64 key (total ^ signbit, predecessor node index), leaders write.
+            for (uint32_t qc = qa; qc < qb; qc += 64) {
+                const uint32_t ql = qc + lane;
+                uint32_t dT = 0, dP = 0, dt0 = 0, dp0 = 0, deb = 0;
+                if (ql < qb) {
+                    dt0 = nb[ql]; dT = nb[ql + 1] - dt0;
+                    dp0 = boff[ql]; dP = boff[ql + 1] - dp0;
+                    deb = ebase[ql] - eb0;
+                }
+                const uint32_t nq = min(64u, qb - qc);
+                for (uint32_t r = 0; r < nq; ++r) {
+                    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)dT, (int)r);
+                    const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)dP, (int)r);
+                    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)dt0, (int)r);
+                    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)dp0, (int)r);
+                    const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)deb, (int)r);
+                    uint32_t lg = P > 1 ? 32 - __clz(P - 1) : 0;  // ceil(log2 P)
+                    if (P == 0) {  // nothing ends here: every target stays at INF with no predecessor
+                        for (uint32_t t = t0 + lane; t < t0 + T; t += 64) {
+                            pre[t] = NONE16;
+                            const uint32_t sl = nSlot[t];
+                            if (sl != NONE16) bk[sl].x = (uint32_t)INF;
                         }
-                        const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + cost;
-                        const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
-                        pre[t] = (uint16_t)(ok ? ((uint32_t)key >> 16) : NONE16);
-                        if (sl != NONE16) bk[sl].x = (uint32_t)(ok ? tot : INF);
-                    }
-                } else if (T) {
-                    uint32_t lg = 32 - __clz(P - 1);  // ceil(log2 P), 0 for P == 1
-                    if (P == 1) lg = 0;
-                    if (lg > 6) lg = 6;
-                    const uint32_t j = lane & ((1u << lg) - 1), tl = lane >> lg, TG = 64u >> lg;
-                    for (uint32_t tbase = 0; tbase < T; tbase += TG) {
-                        const uint32_t ti = tbase + tl;
-                        const bool tvalid = ti < T;
-                        // the group leader's finalisation operands ride in the same LDS round trip
-                        const int32_t cost = tvalid ? (int32_t)nCost[t0 + ti] : 0;
-                        const uint32_t sl = tvalid ? (uint32_t)nSlot[t0 + ti] : NONE16;
+                    } else if (lg <= 4 && (T << lg) <= 64) {
+                        const uint32_t ti = lane >> lg, j = lane & ((1u << lg) - 1);
+                        const bool tv = ti < T;
+                        const uint32_t tt = t0 + (tv ? ti : 0);
+                        const int32_t cost = (int32_t)nCost[tt];  // finalisation operands ride in the same round trip
+                        const uint32_t sl = nSlot[tt];
                         uint64_t key = ~0ull;
-                        for (uint32_t jc = 0; jc < P; jc += 64) {
-                            const uint32_t jj = jc + j;
-                            uint64_t ck = ~0ull;
-                            if (tvalid && jj < P) {
-                                const uint2 e = bk[p0 + jj];
-                                const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + ti * P + jj];
-                                ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (e.y >> 16);
-                            }
-                            ck = group_min(ck, lg);
-                            key = ck < key ? ck : key;
+                        if (tv && j < P) {
+                            const uint2 e = bk[p0 + j];
+                            const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + ti * P + j];
+                            key = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (e.y >> 16);
                         }
-                        if (tvalid && j == 0) {
+                        if (lg >= 1) key = dpp_min_step<0xB1>(key);
+                        if (lg >= 2) key = dpp_min_step<0x4E>(key);
+                        if (lg >= 3) key = dpp_min_step<0x141>(key);
+                        if (lg >= 4) key = dpp_min_step<0x140>(key);
+                        if (tv && j == 0) {
                             const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + cost;
                             const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
-                            pre[t0 + ti] = (uint16_t)(ok ? ((uint32_t)key & 0xFFFFu) : NONE16);
+                            pre[tt] = (uint16_t)(ok ? ((uint32_t)key & 0xFFFFu) : NONE16);
                             if (sl != NONE16) bk[sl].x = (uint32_t)(ok ? tot : INF);
                         }
+                    } else if (T) {  // any shape: loop over target groups and predecessor chunks
+                        if (lg > 6) lg = 6;
+                        const uint32_t j = lane & ((1u << lg) - 1), tl = lane >> lg, TG = 64u >> lg;
+                        for (uint32_t tbase = 0; tbase < T; tbase += TG) {
+                            const uint32_t ti = tbase + tl;
+                            const bool tvalid = ti < T;
+                            const int32_t cost = tvalid ? (int32_t)nCost[t0 + ti] : 0;
+                            const uint32_t sl = tvalid ? (uint32_t)nSlot[t0 + ti] : NONE16;
+                            uint64_t key = ~0ull;
+                            for (uint32_t jc = 0; jc < P; jc += 64) {
+                                const uint32_t jj = jc + j;
+                                uint64_t ck = ~0ull;
+                                if (tvalid && jj < P) {
+                                    const uint2 e = bk[p0 + jj];
+                                    const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + ti * P + jj];
+                                    ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (e.y >> 16);
+                                }
+                                ck = group_min(ck, lg);
+                                key = ck < key ? ck : key;
+                            }
+                            if (tvalid && j == 0) {
+                                const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + cost;
+                                const bool ok = tot < INF;
+                                pre[t0 + ti] = (uint16_t)(ok ? ((uint32_t)key & 0xFFFFu) : NONE16);
+                                if (sl != NONE16) bk[sl].x = (uint32_t)(ok ? tot : INF);
+                            }
+                        }
                     }
+                    __syncthreads();
                 }
-                t0 = t1;
-                p0 = p1;
-                __syncthreads();
             }
             qa = qb;
         }
