@@ -285,3 +285,23 @@ def test_every_memory_tier_is_bit_exact(libs, pack, tiers, monkeypatch):
     sents = synth.make_corpus(sd, 1500, 3, "cfg2") + synth.make_corpus(sd, 300, 4, "cfg3") + synth.make_corpus(sd, 2, 6, "cfg5") + ["", "あ", "ア" * 1500]
     assert_same(tok, orc, sents)
     assert_same(tok, orc, ["", "", "", "あ", "", "すもも", ""])  # packs made of empties / ragged tail
+
+
+def test_built_and_reloaded_dictionary(libs, tmp_path):
+    """8(f): a dictionary built from MeCab-format sources, saved as a Kanpyo .dict, reloaded and
+    uploaded tokenises bit-exactly like the oracle over the same blobs."""
+    from test_builder_cpu import CHAR_DEF, LEX_A, LEX_B, UNK_DEF, _matrix
+
+    from kanpyo_amd import Tokenizer, builder
+    from kanpyo_amd.dictfile import format_tokens, load_dict, save_dict
+
+    _, oracle = libs
+    df = builder.build(builder.parse_csv(LEX_A) + builder.parse_csv(LEX_B), _matrix(), CHAR_DEF, builder.parse_unk_def(UNK_DEF))
+    p = tmp_path / "mini.dict"
+    save_dict(df, str(p))
+    back = load_dict(str(p))
+    tok, orc = Tokenizer(back.dict), oracle.OracleTokenizer.from_dict(df.dict)
+    sents = ["東京都に住む", "東京に住む東京都", "トウキョウ 123 に", "", "a,b都", "住", "にににに"]
+    assert_same(tok, orc, sents, nthreads=1)
+    lines = format_tokens(tok.tokenize("東京都に住む"), back)
+    assert lines.splitlines()[-1] == "EOS\t" and "トウキョウト" in lines
