@@ -378,7 +378,7 @@ TierPlan default_tier_plan(int device) {
     // (measured 25 M vs 30 M sentences/s on cfg 2).  KGPU_PACK=40,4 turns it on.
     t.pack_lds_bytes = 0; t.pack_size = 4; t.pack_workgroups = cus * 4;
     t.n_lds_tiers = 2;
-    t.lds_bytes[0] = 16 * 1024;   t.workgroups[0] = cus * 10;  // one sentence per wavefront, 10 per CU
+    t.lds_bytes[0] = 14 * 1024;   t.workgroups[0] = cus * 11;  // one sentence per wavefront, 11 per CU (best of 12..20 KB on cfg 2)
     t.lds_bytes[1] = 160 * 1024;  t.workgroups[1] = cus;       // one long sentence owns a CU's whole LDS
     if (const char *e = getenv("KGPU_PACK")) {  // "<KiB>,<sentences per pack>" or "0"
         int kib = atoi(e), g = 4;
