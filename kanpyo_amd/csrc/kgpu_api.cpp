@@ -354,7 +354,7 @@ extern "C" int kgpu_dict_get_info(const kgpu_dict *d, kgpu_dict_info *out) {
 
 // ----------------------------------------------------------------------- ctx
 
-static constexpr size_t ARENA_INITIAL = 1ull << 31;  // 2 GiB of the 288 GB
+static constexpr size_t ARENA_INITIAL = 1ull << 28;  // 256 MiB; only the general (HBM-scratch) kernel uses it, grows x2 on demand
 static constexpr size_t ARENA_MAX = 1ull << 37;      // 128 GiB
 
 extern "C" int kgpu_ctx_create(kgpu_dict *d, void *hip_stream, kgpu_ctx **out) {
