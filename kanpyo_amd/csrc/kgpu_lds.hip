@@ -24,6 +24,7 @@
 // not fit the tier's LDS (or has > MAXM dictionary prefixes at one position) is
 // deferred, untouched, to the next tier.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kgpu_device.h"
 
@@ -378,11 +379,13 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
             // butterfly min on the u64 key (total ^ signbit, predecessor node index), leaders write.
             for (uint32_t qc = qa; qc < qb; qc += 64) {
                 const uint32_t ql = qc + lane;
-                uint32_t dT = 0, dP = 0, dt0 = 0, dp0 = 0, deb = 0;
+                uint32_t dT = 0, dP = 0, dt0 = 0, dp0 = 0, deb = 0, dflag = 0;
                 if (ql < qb) {
                     dt0 = nb[ql]; dT = nb[ql + 1] - dt0;
                     dp0 = boff[ql]; dP = boff[ql + 1] - dp0;
                     deb = ebase[ql] - eb0;
+                    const uint32_t lgv = dP > 1 ? 32 - __clz(dP - 1) : 0;  // ceil(log2 P)
+                    dflag = (lgv & 7u) | ((dP != 0 && lgv <= 4 && (dT << lgv) <= 64) ? 8u : 0u);
                 }
                 const uint32_t nq = min(64u, qb - qc);
                 for (uint32_t r = 0; r < nq; ++r) {
@@ -391,36 +394,50 @@ __global__ __launch_bounds__(64) void k_tokenize_lds(DictView d, BatchArgs a, Ti
                     const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)dt0, (int)r);
                     const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)dp0, (int)r);
                     const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)deb, (int)r);
-                    uint32_t lg = P > 1 ? 32 - __clz(P - 1) : 0;  // ceil(log2 P)
-                    if (P == 0) {  // nothing ends here: every target stays at INF with no predecessor
+                    const uint32_t flag = (uint32_t)__builtin_amdgcn_readlane((int)dflag, (int)r);
+                    uint32_t lg = flag & 7u;  // ceil(log2 P), precomputed per position
+                    if (flag & 8u) {
+                        // fast shape: one straight-line body per group size (compile-time shifts, exact
+                        // number of DPP steps, no inner branches)
+                        auto fast = [&](auto LGc) {
+                            constexpr uint32_t LG = decltype(LGc)::value;
+                            const uint32_t ti = lane >> LG, j = lane & ((1u << LG) - 1);
+                            const bool tv = ti < T;
+                            const uint32_t tt = t0 + (tv ? ti : 0);
+                            const int32_t cost = (int32_t)nCost[tt];  // finalisation operands ride in the same round trip
+                            const uint32_t sl = nSlot[tt];
+                            uint64_t key = ~0ull;
+                            if (tv && j < P) {
+                                const uint2 e = bk[p0 + j];
+                                const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + ti * P + j];
+                                key = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (e.y >> 16);
+                            }
+                            if constexpr (LG >= 1) key = dpp_min_step<0xB1>(key);
+                            if constexpr (LG >= 2) key = dpp_min_step<0x4E>(key);
+                            if constexpr (LG >= 3) key = dpp_min_step<0x141>(key);
+                            if constexpr (LG >= 4) key = dpp_min_step<0x140>(key);
+                            if (tv && j == 0) {
+                                const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + cost;
+                                const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
+                                pre[tt] = (uint16_t)(ok ? ((uint32_t)key & 0xFFFFu) : NONE16);
+                                if (sl != NONE16) bk[sl].x = (uint32_t)(ok ? tot : INF);
+                            }
+                        };
+                        switch (lg) {
+                            case 0: fast(std::integral_constant<uint32_t, 0>{}); break;
+                            case 1: fast(std::integral_constant<uint32_t, 1>{}); break;
+                            case 2: fast(std::integral_constant<uint32_t, 2>{}); break;
+                            case 3: fast(std::integral_constant<uint32_t, 3>{}); break;
+                            default: fast(std::integral_constant<uint32_t, 4>{}); break;
+                        }
+                    } else if (P == 0) {  // nothing ends here: every target stays at INF with no predecessor
                         for (uint32_t t = t0 + lane; t < t0 + T; t += 64) {
                             pre[t] = NONE16;
                             const uint32_t sl = nSlot[t];
                             if (sl != NONE16) bk[sl].x = (uint32_t)INF;
                         }
-                    } else if (lg <= 4 && (T << lg) <= 64) {
-                        const uint32_t ti = lane >> lg, j = lane & ((1u << lg) - 1);
-                        const bool tv = ti < T;
-                        const uint32_t tt = t0 + (tv ? ti : 0);
-                        const int32_t cost = (int32_t)nCost[tt];  // finalisation operands ride in the same round trip
-                        const uint32_t sl = nSlot[tt];
-                        uint64_t key = ~0ull;
-                        if (tv && j < P) {
-                            const uint2 e = bk[p0 + j];
-                            const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + ti * P + j];
-                            key = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (e.y >> 16);
-                        }
-                        if (lg >= 1) key = dpp_min_step<0xB1>(key);
-                        if (lg >= 2) key = dpp_min_step<0x4E>(key);
-                        if (lg >= 3) key = dpp_min_step<0x141>(key);
-                        if (lg >= 4) key = dpp_min_step<0x140>(key);
-                        if (tv && j == 0) {
-                            const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + cost;
-                            const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
-                            pre[tt] = (uint16_t)(ok ? ((uint32_t)key & 0xFFFFu) : NONE16);
-                            if (sl != NONE16) bk[sl].x = (uint32_t)(ok ? tot : INF);
-                        }
                     } else if (T) {  // any shape: loop over target groups and predecessor chunks
+                        lg = P > 1 ? 32 - __clz(P - 1) : 0;
                         if (lg > 6) lg = 6;
                         const uint32_t j = lane & ((1u << lg) - 1), tl = lane >> lg, TG = 64u >> lg;
                         for (uint32_t tbase = 0; tbase < T; tbase += TG) {
