@@ -45,7 +45,14 @@ def main():
     ap.add_argument("--queue", type=int, default=8, help="batches in flight (one ctx/stream each)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="lower bound of CPU-baseline work")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (self-test)")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: everything else that libraries print there (RCCL's
+    # banner at communicator creation, ...) is routed to stderr until the result is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -61,13 +68,17 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X: the HIP path has no CPU fallback"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from kanpyo_amd import Tokenizer, synth
     from kanpyo_amd.device import PROFILE_EVENTS, PROFILE_OFF, PROFILE_WORK, DeviceContext
-    from kanpyo_amd.dist import gather_tokens
+    from kanpyo_amd.dist import ChunkedGather
     from kanpyo_amd.tokenizer import pack_sentences
 
     # ---- workload: dictionary replicated per GPU, one 100k-sentence shard per rank
@@ -84,7 +95,7 @@ def main():
     K, W, Q = args.steps, args.warmup, max(1, args.queue)
     ctxs = [DeviceContext(tok) for _ in range(Q)]
     n_out = max(K, W, 1)
-    out_tok = [torch.empty((cap, 6), dtype=torch.int32, device=dev) for _ in range(min(n_out, 8) if world == 1 else n_out)]
+    out_tok = [torch.empty((cap, 6), dtype=torch.int32, device=dev) for _ in range(max(2 * Q, 8))]
     out_off = [torch.empty(BATCH + 1, dtype=torch.int64, device=dev) for _ in range(len(out_tok))]
     out_st = [torch.empty(BATCH, dtype=torch.uint8, device=dev) for _ in range(len(out_tok))]
 
@@ -116,38 +127,59 @@ def main():
         nt = ctxs[0].sync()
         sample_tokens = (out_tok[0][:nt].cpu().numpy().copy(), out_off[0].cpu().numpy().copy())
 
-    # ---- warmup
-    for i in range(W):
-        enqueue(i)
-    drain()
+    def run_steps(nsteps):
+        """Exactly `nsteps` steps; multi-rank: plus the overlapped gather of everything produced."""
+        if not multi:
+            for i in range(nsteps):
+                enqueue(i)
+            drain()
+            return
+        # Chunks of Q steps; the token records of chunk c travel to rank 0 (flat gatherv over
+        # xGMI) while chunk c+1 is being tokenized.  Every byte produced is gathered.
+        gather = ChunkedGather(dst=0)
+        ntok_of = {}
+
+        def post(lo, hi):
+            toks = torch.cat([out_tok[i % len(out_tok)][: ntok_of[i]] for i in range(lo, hi)])
+            cnts = torch.cat([out_off[i % len(out_tok)][1:] - out_off[i % len(out_tok)][:-1] for i in range(lo, hi)])
+            gather.post(toks, cnts)
+
+        for c0 in range(0, nsteps, Q):
+            for i in range(c0, min(c0 + Q, nsteps)):
+                if i >= Q:
+                    ntok_of[i - Q] = ctxs[i % Q].sync()  # step i-Q used this ctx: done before it is reused
+                enqueue(i)
+            if c0 >= Q:
+                for j in range(c0 - Q, c0):  # a short last chunk leaves some ctxs of the previous chunk unvisited
+                    if j not in ntok_of:
+                        ntok_of[j] = ctxs[j % Q].sync()
+                post(c0 - Q, c0)
+        last0 = ((nsteps - 1) // Q) * Q
+        for i in range(max(last0, 0), nsteps):
+            ntok_of[i] = ctxs[i % Q].sync()
+        post(last0, nsteps)
+        chunks = gather.finish()
+        if rank == 0:
+            assert sum(c[0].shape[0] for c in chunks) == sum(s[0] for c in chunks for s in c[2])
+
+    # ---- warmup (also brings up the RCCL channels of the gather)
+    if W > 0:
+        run_steps(W)
     for c in ctxs:
         c.set_profiling(PROFILE_EVENTS)
         c.profile(reset=True)
 
     # ---- timed region: exactly K steps
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    counts = []
-    for i in range(K):
-        enqueue(i)
-    ntoks = drain()
-    if world > 1:  # the one result gather: token records of all K steps to rank 0 over xGMI
-        per_step = []
-        for i in range(K):
-            o = i % len(out_tok)
-            n_i = int(out_off[o][-1].item())
-            per_step.append(out_tok[o][:n_i])
-            counts.append(out_off[o][1:] - out_off[o][:-1])
-        gathered = gather_tokens(torch.cat(per_step), torch.cat(counts), dst=0)
-        if rank == 0:
-            assert gathered[0].shape[0] == sum(s[0] for s in gathered[2])
+    run_steps(K)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -160,8 +192,7 @@ def main():
         c.set_profiling(PROFILE_OFF)
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     sentences = K * BATCH * world
@@ -243,8 +274,12 @@ def main():
             "gpu_batch0_bit_exact": exact,
         }
         result["speedup_vs_cpu_1thread"] = result["value"] / result["cpu_baseline"]["value"]
-    print(json.dumps(result))
-    if world > 1:
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(result), flush=True)
+    if multi:
+        os.dup2(2, 1)
+    if multi:
         dist.destroy_process_group()
 
 

@@ -81,6 +81,64 @@ def gather_tokens(tokens, counts, dst: int = 0, group=None):
     return None, None, sizes
 
 
+class ChunkedGather:
+    """The same flat gatherv, posted chunk by chunk so that it overlaps the tokenization of
+    the following chunk (the root's seven inbound xGMI links work while the CUs compute).
+
+    Every rank calls post() the same number of times in the same order; finish() waits for
+    all transfers and, on `dst`, returns the rank-major (tokens, counts, sizes) of each chunk.
+    """
+
+    def __init__(self, dst: int = 0, group=None):
+        self.dst, self.group = dst, group
+        self._inflight = []  # (works, result-or-None, keepalive)
+
+    def post(self, tokens, counts):
+        import torch
+        import torch.distributed as dist
+
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        meta = torch.tensor([tokens.shape[0], counts.shape[0]], dtype=torch.int64, device=tokens.device)
+        metas = [torch.zeros_like(meta) for _ in range(world)]
+        dist.all_gather(metas, meta, group=self.group)
+        sizes = [(int(m[0]), int(m[1])) for m in metas]
+        ops, result = [], None
+        tokens, counts = tokens.contiguous(), counts.contiguous()
+        if rank == self.dst:
+            tok_all = torch.empty((sum(s[0] for s in sizes), 6), dtype=tokens.dtype, device=tokens.device)
+            cnt_all = torch.empty(sum(s[1] for s in sizes), dtype=counts.dtype, device=counts.device)
+            t0 = c0 = 0
+            for r, (nt, nc) in enumerate(sizes):
+                tv, cv = tok_all[t0 : t0 + nt], cnt_all[c0 : c0 + nc]
+                if r == rank:
+                    tv.copy_(tokens)
+                    cv.copy_(counts)
+                else:
+                    if nt:
+                        ops.append(dist.P2POp(dist.irecv, tv, r, self.group))
+                    if nc:
+                        ops.append(dist.P2POp(dist.irecv, cv, r, self.group))
+                t0 += nt
+                c0 += nc
+            result = (tok_all, cnt_all, sizes)
+        else:
+            if tokens.shape[0]:
+                ops.append(dist.P2POp(dist.isend, tokens, self.dst, self.group))
+            if counts.shape[0]:
+                ops.append(dist.P2POp(dist.isend, counts, self.dst, self.group))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        self._inflight.append((works, result, (tokens, counts)))
+
+    def finish(self):
+        out = []
+        for works, result, _keep in self._inflight:
+            for w in works:
+                w.wait()
+            out.append(result)
+        self._inflight = []
+        return out
+
+
 def reassemble(tok_all: np.ndarray, cnt_all: np.ndarray, n: int, world: int):
     """Rank-major gathered stream -> original sentence order (host side).
     Returns (tokens [T,6], tok_offsets [n+1])."""

@@ -62,3 +62,47 @@ def test_unshard_order_is_a_permutation():
         perm = unshard_order(n, w)
         gathered = np.concatenate([shard_indices(n, r, w) for r in range(w)]) if n else np.zeros(0, dtype=np.int64)
         assert np.array_equal(gathered[perm], np.arange(n))
+
+
+def _worker_chunked(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from kanpyo_amd.dist import ChunkedGather
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = ChunkedGather(dst=0)
+    sent = []
+    for c in range(4):  # ragged chunks, one of them empty on rank 1
+        nt = 0 if (rank == 1 and c == 2) else 10 * (rank + 1) + c
+        tok = (torch.arange(nt * 6, dtype=torch.int32).reshape(nt, 6) + 1000 * rank + 100000 * c)
+        cnt = torch.full((3 + rank,), c, dtype=torch.int64)
+        sent.append((tok, cnt))
+        g.post(tok, cnt)
+    res = g.finish()
+    if rank == 0:
+        ok = len(res) == 4
+        for c, (tok_all, cnt_all, sizes) in enumerate(res):
+            t0 = 0
+            for r, (nt, nc) in enumerate(sizes):
+                exp_nt = 0 if (r == 1 and c == 2) else 10 * (r + 1) + c
+                exp = torch.arange(exp_nt * 6, dtype=torch.int32).reshape(exp_nt, 6) + 1000 * r + 100000 * c
+                ok = ok and nt == exp_nt and torch.equal(tok_all[t0 : t0 + nt], exp) and nc == 3 + r
+                t0 += nt
+            ok = ok and cnt_all.tolist() == sum(([c] * (3 + r) for r in range(world)), [])
+        open(os.path.join(tmpdir, "chunked"), "w").write("ok" if ok else "mismatch")
+    else:
+        assert all(r is None for r in res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chunked_overlapped_gather_gloo(tmp_path):
+    import torch.multiprocessing as mp
+
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_chunked, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert open(tmp_path / "chunked").read() == "ok"
