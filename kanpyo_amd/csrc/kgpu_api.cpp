@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -539,6 +540,36 @@ extern "C" int kgpu_ctx_get_profile(kgpu_ctx *c, kgpu_profile *out, int reset) {
 
 // ------------------------------------------------------- host-buffer entry point
 
+// One chunk of the host-buffer entry point: H2D, tier chain, D2H on the ctx stream.
+static int tokenize_host_chunk(kgpu_ctx *c, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
+                               kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets,
+                               uint8_t *status, uint64_t *n_tokens) {
+    const uint64_t base = offsets[0], total = offsets[n] - base;
+    std::vector<uint64_t> rel((size_t)n + 1);
+    for (uint64_t i = 0; i <= n; ++i) rel[(size_t)i] = offsets[i] - base;
+    int rc;
+    if ((rc = c->in_utf8.ensure((size_t)total + 16)) || (rc = c->in_off.ensure((size_t)(n + 1) * 8)) ||
+        (rc = c->out_tok.ensure((size_t)token_capacity * sizeof(kgpu_token) + 64)) ||
+        (rc = c->out_off.ensure((size_t)(n + 1) * 8)) || (rc = c->out_status.ensure((size_t)n + 16)))
+        return rc;
+    hipError_t e;
+    if (total && (e = hipMemcpyAsync(c->in_utf8.p, utf8 + base, (size_t)total, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { set_error("H2D utf8: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    if ((e = hipMemcpyAsync(c->in_off.p, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { set_error("H2D offsets: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    // `rel` must stay alive until the copy is done: the sync below covers it
+    if ((rc = kgpu_tokenize_device(c, (const uint8_t *)c->in_utf8.p, (const uint64_t *)c->in_off.p, n, total,
+                                   (kgpu_token *)c->out_tok.p, token_capacity, (uint64_t *)c->out_off.p,
+                                   (uint8_t *)c->out_status.p)))
+        return rc;
+    uint64_t got = 0;
+    rc = kgpu_ctx_sync(c, &got);
+    *n_tokens = got;
+    if (rc) return rc;
+    if (got && (e = hipMemcpy(tokens, c->out_tok.p, (size_t)got * sizeof(kgpu_token), hipMemcpyDeviceToHost)) != hipSuccess) { set_error("D2H tokens: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    if ((e = hipMemcpy(tok_offsets, c->out_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost)) != hipSuccess) { set_error("D2H offsets: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    if (status && n && (e = hipMemcpy(status, c->out_status.p, (size_t)n, hipMemcpyDeviceToHost)) != hipSuccess) { set_error("D2H status: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    return KGPU_OK;
+}
+
 extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
                                    kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets,
                                    uint8_t *status, uint64_t *n_tokens) {
@@ -548,8 +579,7 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
     }
     for (uint64_t i = 0; i < n; ++i)
         if (offsets[i + 1] < offsets[i]) { set_error("kgpu_tokenize_batch: offsets not monotone at %llu", (unsigned long long)i); return KGPU_ERR_INVALID_ARG; }
-    const uint64_t base = offsets[0], total = offsets[n] - base;
-    if (total && !utf8) { set_error("kgpu_tokenize_batch: null utf8"); return KGPU_ERR_INVALID_ARG; }
+    if (offsets[n] - offsets[0] && !utf8) { set_error("kgpu_tokenize_batch: null utf8"); return KGPU_ERR_INVALID_ARG; }
     HIPCHECK(hipSetDevice(d->device));
 
     kgpu_ctx *c = nullptr;
@@ -559,31 +589,36 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
     }
     int rc = KGPU_OK;
     if (!c && (rc = kgpu_ctx_create(d, nullptr, &c))) return rc;
-    auto give_back = [&]() { std::lock_guard<std::mutex> g(d->pool_mu); d->pool.push_back(c); };
 
-    std::vector<uint64_t> rel((size_t)n + 1);
-    for (uint64_t i = 0; i <= n; ++i) rel[(size_t)i] = offsets[i] - base;
-    uint64_t got = 0;
-    do {
-        if ((rc = c->in_utf8.ensure((size_t)total + 16)) || (rc = c->in_off.ensure((size_t)(n + 1) * 8)) ||
-            (rc = c->out_tok.ensure((size_t)token_capacity * sizeof(kgpu_token) + 64)) ||
-            (rc = c->out_off.ensure((size_t)(n + 1) * 8)) || (rc = c->out_status.ensure((size_t)n + 16)))
-            break;
-        hipError_t e;
-        if (total && (e = hipMemcpyAsync(c->in_utf8.p, utf8 + base, (size_t)total, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { set_error("H2D utf8: %s", hipGetErrorString(e)); rc = KGPU_ERR_HIP; break; }
-        if ((e = hipMemcpyAsync(c->in_off.p, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { set_error("H2D offsets: %s", hipGetErrorString(e)); rc = KGPU_ERR_HIP; break; }
-        // rel must stay alive until the copy is done: the sync below covers it
-        if ((rc = kgpu_tokenize_device(c, (const uint8_t *)c->in_utf8.p, (const uint64_t *)c->in_off.p, n, total,
-                                       (kgpu_token *)c->out_tok.p, token_capacity, (uint64_t *)c->out_off.p,
-                                       (uint8_t *)c->out_status.p)))
-            break;
-        rc = kgpu_ctx_sync(c, &got);
-        if (n_tokens) *n_tokens = got;
+    // Large inputs go through in chunks of at most HOST_CHUNK_BYTES / HOST_CHUNK_SENTS so that the
+    // device staging (24 B per input byte) stays bounded; tokens stay dense across chunks.
+    const uint64_t HOST_CHUNK_BYTES = getenv("KGPU_HOST_CHUNK_BYTES") ? strtoull(getenv("KGPU_HOST_CHUNK_BYTES"), nullptr, 10) : (64ull << 20);
+    const uint64_t HOST_CHUNK_SENTS = 1ull << 20;
+    uint64_t done = 0, tok_done = 0;
+    bool overflow = false;
+    tok_offsets[0] = 0;
+    while (done < n || (n == 0 && done == 0)) {
+        uint64_t m = 0;
+        while (done + m < n && m < HOST_CHUNK_SENTS && (m == 0 || offsets[done + m + 1] - offsets[done] <= HOST_CHUNK_BYTES)) ++m;
+        const uint64_t cap = token_capacity > tok_done ? token_capacity - tok_done : 0;
+        uint64_t got = 0;
+        rc = tokenize_host_chunk(c, utf8, offsets + done, m, tokens ? tokens + (overflow ? 0 : tok_done) : nullptr, overflow ? 0 : cap,
+                                 tok_offsets + done, status ? status + done : nullptr, &got);
+        if (rc == KGPU_ERR_CAPACITY) { overflow = true; rc = KGPU_OK; }
         if (rc) break;
-        if (got && (e = hipMemcpy(tokens, c->out_tok.p, (size_t)got * sizeof(kgpu_token), hipMemcpyDeviceToHost)) != hipSuccess) { set_error("D2H tokens: %s", hipGetErrorString(e)); rc = KGPU_ERR_HIP; break; }
-        if ((e = hipMemcpy(tok_offsets, c->out_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost)) != hipSuccess) { set_error("D2H offsets: %s", hipGetErrorString(e)); rc = KGPU_ERR_HIP; break; }
-        if (status && n && (e = hipMemcpy(status, c->out_status.p, (size_t)n, hipMemcpyDeviceToHost)) != hipSuccess) { set_error("D2H status: %s", hipGetErrorString(e)); rc = KGPU_ERR_HIP; break; }
-    } while (0);
-    give_back();
+        if (!overflow) for (uint64_t i = 0; i <= m; ++i) tok_offsets[done + i] += tok_done;  // chunk-local -> global
+        tok_done += got;
+        done += m;
+        if (n == 0) break;
+    }
+    {
+        std::lock_guard<std::mutex> g(d->pool_mu);
+        d->pool.push_back(c);
+    }
+    if (n_tokens) *n_tokens = tok_done;
+    if (!rc && overflow) {
+        set_error("token buffer too small: need %llu, capacity %llu", (unsigned long long)tok_done, (unsigned long long)token_capacity);
+        return KGPU_ERR_CAPACITY;
+    }
     return rc;
 }

@@ -305,3 +305,46 @@ def test_built_and_reloaded_dictionary(libs, tmp_path):
     assert_same(tok, orc, sents, nthreads=1)
     lines = format_tokens(tok.tokenize("東京都に住む"), back)
     assert lines.splitlines()[-1] == "EOS\t" and "トウキョウト" in lines
+
+
+def test_host_entry_point_chunks_and_capacity(small, monkeypatch):
+    """kgpu_tokenize_batch splits large inputs into bounded chunks; tokens stay dense; a too-small
+    buffer reports the exact requirement (KGPU_ERR_CAPACITY)."""
+    from kanpyo_amd import _lib, synth
+    from kanpyo_amd.tokenizer import pack_sentences
+
+    sd, tok, orc = small
+    sents = synth.make_corpus(sd, 700, 21, "cfg2") + ["", "あ"] + synth.make_corpus(sd, 40, 22, "cfg3")
+    utf8, offs = pack_sentences(sents)
+    exp = orc.tokenize_batch(utf8, offs, 4)
+    monkeypatch.setenv("KGPU_HOST_CHUNK_BYTES", "3000")  # ~25 sentences per chunk
+    t, toff, st = tok.tokenize_packed(utf8, offs)
+    assert np.array_equal(toff, exp.offsets) and np.array_equal(t, exp.tokens) and not st.any()
+    with pytest.raises(_lib.KgpuError) as e:
+        tok.tokenize_packed(utf8, offs, token_capacity=len(exp.tokens) - 1)
+    assert e.value.code == _lib.KGPU_ERR_CAPACITY and str(len(exp.tokens)) in str(e.value)
+    t2, toff2, _ = tok.tokenize_packed(utf8, offs, token_capacity=len(exp.tokens))
+    assert np.array_equal(t2, exp.tokens)
+
+
+def test_concurrent_callers_share_one_dictionary(small):
+    """Tokenizer::tokenize takes &self: concurrent calls on one dictionary are legal (src/tokenizer.rs:16)."""
+    import threading
+
+    from kanpyo_amd import synth
+    from kanpyo_amd.tokenizer import pack_sentences
+
+    sd, tok, orc = small
+    jobs = [pack_sentences(synth.make_corpus(sd, 400 + 50 * k, 30 + k, "cfg2")) for k in range(6)]
+    want = [orc.tokenize_batch(u, o, 2) for u, o in jobs]
+    got = [None] * len(jobs)
+
+    def run(k):
+        for _ in range(3):
+            got[k] = tok.tokenize_packed(*jobs[k])
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(len(jobs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(len(jobs)):
+        assert np.array_equal(got[k][1], want[k].offsets) and np.array_equal(got[k][0], want[k].tokens)
