@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--queue", type=int, default=8, help="batches in flight (one ctx/stream each)")
+    ap.add_argument("--queue", type=int, default=3, help="batches in flight (one ctx/stream each; HIP multiplexes streams onto 3 hardware queues, more only serialise behind each other)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="lower bound of CPU-baseline work")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (self-test)")
@@ -77,7 +77,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from kanpyo_amd import Tokenizer, synth
-    from kanpyo_amd.device import PROFILE_EVENTS, PROFILE_OFF, PROFILE_WORK, DeviceContext
+    from kanpyo_amd.device import PROFILE_EVENTS, PROFILE_OFF, PROFILE_SAMPLED, PROFILE_WORK, DeviceContext
     from kanpyo_amd.dist import ChunkedGather
     from kanpyo_amd.tokenizer import pack_sentences
 
@@ -166,7 +166,8 @@ def main():
     if W > 0:
         run_steps(W)
     for c in ctxs:
-        c.set_profiling(PROFILE_EVENTS)
+        if not os.environ.get("BENCH_NO_EVENTS"):
+            c.set_profiling(PROFILE_EVENTS | PROFILE_SAMPLED)  # HIP events around every 4th launch
         c.profile(reset=True)
 
     # ---- timed region: exactly K steps

@@ -114,6 +114,7 @@ typedef struct kgpu_work {
 #define KGPU_PROFILE_OFF 0
 #define KGPU_PROFILE_EVENTS 1 /* HIP events around the kernels            */
 #define KGPU_PROFILE_WORK 2   /* device-side work counters (kgpu_work)    */
+#define KGPU_PROFILE_SAMPLED 4 /* with EVENTS: time every 4th launch only  */
 
 const char *kgpu_last_error(void);
 int kgpu_device_count(void);

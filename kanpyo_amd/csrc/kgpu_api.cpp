@@ -9,6 +9,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -78,6 +79,15 @@ struct kgpu_dict {
     std::vector<void *> allocs;
     std::mutex pool_mu;
     std::vector<kgpu_ctx *> pool;
+    // LDS bytes reserved per input byte (x256) by the pool kernel before the lattice is known; a
+    // property of the dictionary + the text, so it is learnt once and shared by all contexts
+    std::atomic<uint32_t> est_q8{80 * 256};
+    // Batches left for which the second (whole-CU) pool is launched.  Its workgroups need a CU's
+    // entire LDS just to start and find their list empty, which stalls them -- and the launches
+    // queued behind -- until both 80 KB pools of that CU have drained; so it is only issued while
+    // recent batches actually overflowed the first pool (otherwise those rare sentences take the
+    // HBM-scratch kernel).  Performance heuristic only: the chain is complete either way.
+    std::atomic<int> big_pool_batches{0};
 };
 
 struct kgpu_ctx {
@@ -85,7 +95,12 @@ struct kgpu_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     Control *d_ctl = nullptr;
-    Control *h_ctl = nullptr;  // pinned
+    Control *h_ctl = nullptr;  // pinned + device-mapped: the scan kernel publishes the launch's Control block here
+    Control *h_ctl_dev = nullptr;  // device-side address of h_ctl
+    bool ctl_dirty = true;     // d_ctl must be zeroed by the host (first launch, or after a failed enqueue)
+    uint32_t launch_seq = 0;
+    int last_pools = 0;        // pool launches issued for the pending batch
+    uint32_t event_every = 1;  // KGPU_PROFILE_SAMPLED: HIP events on every 4th launch only
     DevBuf arena, stage, tok_count;
     // host-buffer path staging
     DevBuf in_utf8, in_off, out_tok, out_off, out_status;
@@ -93,7 +108,6 @@ struct kgpu_ctx {
     BatchArgs last{};
     bool pending = false;
     TierPlan plan{};
-    uint32_t est_q8 = 64 * 256;  // LDS bytes per input byte, adapted after every batch
     DevBuf ovf;
     // profiling
     bool profiling = false;   // KGPU_PROFILE_EVENTS
@@ -371,7 +385,8 @@ extern "C" int kgpu_ctx_create(kgpu_dict *d, void *hip_stream, kgpu_ctx **out) {
         c->own_stream = true;
     }
     if (hipMalloc((void **)&c->d_ctl, sizeof(Control)) != hipSuccess ||
-        hipHostMalloc((void **)&c->h_ctl, sizeof(Control), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void **)&c->h_ctl, sizeof(Control), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->h_ctl_dev, c->h_ctl, 0) != hipSuccess) {
         set_error("kgpu_ctx_create: control block allocation failed");
         kgpu_ctx_destroy(c);
         return KGPU_ERR_HIP;
@@ -405,24 +420,29 @@ static int next_event(kgpu_ctx *c, hipEvent_t *ev) {
 }
 
 static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
-    HIPCHECK(hipMemsetAsync(c->d_ctl, 0, sizeof(Control), c->stream));
+    // The Control block is zero here: the previous launch's scan kernel left it so.
+    if (c->ctl_dirty) HIPCHECK(hipMemsetAsync(c->d_ctl, 0, sizeof(Control), c->stream));
+    c->ctl_dirty = true;  // until this enqueue is through
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     int rc;
-    if (c->profiling) {
+    const bool timed = c->profiling && (c->launch_seq++ % c->event_every) == 0;
+    if (timed) {
         if ((rc = next_event(c, &e0)) || (rc = next_event(c, &e1)) || (rc = next_event(c, &e2))) return rc;
         HIPCHECK(hipEventRecord(e0, c->stream));
     }
     if (a.n) {
-        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, c->stream);
+        const int pools_now = c->dict->big_pool_batches.load(std::memory_order_relaxed) > 0 ? c->plan.n_pools : std::min(c->plan.n_pools, 1);
+        c->last_pools = pools_now;
+        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->stream);
         if (e != hipSuccess) { set_error("k_tokenize launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     }
-    if (c->profiling) HIPCHECK(hipEventRecord(e1, c->stream));
+    if (timed) HIPCHECK(hipEventRecord(e1, c->stream));
     {
-        hipError_t e = (hipError_t)launch_scan_compact(a, c->stream);
+        hipError_t e = (hipError_t)launch_scan_compact(a, c->h_ctl_dev, c->stream);
         if (e != hipSuccess) { set_error("scan/compact launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     }
-    if (c->profiling) HIPCHECK(hipEventRecord(e2, c->stream));
-    HIPCHECK(hipMemcpyAsync(c->h_ctl, c->d_ctl, sizeof(Control), hipMemcpyDeviceToHost, c->stream));
+    if (timed) HIPCHECK(hipEventRecord(e2, c->stream));
+    c->ctl_dirty = false;
     c->last = a;
     c->pending = true;
     return KGPU_OK;
@@ -452,7 +472,7 @@ extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const ui
     a.tok_count = (uint32_t *)c->tok_count.p;
     a.status = d_status; a.out = d_tokens; a.out_cap = token_capacity; a.tok_offsets = d_tok_offsets;
     a.count_work = c->count_work ? 1u : 0u;
-    a.est_q8 = c->est_q8;
+    a.est_q8 = c->dict->est_q8.load(std::memory_order_relaxed);
     for (int k = 0; k < 4; ++k) a.ovf[k] = (uint32_t *)c->ovf.p + (size_t)k * (n + 1);
     return enqueue(c, a);
 }
@@ -477,14 +497,23 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
         break;
     }
     c->pending = false;
-    if (c->last.n && (c->plan.n_lds_tiers > 1 || c->plan.pack_lds_bytes)) {
-        // adapt the early-routing estimate: late deferrals (walk paid twice) push it up,
-        // early deferrals with no late ones let it drift back down
-        const unsigned late = c->h_ctl->late_count[0], all = c->h_ctl->ovf_count[0];
-        if ((uint64_t)late * 50 > c->last.n) c->est_q8 += c->est_q8 / 8;
-        else if (late == 0 && all > 0) c->est_q8 -= c->est_q8 / 64;
-        if (c->est_q8 < 16 * 256) c->est_q8 = 16 * 256;
-        if (c->est_q8 > 1024 * 256) c->est_q8 = 1024 * 256;
+    if (c->last.n && (c->plan.n_pools || c->plan.n_lds_tiers > 1 || c->plan.pack_lds_bytes)) {
+        // The pool kernel reserves est LDS bytes per input byte up front: a reservation that proves
+        // too small costs a redo (late_count), one that is too large only idles pages until the
+        // lattice is known -- steer for a redo rate of 1-3 %.  (The fixed tiers use the same
+        // estimate for early routing.)  Applied to the value the batch ran with; races between
+        // contexts only lose an adjustment.
+        if (c->plan.n_pools > 1) {
+            if (c->h_ctl->ovf_count[0] > 0) c->dict->big_pool_batches.store(64, std::memory_order_relaxed);
+            else if (c->last_pools > 1) c->dict->big_pool_batches.fetch_sub(1, std::memory_order_relaxed);
+        }
+        const unsigned late = c->h_ctl->late_count[0];
+        uint32_t est = c->last.est_q8;
+        if ((uint64_t)late * 4 > c->last.n) est += est / 4;
+        else if ((uint64_t)late * 32 > c->last.n) est += est / 16;
+        else if ((uint64_t)late * 100 < c->last.n) est -= est / 128;
+        est = std::min<uint32_t>(std::max<uint32_t>(est, 16 * 256), 1024 * 256);
+        if (est != c->last.est_q8) c->dict->est_q8.store(est, std::memory_order_relaxed);
     }
     if (c->profiling) {
         for (size_t i = 0; i + 3 <= c->ev_used; i += 3) {
@@ -514,6 +543,8 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
 extern "C" int kgpu_ctx_set_profiling(kgpu_ctx *c, int mode) {
     if (!c) { set_error("kgpu_ctx_set_profiling: null ctx"); return KGPU_ERR_INVALID_ARG; }
     c->profiling = (mode & KGPU_PROFILE_EVENTS) != 0;
+    c->event_every = (mode & KGPU_PROFILE_SAMPLED) ? 4u : 1u;
+    c->launch_seq = 0;
     c->count_work = (mode & KGPU_PROFILE_WORK) != 0;
     return KGPU_OK;
 }

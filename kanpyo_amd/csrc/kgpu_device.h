@@ -109,6 +109,14 @@ __device__ __forceinline__ bool tier_next(const TierIO &io, const BatchArgs &a, 
     s = (uint64_t)bcast32(io.in_list[i]);
     return true;
 }
+// Same, for kernels whose workers are wavefronts of larger workgroups: the caller supplies the work index.
+__device__ __forceinline__ bool tier_next_at(const TierIO &io, const BatchArgs &a, uint64_t i, uint64_t &s) {
+    if (!io.in_list) { s = i; return i < a.n; }
+    const uint64_t n = (uint64_t)bcast32(__hip_atomic_load(io.in_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (i >= n) return false;
+    s = (uint64_t)bcast32(io.in_list[i]);
+    return true;
+}
 __device__ __forceinline__ void tier_defer(const TierIO &io, uint32_t lane, uint64_t s) {
     if (lane == 0) {
         unsigned int k = atomicAdd(io.out_count, 1u);

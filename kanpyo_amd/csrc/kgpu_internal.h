@@ -81,11 +81,19 @@ struct TierPlan {
     uint32_t lds_bytes[3];
     int workgroups[3];       // persistent grid per LDS tier
     int general_workgroups;
+    // LDS page-pool launches (kgpu_pool.hip), run before the fixed tiers: W independent
+    // wavefronts per workgroup share pool_bytes of LDS, each sentence takes what it needs
+    int n_pools;
+    uint32_t pool_bytes[2];
+    uint32_t pool_waves[2];
+    int pool_workgroups[2];
 };
 
 // Launchers (kgpu_kernels.hip).  `stream` is a hipStream_t.
-int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan, void *stream);
-int launch_scan_compact(const BatchArgs &a, void *stream);
+// n_pools_now <= plan.n_pools: how many of the pool launches to issue for this batch (the chain
+// stays complete without the later ones: their work falls through to the next launch).
+int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan, int n_pools_now, void *stream);
+int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream);  // host_ctl: device pointer of the pinned result block
 TierPlan default_tier_plan(int device);
 
 }  // namespace kgpu

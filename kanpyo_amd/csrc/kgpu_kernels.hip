@@ -275,7 +275,10 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
 
 // Exclusive scan of per-sentence token counts -> tok_offsets (single workgroup;
 // n is at most a few million per batch).
-__global__ __launch_bounds__(1024) void k_scan_counts(BatchArgs a) {
+// It is also the last reader of the launch's Control block: it publishes the block to the
+// pinned host copy (no D2H copy node) and zeroes the device copy for the next launch (no memset
+// node) -- two operations fewer per batch on a host-launch-bound stream.
+__global__ __launch_bounds__(1024) void k_scan_counts(BatchArgs a, Control *host_ctl) {
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -295,9 +298,16 @@ __global__ __launch_bounds__(1024) void k_scan_counts(BatchArgs a) {
         if (tid == 1023) carry_s = carry + woff + vs;
         __syncthreads();
     }
-    if (tid == 0) {
-        a.tok_offsets[a.n] = carry_s;
-        a.ctl->n_tokens = carry_s;
+    if (tid == 0) a.tok_offsets[a.n] = carry_s;
+    static_assert(sizeof(Control) % 4 == 0 && sizeof(Control) / 4 <= 1024, "Control is copied one dword per thread");
+    if (tid < sizeof(Control) / 4) {
+        uint32_t *dc = (uint32_t *)a.ctl, *hc = (uint32_t *)host_ctl;
+        uint32_t v = dc[tid];
+        const uint32_t nt = (uint32_t)(offsetof(Control, n_tokens) / 4);
+        if (tid == nt) v = (uint32_t)carry_s;
+        if (tid == nt + 1) v = (uint32_t)(carry_s >> 32);
+        __hip_atomic_store(&hc[tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        dc[tid] = 0;
     }
 }
 
@@ -320,13 +330,17 @@ __global__ __launch_bounds__(256) void k_compact(BatchArgs a) {
 int launch_tokenize_lds(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t lds_bytes, int n_workgroups,
                         void *stream);  // kgpu_lds.hip
 
+int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t pool_bytes, uint32_t waves,
+                         int n_workgroups, void *stream);  // kgpu_pool.hip
+int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
+
 int launch_tokenize_pack(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t lds_bytes, uint32_t gpack,
                          int n_workgroups, void *stream);  // kgpu_pack.hip
 
 // Tier chain: the packed kernel (several short sentences per wavefront), then the
 // per-sentence LDS tiers in ascending LDS size, then the general (HBM scratch)
 // kernel.  Every launch is a persistent grid over its tier's work list.
-int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan, void *stream) {
+int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan, int n_pools_now, void *stream) {
     Control *ctl = a.ctl;
     const uint32_t *in_list = nullptr;
     const unsigned int *in_count = nullptr;
@@ -341,7 +355,17 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan,
         in_count = &ctl->ovf_count[li];
         ++li;
     }
-    for (int k = 0; k < plan.n_lds_tiers; ++k, ++li) {
+    for (int k = 0; k < plan.n_pools && k < n_pools_now; ++k, ++li) {
+        TierIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], &ctl->late_count[li]};
+        uint64_t wg = plan.pool_workgroups[k];
+        const uint64_t want = (a.n + plan.pool_waves[k] - 1) / plan.pool_waves[k];
+        if (!in_list && want < wg) wg = want;
+        int e = launch_tokenize_pool(d, a, io, plan.pool_bytes[k], plan.pool_waves[k], (int)(wg ? wg : 1), stream);
+        if (e) return e;
+        in_list = a.ovf[li];
+        in_count = &ctl->ovf_count[li];
+    }
+    for (int k = 0; k < plan.n_lds_tiers && li < 4; ++k, ++li) {
         TierIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], &ctl->late_count[li]};
         uint64_t wg = plan.workgroups[k];
         if (!in_list && a.n < wg) wg = a.n;
@@ -358,9 +382,9 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan,
     return (int)hipGetLastError();
 }
 
-int launch_scan_compact(const BatchArgs &a, void *stream) {
-    if (getenv("KGPU_DEBUG_SKIP_AUX")) return 0;
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream) {
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, host_ctl);
+    if (getenv("KGPU_DEBUG_SKIP_AUX")) return (int)hipGetLastError();
     uint64_t blocks = (a.n + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
@@ -377,9 +401,9 @@ TierPlan default_tier_plan(int device) {
     // by 2-3x but not the L1-miss traffic that bounds throughput, and it runs 4x fewer waves
     // (measured 25 M vs 30 M sentences/s on cfg 2).  KGPU_PACK=40,4 turns it on.
     t.pack_lds_bytes = 0; t.pack_size = 4; t.pack_workgroups = cus * 4;
-    t.n_lds_tiers = 2;
-    t.lds_bytes[0] = 14 * 1024;   t.workgroups[0] = cus * 11;  // one sentence per wavefront, 11 per CU (best of 12..20 KB on cfg 2)
-    t.lds_bytes[1] = 160 * 1024;  t.workgroups[1] = cus;       // one long sentence owns a CU's whole LDS
+    // Fixed-LDS tiers (kgpu_lds.hip) are off by default -- the page-pool kernel below adapts the
+    // LDS per sentence instead; KGPU_TIERS="14:10,160" brings them back (after the pools).
+    t.n_lds_tiers = 0;
     if (const char *e = getenv("KGPU_PACK")) {  // "<KiB>,<sentences per pack>" or "0"
         int kib = atoi(e), g = 4;
         if (const char *c = strchr(e, ',')) g = atoi(c + 1);
@@ -391,12 +415,43 @@ TierPlan default_tier_plan(int device) {
     if (const char *e = getenv("KGPU_TIERS")) {  // e.g. "20,64,160" (KiB) or "0" for the general kernel only
         t.n_lds_tiers = 0;
         const char *q = e;
-        while (*q && t.n_lds_tiers < 2) {
+        while (*q && t.n_lds_tiers < 3) {
             int kib = atoi(q);
             if (kib > 0 && kib <= 160) {
                 t.lds_bytes[t.n_lds_tiers] = (uint32_t)kib * 1024;
-                t.workgroups[t.n_lds_tiers] = cus * (160 / kib);
+                int per_cu = 160 / kib;
+                const char *c = q;
+                while (*c && *c != ',' && *c != ':') ++c;
+                if (*c == ':' && atoi(c + 1) > 0) per_cu = atoi(c + 1);  // "<KiB>:<workgroups per CU>"
+                t.workgroups[t.n_lds_tiers] = cus * per_cu;
                 ++t.n_lds_tiers;
+            }
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
+    // LDS page pools: "<KiB>:<wavefronts per workgroup>[,<KiB>:<wavefronts>]", "0" = none
+    // Default: two 80 KB pools per CU with 8 wavefronts each (16 sentences in flight per CU, any
+    // mix of sizes up to 80 KB; smaller workgroups drain sooner at the tail of a 4096-sentence
+    // batch than one 160 KB / 16-wavefront workgroup), then one 160 KB pool per CU for the
+    // sentences that need more than 80 KB.  Beyond that: the HBM-scratch kernel.
+    t.n_pools = 0;
+    {
+        const char *e = getenv("KGPU_POOL");
+        const char *q = e ? e : "80:8,160:4";
+        while (*q && t.n_pools < 2) {
+            int kib = atoi(q), w = 8;
+            const char *c = q;
+            while (*c && *c != ',' && *c != ':') ++c;
+            if (*c == ':' && atoi(c + 1) > 0) w = atoi(c + 1);
+            if (w > 16) w = 16;
+            if (kib >= 8 && kib <= 160) {
+                const int per_cu = pool_workgroups_per_cu((uint32_t)kib * 1024, (uint32_t)w);
+                if (per_cu > 0) {
+                    t.pool_bytes[t.n_pools] = (uint32_t)kib * 1024; t.pool_waves[t.n_pools] = (uint32_t)w;
+                    t.pool_workgroups[t.n_pools] = cus * per_cu;
+                    ++t.n_pools;
+                }
             }
             while (*q && *q != ',') ++q;
             if (*q == ',') ++q;

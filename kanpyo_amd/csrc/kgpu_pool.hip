@@ -1,0 +1,615 @@
+// kanpyo_amd/csrc/kgpu_pool.hip -- LDS-resident fused tokenize kernel with a per-workgroup
+// LDS page pool (gfx950).
+//
+// Same per-sentence algorithm as kgpu_lds.hip (one 64-lane wavefront owns one sentence from
+// bytes to tokens; the whole lattice lives in LDS), but the LDS a sentence gets is no longer
+// the launch's fixed dynamic-LDS size.  A workgroup is W independent wavefronts sharing one
+// pool of 64 pages (a u64 bitmap, first-fit runs of contiguous pages, LDS atomics); every
+// wavefront reserves what its sentence is expected to need, gives back what it does not use
+// after the lattice is known, and releases the rest when the tokens are out.  Occupancy
+// therefore follows the sentences (short ones pack ~18 per CU, a long one may take a whole
+// pool) instead of the worst case of a tier, and no sentence that fits a pool is handed to a
+// later launch -- the chain of dependent tier launches (each as long as its slowest sentence)
+// is gone.
+//
+// Waiting rule (deadlock freedom): a wavefront waits for pages only while it holds none.  If
+// its reservation turns out too small it releases it, waits for the exact size (now known)
+// and redoes the sentence; a sentence that cannot fit an empty pool goes to the next launch's
+// work list.  The wavefronts of a workgroup never meet at a barrier after the pool is set up.
+#include <cstdlib>
+#include <type_traits>
+
+#include "kgpu_device.h"
+
+namespace kgpu {
+
+using namespace dev;
+
+namespace {
+
+constexpr uint32_t MAXM = 8;         // trie matches buffered per start position
+constexpr uint32_t NONE16 = 0xFFFFu;
+
+// ---- DPP butterfly: min over aligned groups of 2^lg lanes, every lane gets it.
+// The key is one u64 (total ^ signbit) << 32 | predecessor node index, so one
+// v_cmp_lt_u64 + two v_cndmask per step, no branches.
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_min_step(uint64_t k) {
+    const uint32_t oh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), CTRL, 0xF, 0xF, false);
+    const uint32_t ol = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, CTRL, 0xF, 0xF, false);
+    const uint64_t o = ((uint64_t)oh << 32) | ol;
+    return o < k ? o : k;
+}
+__device__ __forceinline__ uint64_t shfl_min_step(uint64_t k, int d) {
+    const uint32_t oh = (uint32_t)__shfl_xor((int)(uint32_t)(k >> 32), d, 64);
+    const uint32_t ol = (uint32_t)__shfl_xor((int)(uint32_t)k, d, 64);
+    const uint64_t o = ((uint64_t)oh << 32) | ol;
+    return o < k ? o : k;
+}
+__device__ __forceinline__ uint64_t group_min(uint64_t k, uint32_t lg) {  // lg wave-uniform
+    if (lg >= 1) k = dpp_min_step<0xB1>(k);   // quad_perm [1,0,3,2]
+    if (lg >= 2) k = dpp_min_step<0x4E>(k);   // quad_perm [2,3,0,1]
+    if (lg >= 3) k = dpp_min_step<0x141>(k);  // row_half_mirror
+    if (lg >= 4) k = dpp_min_step<0x140>(k);  // row_mirror
+    if (lg >= 5) k = shfl_min_step(k, 16);
+    if (lg >= 6) k = shfl_min_step(k, 32);
+    return k;
+}
+
+__device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }
+
+// Wavefront-level ordering point.  LDS executes one wavefront's instructions in issue order, so
+// data written by one lane is visible to the others at the next instruction; this only stops the
+// compiler from moving LDS accesses across it (no s_barrier: the workgroup's wavefronts are
+// independent, and no vmcnt wait: global loads in flight stay in flight).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- LDS page pool: 64 pages, bit i of *bm set = page i taken ---------------------------------
+constexpr uint32_t POOL_HDR = 16;
+constexpr uint32_t POOL_PAGES = 64;
+__device__ __forceinline__ uint64_t run_mask(uint32_t k, uint32_t pos) { return (k >= 64 ? ~0ull : ((1ull << k) - 1)) << pos; }
+
+// One attempt to take k contiguous pages (first fit).  Wave-uniform result: page index or NONE.
+__device__ __forceinline__ uint32_t pool_try_alloc(uint64_t *bm, uint32_t k, uint32_t lane) {
+    for (int tries = 0; tries < 4; ++tries) {
+        const uint64_t cur = bcast64(__hip_atomic_load(bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        uint64_t r = ~cur;  // bit i: pages i .. i+m-1 free
+        for (uint32_t m = 1; m < k;) { const uint32_t t = min(m, k - m); r &= r >> t; m += t; }
+        if (r == 0) return NONE;
+        const uint32_t pos = (uint32_t)__ffsll((unsigned long long)r) - 1;
+        bool won = false;
+        if (lane == 0) won = atomicCAS((unsigned long long *)bm, (unsigned long long)cur, (unsigned long long)(cur | run_mask(k, pos))) == cur;
+        if (__ballot(won) != 0) return pos;
+    }
+    return NONE;
+}
+__device__ __forceinline__ void pool_free(uint64_t *bm, uint32_t pos, uint32_t from, uint32_t to, uint32_t lane) {  // pages [pos+from, pos+to)
+    wave_sync();
+    if (lane == 0 && to > from) atomicAnd((unsigned long long *)bm, ~(unsigned long long)run_mask(to - from, pos + from));
+}
+// Wait (holding nothing) until k pages are free.  Bounded: gives up with NONE after ~0.5 s.
+__device__ __forceinline__ uint32_t pool_wait_alloc(uint64_t *bm, uint32_t k, uint32_t lane) {
+    for (uint32_t spin = 0; spin < (1u << 20); ++spin) {
+        const uint32_t pg = pool_try_alloc(bm, k, lane);
+        if (pg != NONE) return pg;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    return NONE;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a, TierIO io, uint32_t pool_bytes,
+                                                        uint32_t stop_after /* ablation timing only; 0 = run everything */) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t pool[];
+    const uint32_t lane = threadIdx.x & 63u, wave = bcast32(threadIdx.x >> 6) /* SGPR: everything per-sentence is wave-uniform */, W = blockDim.x >> 6;
+    const int32_t base_root = d.da[1].base;
+    uint64_t *bm = (uint64_t *)pool;
+    const uint32_t page = ((pool_bytes - POOL_HDR) / POOL_PAGES) & ~15u;
+    if (threadIdx.x == 0) *bm = 0;
+    __syncthreads();  // the only workgroup barrier: from here on the wavefronts are independent
+    // profiling accumulators of this workgroup (flushed once at exit: per-sentence
+    // atomics on a handful of hot words distort what they measure)
+    uint64_t accW[7] = {0, 0, 0, 0, 0, 0, 0}, accP[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (uint32_t iter = 0;; ++iter) {
+        uint64_t s = 0;
+        // sentence i of the work list -> workgroup i mod G, wavefront (i / G) mod W
+        if (!tier_next_at(io, a, (uint64_t)blockIdx.x + (uint64_t)gridDim.x * (wave + (uint64_t)W * iter), s)) break;
+        const uint64_t b0 = a.offsets[s];
+        const uint64_t Bl = a.offsets[s + 1] - b0;
+        const uint32_t pool_cap = page * POOL_PAGES;
+        if (Bl + 64 > pool_cap || Bl > 0xFFF0) { tier_defer(io, lane, s); continue; }
+        const uint32_t B = (uint32_t)Bl;
+        const uint8_t *gtext = a.utf8 + b0;
+        // chars of the sentence (sizes the per-position arrays); the bytes are re-read from L1 below
+        uint32_t C = 0;
+        for (uint32_t k0 = 0; k0 < B; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const uint32_t b = k < B ? gtext[k] : 0x80u;
+            C += __popcll(__ballot(k < B && (b & 0xC0) != 0x80));
+        }
+        // reservation: what the per-position arrays + match buffer need for sure, or the host-adapted
+        // estimate of the whole lattice, whichever is larger.  A sentence expected not to fit an empty
+        // pool is routed on without paying for a trie walk that would be thrown away.
+        const uint32_t need1 = align_up(B + 4, 4) + 24 * (C + 2) + 2 * align_up(C + 2, 4) + align_up(C * MAXM * 5, 16) + 32;
+        const uint32_t est = max(need1, (uint32_t)(((uint64_t)B * a.est_q8) >> 8) + 768);
+        uint32_t npg = (est + page - 1) / page;
+        if (npg > POOL_PAGES) { tier_defer(io, lane, s); continue; }
+        uint32_t pg = pool_wait_alloc(bm, npg, lane);
+        if (pg == NONE) { tier_defer(io, lane, s); continue; }
+        for (uint32_t attempt = 0;; ++attempt) {  // at most one redo, with the exact size
+        uint8_t *smem = pool + POOL_HDR + pg * page;
+        const uint32_t lds_bytes = npg * page;
+
+        uint64_t tick[9];
+        const bool prof = a.count_work != 0;
+#define KGPU_TICK(k) do { if (prof) tick[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define KGPU_STOP(k) if (stop_after == (k)) { if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = 0; } break; }
+        KGPU_TICK(0);
+        // ---- phase 0a: stage the sentence in LDS, count chars -----------------
+        uint8_t *text = smem;
+        for (uint32_t k0 = 0; k0 < B + 4; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const uint32_t b = k < B ? gtext[k] : 0x80u;
+            if (k < B + 4) text[k] = (uint8_t)b;
+        }
+        // ---- LDS carve: per-char arrays from the bottom, match buffer from the top
+        uint32_t off = align_up(B + 4, 4);
+        uint32_t *nb = (uint32_t *)(smem + off);    off += 4 * (C + 2);  // node count -> first node index
+        uint32_t *boff = (uint32_t *)(smem + off);  off += 4 * (C + 2);  // bucket count -> offset (edges[e])
+        uint32_t *bfill = (uint32_t *)(smem + off); off += 4 * (C + 2);  // bucket fill cursor
+        uint32_t *ebase = (uint32_t *)(smem + off); off += 4 * (C + 2);  // first pair index per position
+        uint16_t *cbyte = (uint16_t *)(smem + off); off += 2 * (C + 2);  // char -> byte offset
+        uint16_t *uspan = (uint16_t *)(smem + off); off += 2 * (C + 2);  // unknown span (0 = none)
+        uint16_t *path = (uint16_t *)(smem + off);  off += 2 * (C + 2);  // backtrace
+        uint16_t *cp16 = (uint16_t *)(smem + off);  off += 2 * (C + 2);  // BMP code point (0xFFFF: not BMP)
+        uint8_t *ccat = smem + off;                 off += align_up(C + 2, 4);
+        uint8_t *mcnt = smem + off;                 off += align_up(C + 2, 4);
+        const uint32_t mbytes = align_up(C * MAXM * 5, 16);
+        // off + mbytes <= need1 <= lds_bytes by construction of the reservation
+        const uint32_t moff = (lds_bytes - mbytes) & ~15u;
+        uint32_t *mid = (uint32_t *)(smem + moff);           // [C][MAXM] trie ids
+        uint8_t *mnch = smem + moff + 4 * C * MAXM;          // [C][MAXM] match length in chars
+        wave_sync();
+        KGPU_TICK(1);
+        KGPU_STOP(1)
+
+        // ---- phase 0b: decode + validate + category --------------------------------
+        uint32_t cb = 0, bad = 0, lensum = 0;
+        for (uint32_t k0 = 0; k0 < B; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const uint32_t b = k < B ? text[k] : 0x80u;
+            const bool start = k < B && (b & 0xC0) != 0x80;
+            const uint64_t m = __ballot(start);
+            const uint32_t ci = cb + __popcll(m & ((1ull << lane) - 1));
+            if (start) {
+                uint32_t l, cp;
+                if (b < 0x80) { l = 1; cp = b; }
+                else if (b >= 0xC2 && b <= 0xDF) { l = 2; cp = b & 0x1F; }
+                else if ((b & 0xF0) == 0xE0) { l = 3; cp = b & 0x0F; }
+                else if (b >= 0xF0 && b <= 0xF4) { l = 4; cp = b & 0x07; }
+                else { l = 1; cp = 0; bad = 1; }
+                if (k + l > B) { bad = 1; l = 1; }
+                for (uint32_t j = 1; j < l; ++j) {
+                    const uint32_t bb = text[k + j];
+                    if ((bb & 0xC0) != 0x80) bad = 1;
+                    cp = (cp << 6) | (bb & 0x3F);
+                }
+                if (l == 3 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) bad = 1;
+                if (l == 4 && (cp < 0x10000 || cp > 0x10FFFF)) bad = 1;
+                lensum += l;
+                cbyte[ci] = (uint16_t)k;
+                cp16[ci] = (uint16_t)(cp < 0xFFFFu ? cp : 0xFFFFu);
+                ccat[ci] = bad ? 0 : (cp < d.cat_len ? d.cat[cp] : d.cat[0]);  // char_category_def.rs:33-38
+            }
+            cb += __popcll(m);
+        }
+        lensum = bcast32(wave_sum(lensum));  // keep every early exit wave-uniform (SGPR) for the compiler
+        if (__ballot(bad != 0) != 0 || lensum != B) {
+            if (lane == 0) { a.status[s] = KGPU_SENT_INVALID_UTF8; a.tok_count[s] = 0; }
+            break;
+        }
+        if (lane == 0) cbyte[C] = (uint16_t)B;
+        for (uint32_t e = lane; e < C + 2; e += 64) { boff[e] = 0; bfill[e] = 0; }
+        wave_sync();
+
+        KGPU_TICK(2);
+        KGPU_STOP(2)
+        // ---- phase 1: one trie walk per start position; count + park matches ------
+        uint32_t wT = 0, ovf = 0;
+        {
+            const int nchunks = (int)((C + 63) / 64);
+            uint32_t carry_end = C;
+            for (int ch = nchunks - 1; ch >= 0; --ch) {
+                const uint32_t i = (uint32_t)ch * 64 + lane;
+                const bool active = i < C;
+                const uint32_t cat = active ? ccat[i] : 0x1FFu;
+                const uint32_t ncat = (i + 1 < C) ? ccat[i + 1] : 0x2FFu;
+                const uint64_t bm = __ballot(active && ncat != cat);
+                const uint64_t rest = bm >> lane;
+                const uint32_t run_end = rest ? i + (uint32_t)__ffsll((unsigned long long)rest) : carry_end;
+                carry_end = bcast32(run_end);
+                if (active) {
+                    uint32_t cnt = 0, m = 0;
+                    auto on_match = [&](uint32_t id, uint32_t nch) {
+                        if (m < MAXM && nch < 256) { mid[i * MAXM + m] = id; mnch[i * MAXM + m] = (uint8_t)nch; }
+                        else ovf = 1;
+                        ++m;
+                        const uint32_t nrec = 1u + d.morph[id - 1].dup;  // index.rs:46-51
+                        cnt += nrec;
+                        atomicAdd(&boff[i + nch], nrec);
+                    };
+                    const uint32_t cp = cp16[i];
+                    if (cp == 0xFFFFu) {
+                        wT += da_walk(d, text, cbyte[i], B, base_root, on_match);  // non-BMP first char: byte-wise from the root
+                    } else {
+                        const DaNode f = d.first[cp];  // {.base = node, .check = base[node]} or {0, steps}
+                        if (f.base == 0) {
+                            wT += (uint32_t)f.check;  // the walk dies inside the first character
+                        } else {
+                            // Each iteration sits on node p at byte k and issues BOTH dependent-free loads
+                            // together: the terminator probe of p (only where a key can end: a character
+                            // boundary) and the child for the next byte -- one memory latency per byte.
+                            int32_t p = f.base, bp = f.check;
+                            uint32_t k = cbyte[i + 1], nstart = 1;
+                            wT += k - cbyte[i];
+                            for (;;) {
+                                const bool more = k < B;
+                                const uint32_t c = more ? text[k] : 0u;
+                                const bool boundary = !more || (c & 0xC0) != 0x80;
+                                const uint32_t q = (uint32_t)(bp + (int32_t)c);
+                                const bool doprobe = boundary && (uint32_t)bp < d.da_len;
+                                const bool donext = more && q < d.da_len;
+                                DaNode t{0, 0}, nx{0, 0};
+                                if (doprobe) t = d.da[bp];  // + TERMINATOR (da.rs:166)
+                                if (donext) nx = d.da[q];
+                                if (doprobe && t.check == p && t.base < 0) on_match((uint32_t)(-t.base), nstart);
+                                if (!more) break;
+                                ++wT;
+                                if (!donext || nx.check != p) break;  // da.rs:162-165
+                                p = (int32_t)q;
+                                bp = nx.base;
+                                nstart += boundary;
+                                ++k;
+                            }
+                        }
+                    }
+                    mcnt[i] = (uint8_t)(m < MAXM ? m : MAXM);
+                    const CatInfo ci = d.cinfo[cat];
+                    uint32_t span = 0;
+                    if ((cnt == 0 || (ci.flags & CAT_INVOKE)) && (ci.flags & CAT_HAS_UNK) && ci.unk_count) {  // lattice.rs:54,87-92
+                        span = 1;
+                        if (ci.flags & CAT_GROUP) {  // lattice.rs:66-84
+                            const uint32_t r = run_end - i;
+                            span = r < MAX_UNKNOWN_LEN ? r : MAX_UNKNOWN_LEN;
+                        }
+                        cnt += ci.unk_count;
+                        atomicAdd(&boff[i + span], ci.unk_count);
+                    }
+                    uspan[i] = (uint16_t)span;
+                    nb[i] = cnt;
+                }
+            }
+        }
+        if (__ballot(ovf != 0) != 0) { tier_defer(io, lane, s); break; }
+        if (lane == 0) {
+            nb[C] = 1;       // EOS starts at C (lattice.rs:165-175)
+            nb[C + 1] = 0;
+            atomicAdd(&boff[0], 1u);  // BOS ends at 0 (lattice.rs:156-164)
+        }
+        wave_sync();
+
+        KGPU_TICK(3);
+        KGPU_STOP(3)
+        // ---- phase 2: prefix sums: node numbering, bucket offsets, pair offsets ------
+        uint32_t ncarry = 1, bcarry = 0, ecarry = 0, maxpairs = 0;
+        for (uint32_t i0 = 0; i0 < C + 2; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const uint32_t v = i < C + 2 ? nb[i] : 0;    // targets starting at i
+            const uint32_t w = i < C + 2 ? boff[i] : 0;  // predecessors ending at i
+            const uint32_t x = v * w;                    // relaxations at i (lattice.rs:122-125)
+            const uint32_t vs = wave_incl_scan(v, lane), ws = wave_incl_scan(w, lane), xs = wave_incl_scan(x, lane);
+            if (i < C + 2) { nb[i] = ncarry + vs - v; boff[i] = bcarry + ws - w; ebase[i] = ecarry + xs - x; }
+            ncarry += __shfl(vs, 63, 64);
+            bcarry += __shfl(ws, 63, 64);
+            ecarry += __shfl(xs, 63, 64);
+            maxpairs = max(maxpairs, x);
+        }
+#pragma unroll
+        for (int dd = 32; dd > 0; dd >>= 1) maxpairs = max(maxpairs, (uint32_t)__shfl_xor((int)maxpairs, dd, 64));
+        // scalarise: the carve and the fit test below must be wave-uniform branches
+        const uint32_t N = bcast32(ncarry), Nb = bcast32(bcarry), E = bcast32(ecarry);
+        maxpairs = bcast32(maxpairs);
+
+        // ---- LDS carve, part 2: node arrays, buckets, pair table ---------------------
+        off = align_up(off, 8);
+        uint2 *bk = (uint2 *)(smem + off);          off += 8 * Nb;  // bucket (= edges[e]): {dp, right | node << 16}
+        int32_t *nSid = (int32_t *)(smem + off);    off += 4 * N;   // +id known, -id unknown, 0 dummy
+        uint16_t *nLeft = (uint16_t *)(smem + off); off += 2 * N;
+        int16_t *nCost = (int16_t *)(smem + off);   off += 2 * N;
+        uint16_t *nSlot = (uint16_t *)(smem + off); off += 2 * N;   // bucket slot of the node
+        uint16_t *nStart = (uint16_t *)(smem + off); off += 2 * N;
+        off = align_up(off, 4);
+        const uint32_t off_emit_end = off;                          // everything above is written by emit
+        uint16_t *pre = (uint16_t *)(smem + off);   off += align_up(2 * N, 4);  // may overlay the match buffer
+        int16_t *mpair = (int16_t *)(smem + off);
+        if (N > 0xFFFF) { tier_defer(io, lane, s); break; }
+        // exact requirement: emit-written arrays stay below the match buffer; afterwards pre + the
+        // pair table (whole, so that the sweep is one block) overlay it
+        const uint32_t need_emit = off_emit_end + mbytes + 16, need_full = off + 2 * E;
+        if (need_emit > lds_bytes || off + 2 * maxpairs > lds_bytes) {
+            // reservation too small: release, wait (holding nothing) for the exact size, redo
+            pool_free(bm, pg, 0, npg, lane);
+            if (lane == 0) atomicAdd(io.late_count, 1u);
+            pg = NONE;
+            if ((max(need_emit, off + 2 * maxpairs) + page - 1) / page > POOL_PAGES || attempt != 0) { tier_defer(io, lane, s); break; }
+            npg = min(POOL_PAGES, (max(need_emit, need_full) + page - 1) / page);
+            pg = pool_wait_alloc(bm, npg, lane);
+            if (pg == NONE) { tier_defer(io, lane, s); break; }
+            continue;
+        }
+        wave_sync();
+
+        KGPU_TICK(4);
+        KGPU_STOP(4)
+        // ---- phase 3: emit nodes from the parked matches --------------------------------
+        for (uint32_t i = lane; i < C; i += 64) {
+            uint32_t t = nb[i];
+            const uint32_t nm = mcnt[i];
+            for (uint32_t m = 0; m < nm; ++m) {
+                const uint32_t id = mid[i * MAXM + m];
+                const uint32_t end = i + mnch[i * MAXM + m];
+                const uint32_t nrec = 1u + d.morph[id - 1].dup;
+                for (uint32_t r = 0; r < nrec; ++r) {  // lattice.rs:177-188
+                    const Morph8 mm = d.morph[id - 1 + r];
+                    const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
+                    nLeft[t] = (uint16_t)mm.left; nCost[t] = mm.cost; nSlot[t] = (uint16_t)slot; nStart[t] = (uint16_t)i;
+                    nSid[t] = (int32_t)(id + r);
+                    bk[slot].y = (uint32_t)(uint16_t)mm.right | (t << 16);
+                    ++t;
+                }
+            }
+            const uint32_t span = uspan[i];
+            if (span) {  // lattice.rs:87-97,190-201
+                const CatInfo ci = d.cinfo[ccat[i]];
+                const uint32_t end = i + span;
+                for (uint32_t r = 0; r < ci.unk_count; ++r) {
+                    const Morph8 mm = d.unk_morph[ci.unk_first - 1 + (int32_t)r];
+                    const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
+                    nLeft[t] = (uint16_t)mm.left; nCost[t] = mm.cost; nSlot[t] = (uint16_t)slot; nStart[t] = (uint16_t)i;
+                    nSid[t] = -(ci.unk_first + (int32_t)r);
+                    bk[slot].y = (uint32_t)(uint16_t)mm.right | (t << 16);
+                    ++t;
+                }
+            }
+        }
+        if (lane == 0) {
+            nLeft[N - 1] = (uint16_t)d.eos_left; nCost[N - 1] = 0; nSlot[N - 1] = NONE16;  // EOS: Morph(0,0,0), ranked id
+            nStart[N - 1] = (uint16_t)C; nSid[N - 1] = 0;
+            bk[0] = make_uint2(0u, d.bos_right);  // BOS: dp None -> 0 (lattice.rs:127), right_id 0 (ranked), node 0
+        }
+        wave_sync();
+        if (lane == 0) pre[0] = NONE16;
+        {   // the match buffer is dead now: give back the pages beyond pre + the whole pair table
+            const uint32_t keep = (need_full + page - 1) / page;
+            if (keep < npg) { pool_free(bm, pg, keep, npg, lane); npg = keep; }
+        }
+        const uint32_t mcap = (npg * page - off) / 2;
+        KGPU_TICK(5);
+        KGPU_STOP(5)
+        uint64_t cyc_gather = 0;
+        // ---- phases 3b + 4, per block of positions whose pairs fit the pair table ----
+        uint32_t qa = 0;
+        while (qa <= C) {
+            uint32_t qb;
+            if (E - ebase[qa] <= mcap) qb = C + 1;
+            else {  // largest qb with ebase[qb] - ebase[qa] <= mcap (ebase is non-decreasing)
+                uint32_t lo = qa + 1, hi = C + 1;  // invariant: ebase[lo] - ebase[qa] <= mcap (a single position fits)
+                while (lo < hi) {
+                    const uint32_t mid_ = (lo + hi + 1) / 2;
+                    if (ebase[mid_] - ebase[qa] <= mcap) lo = mid_; else hi = mid_ - 1;
+                }
+                qb = lo;
+            }
+            const uint32_t eb0 = ebase[qa];
+            const uint64_t tg0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+            // -- 3b: gather every connection cost of the block into LDS (connection.rs:12-14)
+            const uint32_t ta = nb[qa], tb = nb[qb];
+            for (uint32_t t = ta + lane; t < tb; t += 64) {
+                const uint32_t q = nStart[t];
+                const uint32_t p0 = boff[q], P = boff[q + 1] - p0;
+                const uint32_t ti = t - nb[q];
+                const uint32_t base = ebase[q] - eb0 + ti * P;  // pair (ti, j) lives at ti*P + j
+                const uint32_t stride = 1u;
+                const int16_t *col = d.conn + (size_t)d.conn_rows * nLeft[t];
+                uint32_t j = 0;
+                for (; j + 4 <= P; j += 4) {  // 4 independent gathers in flight per lane
+                    const uint32_t r0 = bk[p0 + j].y & 0xFFFFu, r1 = bk[p0 + j + 1].y & 0xFFFFu;
+                    const uint32_t r2 = bk[p0 + j + 2].y & 0xFFFFu, r3 = bk[p0 + j + 3].y & 0xFFFFu;
+                    const int16_t c0 = col[r0], c1 = col[r1], c2 = col[r2], c3 = col[r3];
+                    mpair[base + j * stride] = c0; mpair[base + (j + 1) * stride] = c1;
+                    mpair[base + (j + 2) * stride] = c2; mpair[base + (j + 3) * stride] = c3;
+                }
+                for (; j < P; ++j) mpair[base + j * stride] = col[bk[p0 + j].y & 0xFFFFu];
+            }
+            wave_sync();
+            if (prof) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
+            if (stop_after == 6) break;
+
+            // -- 4: Viterbi sweep over the block (lattice.rs:116-142), LDS only.
+            // The sweep is one dependent chain per position, so what counts is the length of that
+            // chain, not arithmetic.  Position descriptors are therefore kept in VGPRs, one
+            // position per lane for 64 positions at a time, and broadcast with v_readlane (no LDS
+            // round trip, no wait); the common shape -- ceil_pow2(P) * T <= 64 lanes, P <= 16 --
+            // is straight-line code: pair (ti, j) on lane ti * Pp + j, one batch of LDS reads, a DPP
+            // butterfly min on the u64 key (total ^ signbit, predecessor node index), leaders write.
+            for (uint32_t qc = qa; qc < qb; qc += 64) {
+                const uint32_t ql = qc + lane;
+                uint32_t dT = 0, dP = 0, dt0 = 0, dp0 = 0, deb = 0, dflag = 0;
+                if (ql < qb) {
+                    dt0 = nb[ql]; dT = nb[ql + 1] - dt0;
+                    dp0 = boff[ql]; dP = boff[ql + 1] - dp0;
+                    deb = ebase[ql] - eb0;
+                    const uint32_t lgv = dP > 1 ? 32 - __clz(dP - 1) : 0;  // ceil(log2 P)
+                    dflag = (lgv & 7u) | ((dP != 0 && lgv <= 4 && (dT << lgv) <= 64) ? 8u : 0u);
+                }
+                const uint32_t nq = min(64u, qb - qc);
+                for (uint32_t r = 0; r < nq; ++r) {
+                    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)dT, (int)r);
+                    const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)dP, (int)r);
+                    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)dt0, (int)r);
+                    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)dp0, (int)r);
+                    const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)deb, (int)r);
+                    const uint32_t flag = (uint32_t)__builtin_amdgcn_readlane((int)dflag, (int)r);
+                    uint32_t lg = flag & 7u;  // ceil(log2 P), precomputed per position
+                    if (flag & 8u) {
+                        // fast shape: one straight-line body per group size (compile-time shifts, exact
+                        // number of DPP steps, no inner branches)
+                        auto fast = [&](auto LGc) {
+                            constexpr uint32_t LG = decltype(LGc)::value;
+                            const uint32_t ti = lane >> LG, j = lane & ((1u << LG) - 1);
+                            const bool tv = ti < T;
+                            const uint32_t tt = t0 + (tv ? ti : 0);
+                            const int32_t cost = (int32_t)nCost[tt];  // finalisation operands ride in the same round trip
+                            const uint32_t sl = nSlot[tt];
+                            uint64_t key = ~0ull;
+                            if (tv && j < P) {
+                                const uint2 e = bk[p0 + j];
+                                const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + ti * P + j];
+                                key = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (e.y >> 16);
+                            }
+                            if constexpr (LG >= 1) key = dpp_min_step<0xB1>(key);
+                            if constexpr (LG >= 2) key = dpp_min_step<0x4E>(key);
+                            if constexpr (LG >= 3) key = dpp_min_step<0x141>(key);
+                            if constexpr (LG >= 4) key = dpp_min_step<0x140>(key);
+                            if (tv && j == 0) {
+                                const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + cost;
+                                const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
+                                pre[tt] = (uint16_t)(ok ? ((uint32_t)key & 0xFFFFu) : NONE16);
+                                if (sl != NONE16) bk[sl].x = (uint32_t)(ok ? tot : INF);
+                            }
+                        };
+                        switch (lg) {
+                            case 0: fast(std::integral_constant<uint32_t, 0>{}); break;
+                            case 1: fast(std::integral_constant<uint32_t, 1>{}); break;
+                            case 2: fast(std::integral_constant<uint32_t, 2>{}); break;
+                            case 3: fast(std::integral_constant<uint32_t, 3>{}); break;
+                            default: fast(std::integral_constant<uint32_t, 4>{}); break;
+                        }
+                    } else if (P == 0) {  // nothing ends here: every target stays at INF with no predecessor
+                        for (uint32_t t = t0 + lane; t < t0 + T; t += 64) {
+                            pre[t] = NONE16;
+                            const uint32_t sl = nSlot[t];
+                            if (sl != NONE16) bk[sl].x = (uint32_t)INF;
+                        }
+                    } else if (T) {  // any shape: loop over target groups and predecessor chunks
+                        lg = P > 1 ? 32 - __clz(P - 1) : 0;
+                        if (lg > 6) lg = 6;
+                        const uint32_t j = lane & ((1u << lg) - 1), tl = lane >> lg, TG = 64u >> lg;
+                        for (uint32_t tbase = 0; tbase < T; tbase += TG) {
+                            const uint32_t ti = tbase + tl;
+                            const bool tvalid = ti < T;
+                            const int32_t cost = tvalid ? (int32_t)nCost[t0 + ti] : 0;
+                            const uint32_t sl = tvalid ? (uint32_t)nSlot[t0 + ti] : NONE16;
+                            uint64_t key = ~0ull;
+                            for (uint32_t jc = 0; jc < P; jc += 64) {
+                                const uint32_t jj = jc + j;
+                                uint64_t ck = ~0ull;
+                                if (tvalid && jj < P) {
+                                    const uint2 e = bk[p0 + jj];
+                                    const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + ti * P + jj];
+                                    ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (e.y >> 16);
+                                }
+                                ck = group_min(ck, lg);
+                                key = ck < key ? ck : key;
+                            }
+                            if (tvalid && j == 0) {
+                                const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + cost;
+                                const bool ok = tot < INF;
+                                pre[t0 + ti] = (uint16_t)(ok ? ((uint32_t)key & 0xFFFFu) : NONE16);
+                                if (sl != NONE16) bk[sl].x = (uint32_t)(ok ? tot : INF);
+                            }
+                        }
+                    }
+                    wave_sync();
+                }
+            }
+            qa = qb;
+        }
+
+        KGPU_TICK(6);
+        KGPU_STOP(6)
+        KGPU_STOP(7)
+        // ---- phase 5: backtrace (lattice.rs:144-153) + Node -> Token (tokenizer.rs:22-43)
+        uint32_t K = 0;
+        if (lane == 0) {
+            uint32_t pos = N - 1, pr;
+            while ((pr = pre[pos]) != NONE16 && K <= C) { path[K++] = (uint16_t)pos; pos = pr; }  // K <= C + 1 always; bound the walk anyway
+        }
+        K = bcast32(K);
+        // staging slot of the sentence: K <= C + 1 <= B + 1 tokens always fit at b0 + s
+        // (no cursor atomics: a single hot word serialises ~90 sentences/us chip-wide)
+        const uint64_t ts = b0 - a.offsets[0] + s;
+        wave_sync();
+        {
+            for (uint32_t k = lane; k < K; k += 64) {
+                const uint32_t t = path[K - 1 - k];
+                const int32_t sid = nSid[t];
+                kgpu_token tk;
+                if (sid == 0) {  // Dummy -> "EOS" (tokenizer.rs:27-28,34)
+                    tk.id = 0; tk.cls = KGPU_CLASS_DUMMY; tk.position = B; tk.start = C; tk.end = C + 3; tk.byte_len = 0;
+                } else {
+                    // a word is never last on the path (EOS is): it ends where its successor starts
+                    const uint32_t st = nStart[t], en = nStart[path[K - 2 - k]], bs = cbyte[st];
+                    tk.id = sid > 0 ? sid : -sid;
+                    tk.cls = sid > 0 ? KGPU_CLASS_KNOWN : KGPU_CLASS_UNKNOWN;
+                    tk.position = bs; tk.start = st; tk.end = en; tk.byte_len = cbyte[en] - bs;
+                }
+                a.stage[ts + k] = tk;
+            }
+        }
+        if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; }
+        if (a.count_work) {
+            wT = wave_sum(wT);
+            const uint64_t t7 = __builtin_amdgcn_s_memtime();
+            accW[0] += 1; accW[1] += B; accW[2] += C; accW[3] += wT; accW[4] += N - 1; accW[5] += E; accW[6] += K;
+            accP[0] += tick[1] - tick[0]; accP[1] += tick[2] - tick[1]; accP[2] += tick[3] - tick[2];
+            accP[3] += tick[4] - tick[3]; accP[4] += tick[5] - tick[4]; accP[5] += cyc_gather;
+            accP[6] += tick[6] - tick[5] - cyc_gather; accP[7] += t7 - tick[6]; accP[8] += 1;
+        }
+        break;
+        }  // attempt
+        if (pg != NONE) pool_free(bm, pg, 0, npg, lane);
+    }
+    if (a.count_work && lane == 0) {
+        for (int k = 0; k < 7; ++k) atomicAdd(&a.ctl->work[k], (unsigned long long)accW[k]);
+        for (int k = 0; k < 9; ++k) atomicAdd(&a.ctl->phase[k], (unsigned long long)accP[k]);
+    }
+}
+
+// Workgroups of this kernel that are resident per CU for a given shape (the LDS allocation
+// granularity makes this smaller than 160 KB / pool_bytes would suggest for odd sizes).
+int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves) {
+    if (pool_bytes > 64 * 1024)
+        if (hipFuncSetAttribute((const void *)k_tokenize_pool, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes) != hipSuccess) return 0;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_pool, (int)(64 * waves), (size_t)pool_bytes) != hipSuccess) return 0;
+    return n;
+}
+
+int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t pool_bytes, uint32_t waves,
+                         int n_workgroups, void *stream) {
+    static const uint32_t stop_after = getenv("KGPU_DEBUG_STOP") ? (uint32_t)atoi(getenv("KGPU_DEBUG_STOP")) : 0u;
+    if (pool_bytes > 64 * 1024) {  // beyond the default dynamic-LDS cap the kernel has to opt in
+        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k_tokenize_pool, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, d, a, io, pool_bytes, stop_after);
+    return (int)hipGetLastError();
+}
+
+}  // namespace kgpu

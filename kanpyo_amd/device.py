@@ -10,7 +10,7 @@ import ctypes as C
 
 from . import _lib
 
-PROFILE_OFF, PROFILE_EVENTS, PROFILE_WORK = 0, 1, 2
+PROFILE_OFF, PROFILE_EVENTS, PROFILE_WORK, PROFILE_SAMPLED = 0, 1, 2, 4
 
 
 class DeviceContext:

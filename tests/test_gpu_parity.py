@@ -287,6 +287,25 @@ def test_every_memory_tier_is_bit_exact(libs, pack, tiers, monkeypatch):
     assert_same(tok, orc, ["", "", "", "あ", "", "すもも", ""])  # packs made of empties / ragged tail
 
 
+@pytest.mark.parametrize("pool,tiers", [("80:10", "0"), ("80:8,160:4", "0"), ("16:4", "160"), ("8:2", "0"), ("160:16", "0"),
+                                        ("40:16", "20"), ("24:1", "0")])
+def test_lds_page_pool_is_bit_exact(libs, pool, tiers, monkeypatch):
+    """The pool kernel (KiB of LDS per workgroup : independent wavefronts sharing it) under pressure:
+    more wavefronts than the pool can serve at once, pools too small for the long sentences,
+    reservations that prove too small (redo), all followed by the fixed tiers / HBM-scratch kernel."""
+    from kanpyo_amd import Tokenizer, synth
+
+    _, oracle = libs
+    monkeypatch.setenv("KGPU_POOL", pool)
+    monkeypatch.setenv("KGPU_TIERS", tiers)
+    sd = synth.build_dict(20000, seed=11)
+    tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
+    sents = synth.make_corpus(sd, 3000, 3, "cfg2") + synth.make_corpus(sd, 300, 4, "cfg3") + synth.make_corpus(sd, 2, 6, "cfg5") + ["", "あ", "ア" * 1500]
+    for _ in range(3):  # the reservation estimate adapts between calls
+        assert_same(tok, orc, sents)
+    assert_same(tok, orc, ["", "", "", "あ", "", "すもも", ""])
+
+
 def test_built_and_reloaded_dictionary(libs, tmp_path):
     """8(f): a dictionary built from MeCab-format sources, saved as a Kanpyo .dict, reloaded and
     uploaded tokenises bit-exactly like the oracle over the same blobs."""

@@ -13,7 +13,7 @@ from kanpyo_amd.tokenizer import pack_sentences
 kind, n = sys.argv[1], int(sys.argv[2])
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 sd = synth.build_dict()
-sents = synth.make_corpus(sd, n, 2 if kind == "cfg3" else 5 if kind == "cfg5" else 1, kind)
+sents = synth.make_corpus(sd, n, 2 if kind == "cfg3" else 5 if kind == "cfg5" else 100, kind)
 tok = Tokenizer(sd.dict)
 dev = torch.device("cuda", 0)
 bs = []
@@ -23,7 +23,7 @@ for lo in range(0, n, batch):
     cap = int(offs[-1]) + m
     bs.append((torch.from_numpy(utf8.copy()).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev), m, int(offs[-1]), cap))
 capmax = max(b[4] for b in bs)
-Q = 4
+Q = int(os.environ.get('BENCH_Q', '4'))
 ctxs = [DeviceContext(tok) for _ in range(Q)]
 outs = [(torch.empty((capmax, 6), dtype=torch.int32, device=dev), torch.empty(batch + 1, dtype=torch.int64, device=dev),
          torch.empty(batch, dtype=torch.uint8, device=dev)) for _ in range(Q)]
