@@ -497,11 +497,10 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
         break;
     }
     c->pending = false;
-    if (c->last.n && (c->plan.n_pools || c->plan.n_lds_tiers > 1 || c->plan.pack_lds_bytes)) {
+    if (c->last.n && c->plan.n_pools) {
         // The pool kernel reserves est LDS bytes per input byte up front: a reservation that proves
         // too small costs a redo (late_count), one that is too large only idles pages until the
-        // lattice is known -- steer for a redo rate of 1-3 %.  (The fixed tiers use the same
-        // estimate for early routing.)  Applied to the value the batch ran with; races between
+        // lattice is known -- steer for a redo rate of 1-3 %.  Applied to the value the batch ran with; races between
         // contexts only lose an adjustment.
         if (c->plan.n_pools > 1) {
             if (c->h_ctl->ovf_count[0] > 0) c->dict->big_pool_batches.store(64, std::memory_order_relaxed);

@@ -69,24 +69,16 @@ struct BatchArgs {
     uint32_t est_q8;              // expected LDS bytes per input byte (x256): early tier routing
 };
 
-// Memory tiers of the fused tokenize kernel: tier k keeps the whole lattice of a
-// sentence in `lds_bytes` of LDS (one 64-lane workgroup per sentence); what does
-// not fit is deferred to the next tier; the last tier is the general kernel
-// whose lattice lives in HBM scratch.
+// Launch plan of one batch: the LDS page-pool kernel (kgpu_pool.hip) once or twice -- W independent
+// wavefronts per workgroup share pool_bytes of LDS, each sentence takes what it needs -- then the
+// general kernel, whose lattices live in HBM scratch, for whatever fits no pool.  A sentence that
+// a launch cannot serve is pushed onto the next launch's work list.
 struct TierPlan {
-    uint32_t pack_lds_bytes;  // 0: no packed first tier (kgpu_pack.hip)
-    uint32_t pack_size;       // sentences per pack: 1, 2 or 4
-    int pack_workgroups;
-    int n_lds_tiers;
-    uint32_t lds_bytes[3];
-    int workgroups[3];       // persistent grid per LDS tier
-    int general_workgroups;
-    // LDS page-pool launches (kgpu_pool.hip), run before the fixed tiers: W independent
-    // wavefronts per workgroup share pool_bytes of LDS, each sentence takes what it needs
     int n_pools;
     uint32_t pool_bytes[2];
     uint32_t pool_waves[2];
-    int pool_workgroups[2];
+    int pool_workgroups[2];   // persistent grid per pool launch
+    int general_workgroups;
 };
 
 // Launchers (kgpu_kernels.hip).  `stream` is a hipStream_t.

@@ -327,49 +327,23 @@ __global__ __launch_bounds__(256) void k_compact(BatchArgs a) {
     }
 }
 
-int launch_tokenize_lds(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t lds_bytes, int n_workgroups,
-                        void *stream);  // kgpu_lds.hip
-
 int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t pool_bytes, uint32_t waves,
                          int n_workgroups, void *stream);  // kgpu_pool.hip
 int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
 
-int launch_tokenize_pack(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t lds_bytes, uint32_t gpack,
-                         int n_workgroups, void *stream);  // kgpu_pack.hip
-
-// Tier chain: the packed kernel (several short sentences per wavefront), then the
-// per-sentence LDS tiers in ascending LDS size, then the general (HBM scratch)
-// kernel.  Every launch is a persistent grid over its tier's work list.
+// Launch chain: pool kernel(s), then the general (HBM scratch) kernel.  Every launch is a
+// persistent grid over its work list (the first one: the identity over [0, n)).
 int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan, int n_pools_now, void *stream) {
     Control *ctl = a.ctl;
     const uint32_t *in_list = nullptr;
     const unsigned int *in_count = nullptr;
     int li = 0;  // next free work list
-    if (plan.pack_lds_bytes && a.n) {
-        TierIO io{nullptr, nullptr, a.ovf[li], &ctl->ovf_count[li], &ctl->late_count[li]};
-        uint64_t packs = (a.n + plan.pack_size - 1) / plan.pack_size;
-        uint64_t wg = std::min<uint64_t>((uint64_t)plan.pack_workgroups, packs);
-        int e = launch_tokenize_pack(d, a, io, plan.pack_lds_bytes, plan.pack_size, (int)(wg ? wg : 1), stream);
-        if (e) return e;
-        in_list = a.ovf[li];
-        in_count = &ctl->ovf_count[li];
-        ++li;
-    }
     for (int k = 0; k < plan.n_pools && k < n_pools_now; ++k, ++li) {
         TierIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], &ctl->late_count[li]};
         uint64_t wg = plan.pool_workgroups[k];
         const uint64_t want = (a.n + plan.pool_waves[k] - 1) / plan.pool_waves[k];
         if (!in_list && want < wg) wg = want;
         int e = launch_tokenize_pool(d, a, io, plan.pool_bytes[k], plan.pool_waves[k], (int)(wg ? wg : 1), stream);
-        if (e) return e;
-        in_list = a.ovf[li];
-        in_count = &ctl->ovf_count[li];
-    }
-    for (int k = 0; k < plan.n_lds_tiers && li < 4; ++k, ++li) {
-        TierIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], &ctl->late_count[li]};
-        uint64_t wg = plan.workgroups[k];
-        if (!in_list && a.n < wg) wg = a.n;
-        int e = launch_tokenize_lds(d, a, io, plan.lds_bytes[k], (int)(wg ? wg : 1), stream);
         if (e) return e;
         in_list = a.ovf[li];
         in_count = &ctl->ovf_count[li];
@@ -397,40 +371,7 @@ TierPlan default_tier_plan(int device) {
     int cus = 256;
     if (hipGetDeviceProperties(&p, device) == hipSuccess) cus = p.multiProcessorCount;
     TierPlan t{};
-    // The packed first tier (kgpu_pack.hip) is OFF by default: it cuts VALU/SALU work per sentence
-    // by 2-3x but not the L1-miss traffic that bounds throughput, and it runs 4x fewer waves
-    // (measured 25 M vs 30 M sentences/s on cfg 2).  KGPU_PACK=40,4 turns it on.
-    t.pack_lds_bytes = 0; t.pack_size = 4; t.pack_workgroups = cus * 4;
-    // Fixed-LDS tiers (kgpu_lds.hip) are off by default -- the page-pool kernel below adapts the
-    // LDS per sentence instead; KGPU_TIERS="14:10,160" brings them back (after the pools).
-    t.n_lds_tiers = 0;
-    if (const char *e = getenv("KGPU_PACK")) {  // "<KiB>,<sentences per pack>" or "0"
-        int kib = atoi(e), g = 4;
-        if (const char *c = strchr(e, ',')) g = atoi(c + 1);
-        if (g != 1 && g != 2 && g != 4) g = 4;
-        if (kib <= 0 || kib > 160) { t.pack_lds_bytes = 0; }
-        else { t.pack_lds_bytes = (uint32_t)kib * 1024; t.pack_size = (uint32_t)g; t.pack_workgroups = cus * (160 / kib); }
-    }
     t.general_workgroups = cus * 8;
-    if (const char *e = getenv("KGPU_TIERS")) {  // e.g. "20,64,160" (KiB) or "0" for the general kernel only
-        t.n_lds_tiers = 0;
-        const char *q = e;
-        while (*q && t.n_lds_tiers < 3) {
-            int kib = atoi(q);
-            if (kib > 0 && kib <= 160) {
-                t.lds_bytes[t.n_lds_tiers] = (uint32_t)kib * 1024;
-                int per_cu = 160 / kib;
-                const char *c = q;
-                while (*c && *c != ',' && *c != ':') ++c;
-                if (*c == ':' && atoi(c + 1) > 0) per_cu = atoi(c + 1);  // "<KiB>:<workgroups per CU>"
-                t.workgroups[t.n_lds_tiers] = cus * per_cu;
-                ++t.n_lds_tiers;
-            }
-            while (*q && *q != ',') ++q;
-            if (*q == ',') ++q;
-        }
-    }
-    // LDS page pools: "<KiB>:<wavefronts per workgroup>[,<KiB>:<wavefronts>]", "0" = none
     // Default: two 80 KB pools per CU with 8 wavefronts each (16 sentences in flight per CU, any
     // mix of sizes up to 80 KB; smaller workgroups drain sooner at the tail of a 4096-sentence
     // batch than one 160 KB / 16-wavefront workgroup), then one 160 KB pool per CU for the

@@ -1,21 +1,35 @@
-// kanpyo_amd/csrc/kgpu_pool.hip -- LDS-resident fused tokenize kernel with a per-workgroup
-// LDS page pool (gfx950).
+// kanpyo_amd/csrc/kgpu_pool.hip -- the LDS-resident fused tokenize kernel (gfx950).
 //
-// Same per-sentence algorithm as kgpu_lds.hip (one 64-lane wavefront owns one sentence from
-// bytes to tokens; the whole lattice lives in LDS), but the LDS a sentence gets is no longer
-// the launch's fixed dynamic-LDS size.  A workgroup is W independent wavefronts sharing one
-// pool of 64 pages (a u64 bitmap, first-fit runs of contiguous pages, LDS atomics); every
-// wavefront reserves what its sentence is expected to need, gives back what it does not use
-// after the lattice is known, and releases the rest when the tokens are out.  Occupancy
-// therefore follows the sentences (short ones pack ~18 per CU, a long one may take a whole
-// pool) instead of the worst case of a tier, and no sentence that fits a pool is handed to a
-// later launch -- the chain of dependent tier launches (each as long as its slowest sentence)
-// is gone.
+// One 64-lane wavefront owns one sentence from bytes to tokens; the whole lattice of the
+// sentence lives in the CU's LDS (160 KB per CU on MI355X) and the Viterbi dependency chain
+// touches nothing but LDS and registers:
+//
+//   * one double-array walk per start position; its matches (trie id, char length) are parked
+//     in an LDS match buffer so the emit phase re-walks nothing (trie/da.rs:155-182 once per
+//     position);
+//   * every connection cost the sweep will need -- M[right(j)][left(t)] for each (target t,
+//     predecessor j) pair, connection.rs:12-14 -- depends only on the morph ids, not on the DP
+//     values, so all of them are gathered from HBM/L2 into an LDS pair table in ONE parallel pass
+//     before the sweep ("the connection matrix tiled through LDS"); the sweep itself then runs
+//     at LDS latency;
+//   * per position the (target, predecessor) pairs are spread across the 64 lanes, each target
+//     owning an aligned power-of-two lane group, and the strict-'<' first-minimum of
+//     lattice.rs:125-139 is a DPP butterfly min-reduction on the 64-bit key
+//     (total ^ signbit, predecessor node index).
+//
+// LDS page pool.  A workgroup is W independent wavefronts sharing one pool of 64 pages (a u64
+// bitmap, first-fit runs of contiguous pages, LDS atomics).  Every wavefront reserves what its
+// sentence is expected to need (host-adapted bytes-per-input-byte estimate), gives back what it
+// does not use once the lattice is known, and releases the rest when the tokens are out.
+// Occupancy therefore follows the sentences (short ones run 16 per CU, a long one may take a
+// whole pool) instead of a launch-wide worst case, and no sentence that fits a pool waits for a
+// later launch.
 //
 // Waiting rule (deadlock freedom): a wavefront waits for pages only while it holds none.  If
 // its reservation turns out too small it releases it, waits for the exact size (now known)
-// and redoes the sentence; a sentence that cannot fit an empty pool goes to the next launch's
-// work list.  The wavefronts of a workgroup never meet at a barrier after the pool is set up.
+// and redoes the sentence; a sentence that cannot fit an empty pool, or has more than MAXM
+// dictionary prefixes at one position, goes to the next launch's work list.  The wavefronts of
+// a workgroup never meet at a barrier after the pool is set up.
 #include <cstdlib>
 #include <type_traits>
 
@@ -35,8 +49,8 @@ constexpr uint32_t NONE16 = 0xFFFFu;
 // v_cmp_lt_u64 + two v_cndmask per step, no branches.
 template <int CTRL>
 __device__ __forceinline__ uint64_t dpp_min_step(uint64_t k) {
-    const uint32_t oh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), CTRL, 0xF, 0xF, false);
-    const uint32_t ol = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, CTRL, 0xF, 0xF, false);
+    const uint32_t oh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), CTRL, 0xF, 0xF, true);
+    const uint32_t ol = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, CTRL, 0xF, 0xF, true);
     const uint64_t o = ((uint64_t)oh << 32) | ol;
     return o < k ? o : k;
 }
@@ -102,6 +116,10 @@ __device__ __forceinline__ uint32_t pool_wait_alloc(uint64_t *bm, uint32_t k, ui
 
 }  // namespace
 
+// PROF: device-side work counters + per-phase shader clocks (KGPU_PROFILE_WORK).  A separate
+// instantiation, because the 16 wave-uniform u64 accumulators + 9 ticks cost ~50 of the 102 SGPRs
+// and push the plain kernel into SGPR spilling (v_readlane / v_writelane traffic on the VALU).
+template <bool PROF>
 __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a, TierIO io, uint32_t pool_bytes,
                                                         uint32_t stop_after /* ablation timing only; 0 = run everything */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t pool[];
@@ -146,7 +164,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         const uint32_t lds_bytes = npg * page;
 
         uint64_t tick[9];
-        const bool prof = a.count_work != 0;
+        constexpr bool prof = PROF;
 #define KGPU_TICK(k) do { if (prof) tick[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #define KGPU_STOP(k) if (stop_after == (k)) { if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = 0; } break; }
         KGPU_TICK(0);
@@ -327,11 +345,10 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
 
         // ---- LDS carve, part 2: node arrays, buckets, pair table ---------------------
         off = align_up(off, 8);
-        uint2 *bk = (uint2 *)(smem + off);          off += 8 * Nb;  // bucket (= edges[e]): {dp, right | node << 16}
+        uint2 *bk = (uint2 *)(smem + off);          off += 8 * (Nb + 1);  // bucket (= edges[e]): {dp, right | node << 16}; [Nb]: sink for EOS
         int32_t *nSid = (int32_t *)(smem + off);    off += 4 * N;   // +id known, -id unknown, 0 dummy
         uint16_t *nLeft = (uint16_t *)(smem + off); off += 2 * N;
-        int16_t *nCost = (int16_t *)(smem + off);   off += 2 * N;
-        uint16_t *nSlot = (uint16_t *)(smem + off); off += 2 * N;   // bucket slot of the node
+        uint32_t *nCS = (uint32_t *)(smem + off);   off += 4 * N;   // word cost (i16) | bucket slot of the node << 16
         uint16_t *nStart = (uint16_t *)(smem + off); off += 2 * N;
         off = align_up(off, 4);
         const uint32_t off_emit_end = off;                          // everything above is written by emit
@@ -363,11 +380,12 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
             for (uint32_t m = 0; m < nm; ++m) {
                 const uint32_t id = mid[i * MAXM + m];
                 const uint32_t end = i + mnch[i * MAXM + m];
-                const uint32_t nrec = 1u + d.morph[id - 1].dup;
+                const Morph8 m0 = d.morph[id - 1];  // first record: carries the duplicate count (index.rs:46-51)
+                const uint32_t nrec = 1u + m0.dup;
                 for (uint32_t r = 0; r < nrec; ++r) {  // lattice.rs:177-188
-                    const Morph8 mm = d.morph[id - 1 + r];
+                    const Morph8 mm = r ? d.morph[id - 1 + r] : m0;
                     const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
-                    nLeft[t] = (uint16_t)mm.left; nCost[t] = mm.cost; nSlot[t] = (uint16_t)slot; nStart[t] = (uint16_t)i;
+                    nLeft[t] = (uint16_t)mm.left; nCS[t] = (uint32_t)(uint16_t)mm.cost | (slot << 16); nStart[t] = (uint16_t)i;
                     nSid[t] = (int32_t)(id + r);
                     bk[slot].y = (uint32_t)(uint16_t)mm.right | (t << 16);
                     ++t;
@@ -380,7 +398,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
                 for (uint32_t r = 0; r < ci.unk_count; ++r) {
                     const Morph8 mm = d.unk_morph[ci.unk_first - 1 + (int32_t)r];
                     const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
-                    nLeft[t] = (uint16_t)mm.left; nCost[t] = mm.cost; nSlot[t] = (uint16_t)slot; nStart[t] = (uint16_t)i;
+                    nLeft[t] = (uint16_t)mm.left; nCS[t] = (uint32_t)(uint16_t)mm.cost | (slot << 16); nStart[t] = (uint16_t)i;
                     nSid[t] = -(ci.unk_first + (int32_t)r);
                     bk[slot].y = (uint32_t)(uint16_t)mm.right | (t << 16);
                     ++t;
@@ -388,7 +406,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
             }
         }
         if (lane == 0) {
-            nLeft[N - 1] = (uint16_t)d.eos_left; nCost[N - 1] = 0; nSlot[N - 1] = NONE16;  // EOS: Morph(0,0,0), ranked id
+            nLeft[N - 1] = (uint16_t)d.eos_left; nCS[N - 1] = Nb << 16;  // EOS: Morph(0,0,0), ranked id; its dp goes to the sink slot
             nStart[N - 1] = (uint16_t)C; nSid[N - 1] = 0;
             bk[0] = make_uint2(0u, d.bos_right);  // BOS: dp None -> 0 (lattice.rs:127), right_id 0 (ranked), node 0
         }
@@ -415,17 +433,18 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
                 }
                 qb = lo;
             }
-            const uint32_t eb0 = ebase[qa];
+            qb = bcast32(qb);  // values read back from LDS are VGPRs to the compiler: keep the loop control scalar
+            const uint32_t eb0 = bcast32(ebase[qa]);
             const uint64_t tg0 = prof ? __builtin_amdgcn_s_memtime() : 0;
             // -- 3b: gather every connection cost of the block into LDS (connection.rs:12-14)
-            const uint32_t ta = nb[qa], tb = nb[qb];
+            const uint32_t ta = bcast32(nb[qa]), tb = bcast32(nb[qb]);
             for (uint32_t t = ta + lane; t < tb; t += 64) {
                 const uint32_t q = nStart[t];
                 const uint32_t p0 = boff[q], P = boff[q + 1] - p0;
                 const uint32_t ti = t - nb[q];
                 const uint32_t base = ebase[q] - eb0 + ti * P;  // pair (ti, j) lives at ti*P + j
                 const uint32_t stride = 1u;
-                const int16_t *col = d.conn + (size_t)d.conn_rows * nLeft[t];
+                const int16_t *col = d.conn + (stop_after == 8 ? (size_t)0 : (size_t)d.conn_rows * nLeft[t]);  // 8: timing experiment (one hot row)
                 uint32_t j = 0;
                 for (; j + 4 <= P; j += 4) {  // 4 independent gathers in flight per lane
                     const uint32_t r0 = bk[p0 + j].y & 0xFFFFu, r1 = bk[p0 + j + 1].y & 0xFFFFu;
@@ -449,24 +468,26 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
             // butterfly min on the u64 key (total ^ signbit, predecessor node index), leaders write.
             for (uint32_t qc = qa; qc < qb; qc += 64) {
                 const uint32_t ql = qc + lane;
-                uint32_t dT = 0, dP = 0, dt0 = 0, dp0 = 0, deb = 0, dflag = 0;
+                // two packed descriptor words per position: d0 = first target | first bucket slot << 16,
+                // d1 = pair offset (17 bits) | T (7) | P (5) | ceil(log2 P) (3; 7 = not the fast shape)
+                uint32_t dT = 0, dP = 0, d0 = 0, d1 = 7u << 29;
                 if (ql < qb) {
-                    dt0 = nb[ql]; dT = nb[ql + 1] - dt0;
-                    dp0 = boff[ql]; dP = boff[ql + 1] - dp0;
-                    deb = ebase[ql] - eb0;
+                    const uint32_t dt0 = nb[ql], dp0 = boff[ql], deb = ebase[ql] - eb0;  // deb <= mcap <= 80 Ki pairs
+                    dT = nb[ql + 1] - dt0;
+                    dP = boff[ql + 1] - dp0;
                     const uint32_t lgv = dP > 1 ? 32 - __clz(dP - 1) : 0;  // ceil(log2 P)
-                    dflag = (lgv & 7u) | ((dP != 0 && lgv <= 4 && (dT << lgv) <= 64) ? 8u : 0u);
+                    const bool fastq = dP != 0 && lgv <= 4 && (dT << lgv) <= 64;
+                    d0 = dt0 | (dp0 << 16);
+                    d1 = deb | (fastq ? (dT << 17) | (dP << 24) | (lgv << 29) : 7u << 29);
                 }
                 const uint32_t nq = min(64u, qb - qc);
                 for (uint32_t r = 0; r < nq; ++r) {
-                    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)dT, (int)r);
-                    const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)dP, (int)r);
-                    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)dt0, (int)r);
-                    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)dp0, (int)r);
-                    const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)deb, (int)r);
-                    const uint32_t flag = (uint32_t)__builtin_amdgcn_readlane((int)dflag, (int)r);
-                    uint32_t lg = flag & 7u;  // ceil(log2 P), precomputed per position
-                    if (flag & 8u) {
+                    const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)r);
+                    const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)r);
+                    const uint32_t t0 = D0 & 0xFFFFu, p0 = D0 >> 16, eb = D1 & 0x1FFFFu;
+                    uint32_t lg = D1 >> 29;
+                    uint32_t T = (D1 >> 17) & 127u, P = (D1 >> 24) & 31u;
+                    if (lg != 7u) {
                         // fast shape: one straight-line body per group size (compile-time shifts, exact
                         // number of DPP steps, no inner branches)
                         auto fast = [&](auto LGc) {
@@ -474,8 +495,9 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
                             const uint32_t ti = lane >> LG, j = lane & ((1u << LG) - 1);
                             const bool tv = ti < T;
                             const uint32_t tt = t0 + (tv ? ti : 0);
-                            const int32_t cost = (int32_t)nCost[tt];  // finalisation operands ride in the same round trip
-                            const uint32_t sl = nSlot[tt];
+                            const uint32_t cs = nCS[tt];  // finalisation operands ride in the same round trip
+                            const int32_t cost = (int32_t)(int16_t)cs;
+                            const uint32_t sl = cs >> 16;
                             uint64_t key = ~0ull;
                             if (tv && j < P) {
                                 const uint2 e = bk[p0 + j];
@@ -490,7 +512,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
                                 const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + cost;
                                 const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
                                 pre[tt] = (uint16_t)(ok ? ((uint32_t)key & 0xFFFFu) : NONE16);
-                                if (sl != NONE16) bk[sl].x = (uint32_t)(ok ? tot : INF);
+                                bk[sl].x = (uint32_t)(ok ? tot : INF);
                             }
                         };
                         switch (lg) {
@@ -500,11 +522,12 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
                             case 3: fast(std::integral_constant<uint32_t, 3>{}); break;
                             default: fast(std::integral_constant<uint32_t, 4>{}); break;
                         }
-                    } else if (P == 0) {  // nothing ends here: every target stays at INF with no predecessor
+                    } else if ((T = (uint32_t)__builtin_amdgcn_readlane((int)dT, (int)r),
+                                P = (uint32_t)__builtin_amdgcn_readlane((int)dP, (int)r)) == 0) {
+                        // nothing ends here: every target stays at INF with no predecessor
                         for (uint32_t t = t0 + lane; t < t0 + T; t += 64) {
                             pre[t] = NONE16;
-                            const uint32_t sl = nSlot[t];
-                            if (sl != NONE16) bk[sl].x = (uint32_t)INF;
+                            bk[nCS[t] >> 16].x = (uint32_t)INF;
                         }
                     } else if (T) {  // any shape: loop over target groups and predecessor chunks
                         lg = P > 1 ? 32 - __clz(P - 1) : 0;
@@ -513,8 +536,9 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
                         for (uint32_t tbase = 0; tbase < T; tbase += TG) {
                             const uint32_t ti = tbase + tl;
                             const bool tvalid = ti < T;
-                            const int32_t cost = tvalid ? (int32_t)nCost[t0 + ti] : 0;
-                            const uint32_t sl = tvalid ? (uint32_t)nSlot[t0 + ti] : NONE16;
+                            const uint32_t cs = tvalid ? nCS[t0 + ti] : 0u;
+                            const int32_t cost = (int32_t)(int16_t)cs;
+                            const uint32_t sl = cs >> 16;
                             uint64_t key = ~0ull;
                             for (uint32_t jc = 0; jc < P; jc += 64) {
                                 const uint32_t jj = jc + j;
@@ -531,7 +555,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
                                 const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + cost;
                                 const bool ok = tot < INF;
                                 pre[t0 + ti] = (uint16_t)(ok ? ((uint32_t)key & 0xFFFFu) : NONE16);
-                                if (sl != NONE16) bk[sl].x = (uint32_t)(ok ? tot : INF);
+                                bk[sl].x = (uint32_t)(ok ? tot : INF);
                             }
                         }
                     }
@@ -573,7 +597,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
             }
         }
         if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; }
-        if (a.count_work) {
+        if constexpr (PROF) {
             wT = wave_sum(wT);
             const uint64_t t7 = __builtin_amdgcn_s_memtime();
             accW[0] += 1; accW[1] += B; accW[2] += C; accW[3] += wT; accW[4] += N - 1; accW[5] += E; accW[6] += K;
@@ -585,7 +609,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         }  // attempt
         if (pg != NONE) pool_free(bm, pg, 0, npg, lane);
     }
-    if (a.count_work && lane == 0) {
+    if (PROF && lane == 0) {
         for (int k = 0; k < 7; ++k) atomicAdd(&a.ctl->work[k], (unsigned long long)accW[k]);
         for (int k = 0; k < 9; ++k) atomicAdd(&a.ctl->phase[k], (unsigned long long)accP[k]);
     }
@@ -595,9 +619,9 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
 // granularity makes this smaller than 160 KB / pool_bytes would suggest for odd sizes).
 int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves) {
     if (pool_bytes > 64 * 1024)
-        if (hipFuncSetAttribute((const void *)k_tokenize_pool, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)k_tokenize_pool<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes) != hipSuccess) return 0;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_pool, (int)(64 * waves), (size_t)pool_bytes) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_pool<false>, (int)(64 * waves), (size_t)pool_bytes) != hipSuccess) return 0;
     return n;
 }
 
@@ -605,10 +629,18 @@ int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const TierIO &io
                          int n_workgroups, void *stream) {
     static const uint32_t stop_after = getenv("KGPU_DEBUG_STOP") ? (uint32_t)atoi(getenv("KGPU_DEBUG_STOP")) : 0u;
     if (pool_bytes > 64 * 1024) {  // beyond the default dynamic-LDS cap the kernel has to opt in
-        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k_tokenize_pool, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, d, a, io, pool_bytes, stop_after);
+    if (a.count_work) {
+        if (pool_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(k_tokenize_pool<true>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, d, a, io, pool_bytes, stop_after);
+    } else {
+        hipLaunchKernelGGL(k_tokenize_pool<false>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, d, a, io, pool_bytes, stop_after);
+    }
     return (int)hipGetLastError();
 }
 

@@ -270,38 +270,20 @@ def test_device_api_and_work_counters(full):
     assert p["launches"] == 1 and p["tokenize_ms"] > 0
 
 
-@pytest.mark.parametrize("pack,tiers", [("0", "0"), ("0", "8"), ("0", "4,24"), ("0", "20,160"), ("0", "160"),
-                                        ("40,4", "20,160"), ("8,4", "8,160"), ("24,2", "0"), ("16,1", "160"), ("160,4", "0")])
-def test_every_memory_tier_is_bit_exact(libs, pack, tiers, monkeypatch):
-    """Force sentences through each tier chain: packed kernel (KiB, sentences per pack; '0' = off),
-    per-sentence LDS tiers (KiB; '0' = none), HBM-scratch kernel last."""
-    from kanpyo_amd import Tokenizer, synth
-
-    _, oracle = libs
-    monkeypatch.setenv("KGPU_PACK", pack)
-    monkeypatch.setenv("KGPU_TIERS", tiers)
-    sd = synth.build_dict(20000, seed=11)
-    tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
-    sents = synth.make_corpus(sd, 1500, 3, "cfg2") + synth.make_corpus(sd, 300, 4, "cfg3") + synth.make_corpus(sd, 2, 6, "cfg5") + ["", "あ", "ア" * 1500]
-    assert_same(tok, orc, sents)
-    assert_same(tok, orc, ["", "", "", "あ", "", "すもも", ""])  # packs made of empties / ragged tail
-
-
-@pytest.mark.parametrize("pool,tiers", [("80:10", "0"), ("80:8,160:4", "0"), ("16:4", "160"), ("8:2", "0"), ("160:16", "0"),
-                                        ("40:16", "20"), ("24:1", "0")])
-def test_lds_page_pool_is_bit_exact(libs, pool, tiers, monkeypatch):
-    """The pool kernel (KiB of LDS per workgroup : independent wavefronts sharing it) under pressure:
-    more wavefronts than the pool can serve at once, pools too small for the long sentences,
-    reservations that prove too small (redo), all followed by the fixed tiers / HBM-scratch kernel."""
+@pytest.mark.parametrize("pool", ["0", "80:10", "80:8,160:4", "16:4", "8:2,160:2", "160:16", "40:16,24:1", "24:1"])
+def test_every_launch_chain_is_bit_exact(libs, pool, monkeypatch):
+    """Force sentences through every launch chain.  KGPU_POOL = KiB of LDS per workgroup : independent
+    wavefronts sharing it ('0' = HBM-scratch kernel only), under pressure: more wavefronts than the pool
+    can serve at once, pools too small for the long sentences, reservations that prove too small (redo);
+    whatever fits no pool ends in the HBM-scratch kernel."""
     from kanpyo_amd import Tokenizer, synth
 
     _, oracle = libs
     monkeypatch.setenv("KGPU_POOL", pool)
-    monkeypatch.setenv("KGPU_TIERS", tiers)
     sd = synth.build_dict(20000, seed=11)
     tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
     sents = synth.make_corpus(sd, 3000, 3, "cfg2") + synth.make_corpus(sd, 300, 4, "cfg3") + synth.make_corpus(sd, 2, 6, "cfg5") + ["", "あ", "ア" * 1500]
-    for _ in range(3):  # the reservation estimate adapts between calls
+    for _ in range(3):  # the reservation estimate and the second-pool heuristic adapt between calls
         assert_same(tok, orc, sents)
     assert_same(tok, orc, ["", "", "", "あ", "", "すもも", ""])
 

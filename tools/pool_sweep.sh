@@ -1,7 +1,10 @@
 #!/bin/bash
-export KGPU_TIERS=0
-for cfg in "8 5" "8 6" "8 7" "16 8" "16 12" "2 1" "2 2" "3 2" "3 3" "6 5"; do
-  set -- $cfg
-  echo "== hwq $1 Q $2"
-  GPU_MAX_HW_QUEUES=$1 KGPU_POOL="80:8" BENCH_Q=$2 timeout 120 python tools/bench_cfg.py cfg2 98304 4096 2>&1 | tail -1
+# Throughput of cfg2 under different LDS pool shapes ("KiB:wavefronts[,KiB:wavefronts]") and numbers of
+# batches in flight.  usage (GPU box): bash tools/pool_sweep.sh
+for p in "80:8" "160:16" "40:4" "80:8,160:4"; do
+  for q in 2 3 4; do
+    echo "== pool $p, $q batches in flight"
+    KGPU_POOL="$p" BENCH_Q=$q timeout 120 python tools/bench_cfg.py cfg2 98304 4096 2>&1 | tail -1
+  done
+  KGPU_POOL="$p" BENCH_Q=2 timeout 120 python tools/bench_cfg.py cfg2 131072 65536 2>&1 | tail -1
 done
