@@ -225,11 +225,17 @@ def main():
         "work_per_sentence": {k: work[k] / work["sentences"] for k in ("B", "C", "T", "N", "E", "K")},
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": "k_tokenize (fused lattice build + Viterbi + backtrace)",
+            "traffic": traffic, "kernel": "k_tokenize_pool (fused lattice build + Viterbi + backtrace, LDS page pool)",
             "algorithmic_bytes_per_launch": per_launch_bytes,
             "stage_bytes_per_launch": {"A_lattice": a / nb, "B_viterbi": b / nb, "C_emit": c_ / nb},
             "avg_kernel_ms": avg_kernel_s * 1e3, "launches_timed": prof["launches"],
             "aux_kernels_avg_ms": prof["aux_ms"] / max(prof["launches"], 1),
+            # `achieved` divides by the duration of ONE launch while `batches_in_flight` launches share the
+            # chip (each therefore lasts ~that many times longer than its share of the work); the same
+            # algorithmic bytes at the measured whole-job rate:
+            "launches_in_flight": Q,
+            "achieved_at_job_rate": per_launch_bytes * (sentences / world / BATCH) / elapsed / 1e9,
+            "frac_at_job_rate": per_launch_bytes * (sentences / world / BATCH) / elapsed / 1e9 / HBM_PEAK_GBS,
         },
     }
 

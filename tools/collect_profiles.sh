@@ -11,5 +11,6 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace"
 cp $(find "$OUT/trace" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv"
 bash "$REPO/tools/pmc_passes.sh" "$OUT/pmc" > "$OUT/pmc.log" 2>&1
 python "$REPO/tools/pmc_summary.py" "$OUT/pmc" --json "$OUT/pmc_summary.json" > "$OUT/pmc_summary.txt"
+python "$REPO/tools/make_traffic_json.py" "$OUT/pmc_summary.json" "$OUT/pmc_traffic.json" > /dev/null
 rm -rf "$OUT/trace" "$OUT/pmc"/pass*/
 echo done

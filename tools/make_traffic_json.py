@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""profiles/pmc_traffic.json from a pmc_summary.json (tools/pmc_summary.py --json): HBM bytes per
+batch of the tokenize kernels, FETCH_SIZE corrected as MI355X_MICROARCH.md's HBM section prescribes.
+usage: python tools/make_traffic_json.py <pmc_summary.json> <out.json>"""
+import json
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+d = json.load(open(src))
+# the plain instantiation only: the <true> one (device-side work counters) runs outside the timed region
+kernels = [k for k in d if "k_tokenize" in k and "<true>" not in k]
+main = [k for k in kernels if "k_tokenize_pool" in k][0]
+batches = d[main]["FETCH_SIZE"]["dispatches"]  # the first pool launch of every plain batch
+fetch = write = 0.0
+for k in kernels:
+    scale = 1.0 if k == main else batches / max(d[k]["FETCH_SIZE"]["dispatches"], 1)  # general kernel: per-dispatch average
+    fetch += d[k]["FETCH_SIZE"]["sum"] * scale
+    write += d[k]["WRITE_SIZE"]["sum"] * scale
+fetch_kb, write_kb = fetch / batches, write / batches
+out = {
+    "source": f"profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+              "`python bench.py --steps 24 --warmup 2 --queue 1 --no-cpu`, tools/pmc_passes.sh)",
+    "per": "one batch of 4096 sentences = the k_tokenize_pool launch(es) + the k_tokenize_general launch: " + ", ".join(kernels),
+    "batches": batches,
+    "fetch_size_kb": fetch_kb,
+    "write_size_kb": write_kb,
+    "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE counts 64 B per 128 B request on gfx950 -> x2 (calibrated "
+                  "for wide coalesced reads; this kernel issues narrow gathers, so x2 is an upper bound); WRITE_SIZE "
+                  "uncalibrated, taken as is; unit KB = 1024 B",
+    "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024,
+    "hbm_bytes_per_launch_uncorrected": (fetch_kb + write_kb) * 1024,
+}
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps(out, indent=1))
