@@ -502,6 +502,11 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
         // too small costs a redo (late_count), one that is too large only idles pages until the
         // lattice is known -- steer for a redo rate of 1-3 %.  Applied to the value the batch ran with; races between
         // contexts only lose an adjustment.
+        static const bool debug_print = getenv("KGPU_DEBUG_PRINT") != nullptr;
+        if (debug_print)
+            fprintf(stderr, "[kgpu] n=%llu pools=%d est=%.1f B/B deferred={%u,%u,%u} redone={%u,%u}\n", (unsigned long long)c->last.n,
+                    c->last_pools, c->last.est_q8 / 256.0, c->h_ctl->ovf_count[0], c->h_ctl->ovf_count[1], c->h_ctl->ovf_count[2],
+                    c->h_ctl->late_count[0], c->h_ctl->late_count[1]);
         if (c->plan.n_pools > 1) {
             if (c->h_ctl->ovf_count[0] > 0) c->dict->big_pool_batches.store(64, std::memory_order_relaxed);
             else if (c->last_pools > 1) c->dict->big_pool_batches.fetch_sub(1, std::memory_order_relaxed);

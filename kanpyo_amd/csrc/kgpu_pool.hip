@@ -43,6 +43,7 @@ namespace {
 
 constexpr uint32_t MAXM = 8;         // trie matches buffered per start position
 constexpr uint32_t NONE16 = 0xFFFFu;
+constexpr uint32_t PAIR_CAP = 16 * 1024;  // bytes of pair table a sentence may hold beyond its largest position
 
 // ---- DPP butterfly: min over aligned groups of 2^lg lanes, every lane gets it.
 // The key is one u64 (total ^ signbit) << 32 | predecessor node index, so one
@@ -53,6 +54,26 @@ __device__ __forceinline__ uint64_t dpp_min_step(uint64_t k) {
     const uint32_t ol = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, CTRL, 0xF, 0xF, true);
     const uint64_t o = ((uint64_t)oh << 32) | ol;
     return o < k ? o : k;
+}
+// 32-bit group minima for the straight-line sweep shapes: one DPP-fused v_min per step.  (Exec is
+// full wherever these run -- wave-uniform control flow -- so bound_ctrl never substitutes a zero.)
+template <int CTRL>
+__device__ __forceinline__ int32_t dpp_i32(int32_t x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+template <uint32_t LG>
+__device__ __forceinline__ int32_t group_min_i32(int32_t v) {
+    if constexpr (LG >= 1) v = min(v, dpp_i32<0xB1>(v));
+    if constexpr (LG >= 2) v = min(v, dpp_i32<0x4E>(v));
+    if constexpr (LG >= 3) v = min(v, dpp_i32<0x141>(v));
+    if constexpr (LG >= 4) v = min(v, dpp_i32<0x140>(v));
+    return v;
+}
+template <uint32_t LG>
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t v) {
+    if constexpr (LG >= 1) v = min(v, (uint32_t)dpp_i32<0xB1>((int32_t)v));
+    if constexpr (LG >= 2) v = min(v, (uint32_t)dpp_i32<0x4E>((int32_t)v));
+    if constexpr (LG >= 3) v = min(v, (uint32_t)dpp_i32<0x141>((int32_t)v));
+    if constexpr (LG >= 4) v = min(v, (uint32_t)dpp_i32<0x140>((int32_t)v));
+    return v;
 }
 __device__ __forceinline__ uint64_t shfl_min_step(uint64_t k, int d) {
     const uint32_t oh = (uint32_t)__shfl_xor((int)(uint32_t)(k >> 32), d, 64);
@@ -357,7 +378,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         if (N > 0xFFFF) { tier_defer(io, lane, s); break; }
         // exact requirement: emit-written arrays stay below the match buffer; afterwards pre + the
         // pair table (whole, so that the sweep is one block) overlay it
-        const uint32_t need_emit = off_emit_end + mbytes + 16, need_full = off + 2 * E;
+        const uint32_t need_emit = off_emit_end + mbytes + 16, need_full = off + min(2 * E, max(2 * maxpairs, PAIR_CAP));
         if (need_emit > lds_bytes || off + 2 * maxpairs > lds_bytes) {
             // reservation too small: release, wait (holding nothing) for the exact size, redo
             pool_free(bm, pg, 0, npg, lane);
@@ -498,20 +519,19 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
                             const uint32_t cs = nCS[tt];  // finalisation operands ride in the same round trip
                             const int32_t cost = (int32_t)(int16_t)cs;
                             const uint32_t sl = cs >> 16;
-                            uint64_t key = ~0ull;
+                            int32_t v = 0x7FFFFFFF;  // a real total is at most INF + 32767
+                            uint32_t nd = 0xFFFFFFFFu;
                             if (tv && j < P) {
                                 const uint2 e = bk[p0 + j];
-                                const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + ti * P + j];
-                                key = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (e.y >> 16);
+                                v = (int32_t)e.x + (int32_t)mpair[eb + ti * P + j];
+                                nd = e.y >> 16;
                             }
-                            if constexpr (LG >= 1) key = dpp_min_step<0xB1>(key);
-                            if constexpr (LG >= 2) key = dpp_min_step<0x4E>(key);
-                            if constexpr (LG >= 3) key = dpp_min_step<0x141>(key);
-                            if constexpr (LG >= 4) key = dpp_min_step<0x140>(key);
+                            const int32_t vmin = group_min_i32<LG>(v);
+                            const uint32_t nmin = group_min_u32<LG>(v == vmin ? nd : 0xFFFFFFFFu);
                             if (tv && j == 0) {
-                                const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + cost;
+                                const int32_t tot = vmin + cost;
                                 const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
-                                pre[tt] = (uint16_t)(ok ? ((uint32_t)key & 0xFFFFu) : NONE16);
+                                pre[tt] = (uint16_t)(ok ? nmin : NONE16);
                                 bk[sl].x = (uint32_t)(ok ? tot : INF);
                             }
                         };
