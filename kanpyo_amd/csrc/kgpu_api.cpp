@@ -88,6 +88,9 @@ struct kgpu_dict {
     // recent batches actually overflowed the first pool (otherwise those rare sentences take the
     // HBM-scratch kernel).  Performance heuristic only: the chain is complete either way.
     std::atomic<int> big_pool_batches{0};
+    // Same for the long-sentence kernel (its workgroups hold 32 KB of LDS each): issued while recent
+    // batches still had sentences left after the pools.
+    std::atomic<int> long_batches{0};
 };
 
 struct kgpu_ctx {
@@ -100,6 +103,7 @@ struct kgpu_ctx {
     bool ctl_dirty = true;     // d_ctl must be zeroed by the host (first launch, or after a failed enqueue)
     uint32_t launch_seq = 0;
     int last_pools = 0;        // pool launches issued for the pending batch
+    bool last_long = false;    // ... and whether the long-sentence kernel was
     uint32_t event_every = 1;  // KGPU_PROFILE_SAMPLED: HIP events on every 4th launch only
     DevBuf arena, stage, tok_count;
     // host-buffer path staging
@@ -433,7 +437,8 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
     if (a.n) {
         const int pools_now = c->dict->big_pool_batches.load(std::memory_order_relaxed) > 0 ? c->plan.n_pools : std::min(c->plan.n_pools, 1);
         c->last_pools = pools_now;
-        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->stream);
+        c->last_long = c->plan.long_lds_bytes && (c->plan.n_pools == 0 || c->dict->long_batches.load(std::memory_order_relaxed) > 0);
+        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->last_long, c->stream);
         if (e != hipSuccess) { set_error("k_tokenize launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     }
     if (timed) HIPCHECK(hipEventRecord(e1, c->stream));
@@ -507,6 +512,10 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
             fprintf(stderr, "[kgpu] n=%llu pools=%d est=%.1f B/B deferred={%u,%u,%u} redone={%u,%u}\n", (unsigned long long)c->last.n,
                     c->last_pools, c->last.est_q8 / 256.0, c->h_ctl->ovf_count[0], c->h_ctl->ovf_count[1], c->h_ctl->ovf_count[2],
                     c->h_ctl->late_count[0], c->h_ctl->late_count[1]);
+        if (c->last_pools > 0 && c->plan.long_lds_bytes) {  // sentences that no pool could take
+            if (c->h_ctl->ovf_count[c->last_pools - 1] > 0) c->dict->long_batches.store(64, std::memory_order_relaxed);
+            else if (c->last_long) c->dict->long_batches.fetch_sub(1, std::memory_order_relaxed);
+        }
         if (c->plan.n_pools > 1) {
             if (c->h_ctl->ovf_count[0] > 0) c->dict->big_pool_batches.store(64, std::memory_order_relaxed);
             else if (c->last_pools > 1) c->dict->big_pool_batches.fetch_sub(1, std::memory_order_relaxed);

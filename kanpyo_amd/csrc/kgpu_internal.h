@@ -77,14 +77,17 @@ struct TierPlan {
     int n_pools;
     uint32_t pool_bytes[2];
     uint32_t pool_waves[2];
+    uint32_t pool_max_pages[2];  // of 64: larger reservations are routed to the next launch
     int pool_workgroups[2];   // persistent grid per pool launch
     int general_workgroups;
+    uint32_t long_lds_bytes;  // 0: no long-sentence kernel (general kernel with an LDS-blocked sweep)
+    int long_workgroups;
 };
 
 // Launchers (kgpu_kernels.hip).  `stream` is a hipStream_t.
 // n_pools_now <= plan.n_pools: how many of the pool launches to issue for this batch (the chain
 // stays complete without the later ones: their work falls through to the next launch).
-int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan, int n_pools_now, void *stream);
+int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan, int n_pools_now, bool long_now, void *stream);
 int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream);  // host_ctl: device pointer of the pinned result block
 TierPlan default_tier_plan(int device);
 

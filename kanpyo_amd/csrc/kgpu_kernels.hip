@@ -20,6 +20,13 @@
 //
 // This file holds the GENERAL kernel: every per-sentence array lives in a
 // bump-allocated HBM scratch slab, so any sentence length / lattice size works.
+// Two instantiations.  LDS_SWEEP = false: no LDS at all, every step of the Viterbi
+// chain is a global-memory round trip (the always-launched last resort; its
+// workgroups can start on a CU whose LDS is fully taken).  LDS_SWEEP = true: the
+// lattice is still built in HBM, but the sweep runs over blocks of up to 64
+// positions staged in LDS (bucket entries, word costs, gathered connection costs):
+// one global round trip per block instead of three per position, and a blocked
+// backtrace -- the long-document path (BASELINE cfg 5: 2048-char sentences).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -32,7 +39,40 @@ namespace kgpu {
 
 using namespace dev;
 
-__global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a, TierIO io) {
+namespace {
+
+// ---- 32/64-bit group minima over aligned groups of 2^lg lanes (lg wave-uniform, exec full) ----
+template <int CTRL>
+__device__ __forceinline__ int32_t g_dpp(int32_t x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ int32_t gmin_i32(int32_t v, uint32_t lg) {
+    if (lg >= 1) v = min(v, g_dpp<0xB1>(v));   // quad_perm [1,0,3,2]
+    if (lg >= 2) v = min(v, g_dpp<0x4E>(v));   // quad_perm [2,3,0,1]
+    if (lg >= 3) v = min(v, g_dpp<0x141>(v));  // row_half_mirror
+    if (lg >= 4) v = min(v, g_dpp<0x140>(v));  // row_mirror
+    if (lg >= 5) v = min(v, __shfl_xor(v, 16, 64));
+    if (lg >= 6) v = min(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t gmin_u32(uint32_t v, uint32_t lg) {
+    if (lg >= 1) v = min(v, (uint32_t)g_dpp<0xB1>((int32_t)v));
+    if (lg >= 2) v = min(v, (uint32_t)g_dpp<0x4E>((int32_t)v));
+    if (lg >= 3) v = min(v, (uint32_t)g_dpp<0x141>((int32_t)v));
+    if (lg >= 4) v = min(v, (uint32_t)g_dpp<0x140>((int32_t)v));
+    if (lg >= 5) v = min(v, (uint32_t)__shfl_xor((int32_t)v, 16, 64));
+    if (lg >= 6) v = min(v, (uint32_t)__shfl_xor((int32_t)v, 32, 64));
+    return v;
+}
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace
+
+template <bool LDS_SWEEP>
+__global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a, TierIO io, uint32_t lds_bytes,
+                                                          uint32_t stop_after /* ablation timing only */) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x;
     Slab sa{nullptr, 0}, sn{nullptr, 0};
     const int32_t base_root = d.da[1].base;
@@ -96,7 +136,15 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             continue;
         }
         if (lane == 0) cbyte[C] = B;
-        for (uint32_t e = lane; e < C + 3; e += 64) { boff[e] = 0; bfill[e] = 0; }
+        // Per-end-position counters / fill cursors: in LDS when the sentence's C + 3 words fit (LDS atomics
+        // instead of one global round trip per node), else in the HBM slab.
+        uint32_t *cnt_e = boff, *fill_e = bfill;
+        bool lds_cursors = false;
+        if constexpr (LDS_SWEEP) {
+            lds_cursors = (uint64_t)(C + 3) * 4 <= lds_bytes;
+            if (lds_cursors) { cnt_e = (uint32_t *)lds; fill_e = (uint32_t *)lds; }
+        }
+        for (uint32_t e = lane; e < C + 3; e += 64) { cnt_e[e] = 0; if (!lds_cursors) bfill[e] = 0; }
         __syncthreads();
 
         // ---- phase 1: count ----------------------------------------------------
@@ -117,7 +165,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                 wT += da_walk(d, text, cbyte[i], B, base_root, [&](uint32_t id, uint32_t nch) {
                     uint32_t nrec = 1u + d.morph[id - 1].dup;  // index.rs:46-51
                     cnt += nrec;
-                    atomicAdd(&boff[i + nch], nrec);
+                    atomicAdd(&cnt_e[i + nch], nrec);
                 });
                 const CatInfo ci = d.cinfo[cat];
                 uint32_t span = 0;
@@ -129,7 +177,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                         span = r < MAX_UNKNOWN_LEN ? r : MAX_UNKNOWN_LEN;
                     }
                     cnt += ci.unk_count;
-                    atomicAdd(&boff[i + span], ci.unk_count);
+                    atomicAdd(&cnt_e[i + span], ci.unk_count);
                 }
                 uspan[i] = span;
                 nb[i] = cnt;
@@ -138,18 +186,20 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         if (lane == 0) {
             nb[C] = 1;      // EOS starts at C (lattice.rs:165-175)
             nb[C + 1] = 0;
-            atomicAdd(&boff[0], 1u);  // BOS ends at 0 (lattice.rs:156-164)
+            atomicAdd(&cnt_e[0], 1u);  // BOS ends at 0 (lattice.rs:156-164)
         }
         __syncthreads();
 
+#define KGPU_GSTOP(k) if (stop_after == (k)) { if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = 0; } continue; }
+        KGPU_GSTOP(3)
         // ---- phase 2: prefix sums ------------------------------------------------
         uint32_t ncarry = 1, bcarry = 0;  // node 0 is BOS
         for (uint32_t i0 = 0; i0 < C + 2; i0 += 64) {
             const uint32_t i = i0 + lane;
             const uint32_t v = i < C + 2 ? nb[i] : 0;
-            const uint32_t w = i < C + 2 ? ld_l2(&boff[i]) : 0;  // updated by L2 atomics
+            const uint32_t w = i < C + 2 ? (lds_cursors ? cnt_e[i] : ld_l2(&boff[i])) : 0;  // updated by LDS / L2 atomics
             const uint32_t vs = wave_incl_scan(v, lane), ws = wave_incl_scan(w, lane);
-            if (i < C + 2) { nb[i] = ncarry + vs - v; boff[i] = bcarry + ws - w; }
+            if (i < C + 2) { nb[i] = ncarry + vs - v; boff[i] = bcarry + ws - w; if (lds_cursors) cnt_e[i] = 0; /* becomes the fill cursor */ }
             ncarry += __shfl(vs, 63, 64);
             bcarry += __shfl(ws, 63, 64);
         }
@@ -174,10 +224,11 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                 const uint32_t nrec = 1u + d.morph[id - 1].dup;
                 for (uint32_t r = 0; r < nrec; ++r) {  // lattice.rs:177-188
                     const Morph8 m = d.morph[id - 1 + r];
-                    const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
+                    const uint32_t slot = boff[end] + atomicAdd(&fill_e[end], 1u);
                     nodeA[t] = make_uint4((uint16_t)m.left | ((uint32_t)(uint16_t)m.right << 16),
                                           (uint32_t)(int32_t)m.cost, slot, id + r);
                     nodeB[t] = make_uint2(i, end);
+                    bucket[slot] = make_uint4((uint32_t)INF, (uint16_t)m.right, t, 0);  // dp is filled in by the sweep
                     ++t;
                 }
             });
@@ -187,11 +238,12 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                 const uint32_t end = i + span;
                 for (uint32_t r = 0; r < ci.unk_count; ++r) {
                     const Morph8 m = d.unk_morph[ci.unk_first - 1 + (int32_t)r];
-                    const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
+                    const uint32_t slot = boff[end] + atomicAdd(&fill_e[end], 1u);
                     nodeA[t] = make_uint4((uint16_t)m.left | ((uint32_t)(uint16_t)m.right << 16),
                                           (uint32_t)(int32_t)m.cost, slot,
                                           (uint32_t)(-(ci.unk_first + (int32_t)r)));
                     nodeB[t] = make_uint2(i, end);
+                    bucket[slot] = make_uint4((uint32_t)INF, (uint16_t)m.right, t, 0);
                     ++t;
                 }
             }
@@ -204,12 +256,38 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         }
         __syncthreads();
 
+        KGPU_GSTOP(5)
         // ---- phase 4: Viterbi sweep ---------------------------------------------------
-        uint32_t t0 = nb[0], p0 = boff[0];
-        for (uint32_t q = 0; q <= C; ++q) {
-            const uint32_t t1 = nb[q + 1], p1 = boff[q + 1];
-            const uint32_t P = p1 - p0;
+        // one position through global memory (lattice.rs:116-142): lanes take targets, every lane
+        // walks the whole predecessor bucket
+        auto global_step = [&](uint32_t q) {
+            const uint32_t t0 = nb[q], t1 = nb[q + 1], p0 = boff[q], P = boff[q + 1] - p0;
             wE += (lane == 0) ? P * (t1 - t0) : 0;
+            if (P >= 48) {
+                // wide bucket (e.g. every unknown word of a 1024-char run ends at the same position): the lanes
+                // share one target at a time and split its predecessors -- coalesced bucket reads, P/64 steps
+                for (uint32_t t = t0; t < t1; ++t) {
+                    const uint4 na_ = nodeA[t];
+                    const int16_t *col = d.conn + (size_t)d.conn_rows * (na_.x & 0xFFFFu);
+                    int32_t best = 0x7FFFFFFF;
+                    uint32_t bidx = NONE;
+                    for (uint32_t j = lane; j < P; j += 64) {
+                        const uint4 e = bucket[p0 + j];
+                        const int32_t v = (int32_t)e.x + (int32_t)col[e.y];
+                        if (v < best || (v == best && e.z < bidx)) { best = v; bidx = e.z; }
+                    }
+                    const int32_t vmin = gmin_i32(best, 6);
+                    const uint32_t nmin = gmin_u32(best == vmin ? bidx : NONE, 6);
+                    if (lane == 0) {
+                        const int32_t tot = vmin + (int32_t)na_.y;  // min(.., INF) then strict '<' INF
+                        const bool ok = tot < INF;
+                        pre[t] = ok ? nmin : NONE;
+                        if (na_.z != NONE) bucket[na_.z].x = (uint32_t)(ok ? tot : INF);
+                    }
+                }
+                __syncthreads();
+                return;
+            }
             for (uint32_t t = t0 + lane; t < t1; t += 64) {
                 const uint4 na_ = nodeA[t];
                 const int16_t *col = d.conn + (size_t)d.conn_rows * (na_.x & 0xFFFFu);
@@ -227,18 +305,166 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                     if (tot < INF) { dpv = tot; prv = bidx; }
                 }
                 pre[t] = prv;
-                if (na_.z != NONE) bucket[na_.z] = make_uint4((uint32_t)dpv, na_.x >> 16, t, 0);
+                if (na_.z != NONE) bucket[na_.z].x = (uint32_t)dpv;
             }
-            t0 = t1;
-            p0 = p1;
             __syncthreads();
+        };
+        if constexpr (!LDS_SWEEP) {
+            for (uint32_t q = 0; q <= C; ++q) global_step(q);
+        } else {
+            // Blocks of up to 64 consecutive positions whose bucket entries, targets and (target,
+            // predecessor) pairs fit the LDS budget.  Per block: one round of coalesced loads, one
+            // parallel gather of the connection costs, then the serial chain at LDS latency.
+            uint32_t *posT0 = (uint32_t *)lds, *posP0 = posT0 + 64, *posP = posP0 + 64, *posEb = posP + 64;
+            const uint32_t cap = lds_bytes - 1024;
+            for (uint32_t qa = 0; qa <= C;) {
+                const uint32_t ql = qa + lane;
+                const bool in = ql <= C;
+                const uint32_t t0g = in ? nb[ql] : 0, t1g = in ? nb[ql + 1] : 0;
+                const uint32_t p0g = in ? boff[ql] : 0, p1g = in ? boff[ql + 1] : 0;
+                const uint32_t T = t1g - t0g, P = p1g - p0g;
+                const uint64_t pairs64 = (uint64_t)T * P;
+                const uint32_t pairs = pairs64 > 0xFFFFFFu ? 0xFFFFFFu : (uint32_t)pairs64;
+                // LDS per position: bucket entries {dp, node, right} 10 B, targets {cost|slot, dp, pre} 12 B, pairs 2 B
+                const uint32_t need = 10 * P + 12 * T + 2 * pairs + 8;
+                const uint32_t cneed = wave_incl_scan(min(need, 0x1000000u), lane);
+                const uint32_t cP = wave_incl_scan(min(P, 0x100000u), lane), cT = wave_incl_scan(min(T, 0x100000u), lane);
+                const uint32_t cE = wave_incl_scan(pairs, lane);
+                const bool fit = in && cneed <= cap && cP < 0xFFFFu && cT < 0xFFFFu && cE < 0x1FFFFu;
+                const uint32_t nq = (uint32_t)__popcll(__ballot(fit));  // a prefix of the lanes: every sum is monotone
+                if (nq == 0) { global_step(qa); ++qa; continue; }       // one position too large for the budget
+                const uint32_t tA = bcast32(t0g), pA = bcast32(p0g);
+                const uint32_t nt = (uint32_t)__shfl((int)cT, (int)nq - 1, 64), nbk = (uint32_t)__shfl((int)cP, (int)nq - 1, 64);
+                const uint32_t np = (uint32_t)__shfl((int)cE, (int)nq - 1, 64);
+                wE += (lane < nq) ? pairs : 0;  // summed over lanes at the end
+                uint32_t off = 1024;
+                uint32_t *dpL = (uint32_t *)(lds + off);  off += 4 * nbk;   // dp of the bucket entries ending in the block
+                uint32_t *ndL = (uint32_t *)(lds + off);  off += 4 * nbk;   // their node index (tie-break, pre)
+                uint32_t *csL = (uint32_t *)(lds + off);  off += 4 * nt;    // targets: word cost | local bucket slot << 16 (0xFFFF: outside)
+                uint32_t *dpT = (uint32_t *)(lds + off);  off += 4 * nt;    // targets: dp (written back for the outside slots)
+                uint32_t *preL = (uint32_t *)(lds + off); off += 4 * nt;    // targets: best predecessor (written back after the block:
+                                                                            // no global store, hence no vmcnt wait, inside the chain)
+                int16_t *prL = (int16_t *)(lds + off);    off += 2 * np;    // connection cost of pair (t, j) at eb(q) + ti*P + j
+                uint16_t *rtL = (uint16_t *)(lds + off);                    // right id of the bucket entries (gather only)
+                if (lane < nq) { posT0[lane] = t0g - tA; posP0[lane] = p0g - pA; posP[lane] = P; posEb[lane] = cE - pairs; }
+                for (uint32_t i = lane; i < nbk; i += 64) {
+                    const uint4 e = bucket[pA + i];
+                    dpL[i] = e.x; ndL[i] = e.z; rtL[i] = (uint16_t)e.y;
+                }
+                wave_fence();
+                // targets + gather (lane = target, 4 gathers in flight)
+                for (uint32_t t = lane; t < nt; t += 64) {
+                    const uint4 na_ = nodeA[tA + t];
+                    const uint32_t z = na_.z;
+                    const uint32_t loc = (z != NONE && z >= pA && z - pA < nbk) ? z - pA : 0xFFFFu;
+                    csL[t] = (uint32_t)(uint16_t)(int16_t)(int32_t)na_.y | (loc << 16);
+                    const uint32_t q = nodeB[tA + t].x - qa;
+                    const uint32_t Pq = posP[q], p0 = posP0[q], base = posEb[q] + (t - posT0[q]) * Pq;
+                    const int16_t *col = d.conn + (size_t)d.conn_rows * (na_.x & 0xFFFFu);
+                    uint32_t j = 0;
+                    for (; j + 4 <= Pq; j += 4) {
+                        const int16_t c0 = col[rtL[p0 + j]], c1 = col[rtL[p0 + j + 1]], c2 = col[rtL[p0 + j + 2]], c3 = col[rtL[p0 + j + 3]];
+                        prL[base + j] = c0; prL[base + j + 1] = c1; prL[base + j + 2] = c2; prL[base + j + 3] = c3;
+                    }
+                    for (; j < Pq; ++j) prL[base + j] = col[rtL[p0 + j]];
+                }
+                wave_fence();
+                // the chain: position r of the block, pair (ti, j) on lane ti * 2^lg + j when it fits 64 lanes
+                for (uint32_t r = 0; r < nq; ++r) {
+                    const uint32_t Tq = (uint32_t)__builtin_amdgcn_readlane((int)T, (int)r);
+                    const uint32_t Pq = (uint32_t)__builtin_amdgcn_readlane((int)P, (int)r);
+                    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)(t0g - tA), (int)r);
+                    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)(p0g - pA), (int)r);
+                    const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)(cE - pairs), (int)r);
+                    if (Pq == 0) {  // nothing ends here: every target stays at INF with no predecessor
+                        for (uint32_t t = t0 + lane; t < t0 + Tq; t += 64) {
+                            preL[t] = NONE;
+                            dpT[t] = (uint32_t)INF;
+                            const uint32_t sl = csL[t] >> 16;
+                            if (sl != 0xFFFFu) dpL[sl] = (uint32_t)INF;
+                        }
+                    } else if (Tq) {
+                        uint32_t lg = Pq > 1 ? 32 - __clz(Pq - 1) : 0;  // lanes per target: 2^lg >= min(P, 64)
+                        if (lg > 6) lg = 6;
+                        const uint32_t j = lane & ((1u << lg) - 1), tl = lane >> lg, TG = 64u >> lg;
+                        for (uint32_t tbase = 0; tbase < Tq; tbase += TG) {
+                            const uint32_t ti = tbase + tl;
+                            const bool tv = ti < Tq;
+                            const uint32_t tt = t0 + (tv ? ti : 0);
+                            const uint32_t cs = csL[tt];
+                            // strict-'<' first minimum (lattice.rs:125-139): smallest total, then smallest node index
+                            int32_t best = 0x7FFFFFFF;
+                            uint32_t bnode = 0xFFFFFFFFu;
+                            for (uint32_t jc = 0; jc < Pq; jc += 64) {  // one pass unless P > 64
+                                const uint32_t jj = jc + j;
+                                int32_t v = 0x7FFFFFFF;
+                                uint32_t nd = 0xFFFFFFFFu;
+                                if (tv && jj < Pq) {
+                                    v = (int32_t)dpL[p0 + jj] + (int32_t)prL[eb + ti * Pq + jj];
+                                    nd = ndL[p0 + jj];
+                                }
+                                const int32_t vmin = gmin_i32(v, lg);
+                                const uint32_t nmin = gmin_u32(v == vmin ? nd : 0xFFFFFFFFu, lg);
+                                if (vmin < best || (vmin == best && nmin < bnode)) { best = vmin; bnode = nmin; }
+                            }
+                            if (tv && j == 0) {
+                                const int32_t tot = best + (int32_t)(int16_t)cs;
+                                const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
+                                const uint32_t dpn = (uint32_t)(ok ? tot : INF);
+                                preL[tt] = ok ? bnode : NONE;
+                                dpT[tt] = dpn;
+                                const uint32_t sl = cs >> 16;
+                                if (sl != 0xFFFFu) dpL[sl] = dpn;
+                            }
+                        }
+                    }
+                    wave_fence();
+                }
+                // dp of the nodes that end beyond the block goes back to their HBM bucket entries
+                for (uint32_t t = lane; t < nt; t += 64) {
+                    pre[tA + t] = preL[t];
+                    if ((csL[t] >> 16) == 0xFFFFu) {
+                        const uint32_t z = nodeA[tA + t].z;
+                        if (z != NONE) bucket[z].x = dpT[t];
+                    }
+                }
+                __syncthreads();  // single wavefront: a fence that also drains the global stores before the next block reads
+                qa += nq;
+            }
+            wE = wave_sum(wE);
         }
 
+        KGPU_GSTOP(7)
         // ---- phase 5: backtrace + tokens -----------------------------------------------
         uint32_t K = 0;
-        if (lane == 0) {
-            uint32_t pos = N - 1, pr;
-            while ((pr = pre[pos]) != NONE && K <= C) { path[K++] = pos; pos = pr; }  // K <= C + 1 always; bound the walk anyway
+        if constexpr (!LDS_SWEEP) {
+            if (lane == 0) {
+                uint32_t pos = N - 1, pr;
+                while ((pr = pre[pos]) != NONE && K <= C) { path[K++] = pos; pos = pr; }  // K <= C + 1 always; bound the walk anyway
+            }
+        } else {
+            // blocked: a predecessor always has a smaller node index, so the chase runs through windows of
+            // pre[] staged in LDS (one coalesced load per window instead of one global round trip per token)
+            uint32_t *win = (uint32_t *)lds;
+            const uint32_t Wn = lds_bytes / 4;
+            uint32_t pos = N - 1;
+            for (bool done = false; !done;) {
+                const uint32_t wlo = pos >= Wn - 1 ? pos - (Wn - 1) : 0;
+                for (uint32_t i = wlo + lane; i <= pos; i += 64) win[i - wlo] = pre[i];
+                wave_fence();
+                uint32_t npos = pos, nK = K, fin = 0;
+                if (lane == 0) {
+                    for (;;) {
+                        const uint32_t pr = win[npos - wlo];
+                        if (pr == NONE || nK > C) { fin = 1; break; }
+                        path[nK++] = npos;
+                        npos = pr;
+                        if (npos < wlo) break;
+                    }
+                }
+                pos = bcast32(npos); K = bcast32(nK); done = bcast32(fin) != 0;
+                wave_fence();
+            }
         }
         K = bcast32(K);
         // staging slot of the sentence: K <= C + 1 <= B + 1 tokens always fit at b0 + s
@@ -328,12 +554,12 @@ __global__ __launch_bounds__(256) void k_compact(BatchArgs a) {
 }
 
 int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t pool_bytes, uint32_t waves,
-                         int n_workgroups, void *stream);  // kgpu_pool.hip
+                         uint32_t max_pages, int n_workgroups, void *stream);  // kgpu_pool.hip
 int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
 
 // Launch chain: pool kernel(s), then the general (HBM scratch) kernel.  Every launch is a
 // persistent grid over its work list (the first one: the identity over [0, n)).
-int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan, int n_pools_now, void *stream) {
+int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan, int n_pools_now, bool long_now, void *stream) {
     Control *ctl = a.ctl;
     const uint32_t *in_list = nullptr;
     const unsigned int *in_count = nullptr;
@@ -343,16 +569,31 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan,
         uint64_t wg = plan.pool_workgroups[k];
         const uint64_t want = (a.n + plan.pool_waves[k] - 1) / plan.pool_waves[k];
         if (!in_list && want < wg) wg = want;
-        int e = launch_tokenize_pool(d, a, io, plan.pool_bytes[k], plan.pool_waves[k], (int)(wg ? wg : 1), stream);
+        int e = launch_tokenize_pool(d, a, io, plan.pool_bytes[k], plan.pool_waves[k], plan.pool_max_pages[k], (int)(wg ? wg : 1), stream);
         if (e) return e;
         in_list = a.ovf[li];
         in_count = &ctl->ovf_count[li];
     }
     if (getenv("KGPU_DEBUG_SKIP_GENERAL")) return 0;
+    static const uint32_t stop_after = getenv("KGPU_DEBUG_STOP") ? (uint32_t)atoi(getenv("KGPU_DEBUG_STOP")) : 0u;
+    if (long_now && plan.long_lds_bytes) {  // HBM lattice + LDS-blocked sweep; takes its whole list, leaves none
+        TierIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], nullptr};
+        uint64_t wg = plan.long_workgroups;
+        if (!in_list && a.n < wg) wg = a.n;
+        if (plan.long_lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_general<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.long_lds_bytes);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(k_tokenize_general<true>, dim3((unsigned)(wg ? wg : 1)), dim3(64), plan.long_lds_bytes, (hipStream_t)stream, d, a, io,
+                           plan.long_lds_bytes, stop_after);
+        in_list = a.ovf[li];
+        in_count = &ctl->ovf_count[li];
+        ++li;
+    }
     TierIO io{in_list, in_count, nullptr, nullptr, nullptr};
     uint64_t wg = plan.general_workgroups;
     if (!in_list && a.n < wg) wg = a.n;
-    hipLaunchKernelGGL(k_tokenize_general, dim3((unsigned)(wg ? wg : 1)), dim3(64), 0, (hipStream_t)stream, d, a, io);
+    hipLaunchKernelGGL(k_tokenize_general<false>, dim3((unsigned)(wg ? wg : 1)), dim3(64), 0, (hipStream_t)stream, d, a, io, 0u, stop_after);
     return (int)hipGetLastError();
 }
 
@@ -372,24 +613,41 @@ TierPlan default_tier_plan(int device) {
     if (hipGetDeviceProperties(&p, device) == hipSuccess) cus = p.multiProcessorCount;
     TierPlan t{};
     t.general_workgroups = cus * 8;
-    // Default: two 80 KB pools per CU with 8 wavefronts each (16 sentences in flight per CU, any
-    // mix of sizes up to 80 KB; smaller workgroups drain sooner at the tail of a 4096-sentence
-    // batch than one 160 KB / 16-wavefront workgroup), then one 160 KB pool per CU for the
-    // sentences that need more than 80 KB.  Beyond that: the HBM-scratch kernel.
+    // long-sentence kernel (HBM lattice, LDS-blocked sweep): KGPU_LONG="<KiB>" per single-wavefront workgroup, "0" = off
+    {
+        const char *e = getenv("KGPU_LONG");
+        int kib = e ? atoi(e) : 12;
+        if (kib < 0 || kib > 160) kib = 12;
+        t.long_lds_bytes = (uint32_t)kib * 1024;
+        t.long_workgroups = kib ? cus * (160 / kib) : 0;
+    }
+    // Default: two 80 KB pools per CU with 8 wavefronts each (16 sentences in flight per CU, any mix of
+    // sizes; smaller workgroups drain sooner at the tail of a 4096-sentence batch than one 160 KB /
+    // 16-wavefront workgroup).  A sentence expected to need more than 20 of a pool's 64 pages (25 KB,
+    // ~140 chars) goes to the long-sentence kernel instead: LDS x time grows with the square of the
+    // length, and a few long sentences would otherwise hold the pools while the short ones wait
+    // (cfg 3: 3.6 -> 7.3 M sentences/s).  KGPU_POOL="<KiB>:<wavefronts>[:<max pages>][,...]", "0" = none.
     t.n_pools = 0;
     {
         const char *e = getenv("KGPU_POOL");
-        const char *q = e ? e : "80:8,160:4";
+        const char *q = e ? e : "80:8:20";
         while (*q && t.n_pools < 2) {
-            int kib = atoi(q), w = 8;
+            int kib = atoi(q), w = 8, mp = 64;
             const char *c = q;
             while (*c && *c != ',' && *c != ':') ++c;
-            if (*c == ':' && atoi(c + 1) > 0) w = atoi(c + 1);
+            if (*c == ':' && atoi(c + 1) > 0) {
+                w = atoi(c + 1);
+                ++c;
+                while (*c && *c != ',' && *c != ':') ++c;
+                if (*c == ':' && atoi(c + 1) > 0) mp = atoi(c + 1);
+            }
             if (w > 16) w = 16;
+            if (mp > 64) mp = 64;
             if (kib >= 8 && kib <= 160) {
                 const int per_cu = pool_workgroups_per_cu((uint32_t)kib * 1024, (uint32_t)w);
                 if (per_cu > 0) {
                     t.pool_bytes[t.n_pools] = (uint32_t)kib * 1024; t.pool_waves[t.n_pools] = (uint32_t)w;
+                    t.pool_max_pages[t.n_pools] = (uint32_t)mp;
                     t.pool_workgroups[t.n_pools] = cus * per_cu;
                     ++t.n_pools;
                 }

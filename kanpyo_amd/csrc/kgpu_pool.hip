@@ -141,7 +141,7 @@ __device__ __forceinline__ uint32_t pool_wait_alloc(uint64_t *bm, uint32_t k, ui
 // instantiation, because the 16 wave-uniform u64 accumulators + 9 ticks cost ~50 of the 102 SGPRs
 // and push the plain kernel into SGPR spilling (v_readlane / v_writelane traffic on the VALU).
 template <bool PROF>
-__global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a, TierIO io, uint32_t pool_bytes,
+__global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a, TierIO io, uint32_t pool_bytes, uint32_t max_pages,
                                                         uint32_t stop_after /* ablation timing only; 0 = run everything */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t pool[];
     const uint32_t lane = threadIdx.x & 63u, wave = bcast32(threadIdx.x >> 6) /* SGPR: everything per-sentence is wave-uniform */, W = blockDim.x >> 6;
@@ -177,7 +177,9 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         const uint32_t need1 = align_up(B + 4, 4) + 24 * (C + 2) + 2 * align_up(C + 2, 4) + align_up(C * MAXM * 5, 16) + 32;
         const uint32_t est = max(need1, (uint32_t)(((uint64_t)B * a.est_q8) >> 8) + 768);
         uint32_t npg = (est + page - 1) / page;
-        if (npg > POOL_PAGES) { tier_defer(io, lane, s); continue; }
+        // routing: a sentence expected to need more than max_pages would hold a large part of the pool for a long
+        // time (LDS x time grows with the square of the length); it is better served by the long-sentence kernel
+        if (npg > max_pages) { tier_defer(io, lane, s); continue; }
         uint32_t pg = pool_wait_alloc(bm, npg, lane);
         if (pg == NONE) { tier_defer(io, lane, s); continue; }
         for (uint32_t attempt = 0;; ++attempt) {  // at most one redo, with the exact size
@@ -384,8 +386,8 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
             pool_free(bm, pg, 0, npg, lane);
             if (lane == 0) atomicAdd(io.late_count, 1u);
             pg = NONE;
-            if ((max(need_emit, off + 2 * maxpairs) + page - 1) / page > POOL_PAGES || attempt != 0) { tier_defer(io, lane, s); break; }
-            npg = min(POOL_PAGES, (max(need_emit, need_full) + page - 1) / page);
+            if ((max(need_emit, off + 2 * maxpairs) + page - 1) / page > max_pages || attempt != 0) { tier_defer(io, lane, s); break; }
+            npg = min(max_pages, (max(need_emit, need_full) + page - 1) / page);
             pg = pool_wait_alloc(bm, npg, lane);
             if (pg == NONE) { tier_defer(io, lane, s); break; }
             continue;
@@ -646,7 +648,7 @@ int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves) {
 }
 
 int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t pool_bytes, uint32_t waves,
-                         int n_workgroups, void *stream) {
+                         uint32_t max_pages, int n_workgroups, void *stream) {
     static const uint32_t stop_after = getenv("KGPU_DEBUG_STOP") ? (uint32_t)atoi(getenv("KGPU_DEBUG_STOP")) : 0u;
     if (pool_bytes > 64 * 1024) {  // beyond the default dynamic-LDS cap the kernel has to opt in
         hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
@@ -657,9 +659,9 @@ int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const TierIO &io
             hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
             if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL(k_tokenize_pool<true>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, d, a, io, pool_bytes, stop_after);
+        hipLaunchKernelGGL(k_tokenize_pool<true>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, d, a, io, pool_bytes, max_pages, stop_after);
     } else {
-        hipLaunchKernelGGL(k_tokenize_pool<false>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, d, a, io, pool_bytes, stop_after);
+        hipLaunchKernelGGL(k_tokenize_pool<false>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, d, a, io, pool_bytes, max_pages, stop_after);
     }
     return (int)hipGetLastError();
 }

@@ -270,20 +270,23 @@ def test_device_api_and_work_counters(full):
     assert p["launches"] == 1 and p["tokenize_ms"] > 0
 
 
-@pytest.mark.parametrize("pool", ["0", "80:10", "80:8,160:4", "16:4", "8:2,160:2", "160:16", "40:16,24:1", "24:1"])
-def test_every_launch_chain_is_bit_exact(libs, pool, monkeypatch):
+@pytest.mark.parametrize("pool,long_kib", [("0", "0"), ("0", "12"), ("0", "4"), ("0", "160"), ("80:10", "32"), ("80:8:20", "12"), ("80:8,160:4", "32"),
+                                           ("16:4:8", "16"), ("8:2,160:2", "0"), ("160:16:64", "32"), ("40:16,24:1", "8"), ("24:1", "64")])
+def test_every_launch_chain_is_bit_exact(libs, pool, long_kib, monkeypatch):
     """Force sentences through every launch chain.  KGPU_POOL = KiB of LDS per workgroup : independent
-    wavefronts sharing it ('0' = HBM-scratch kernel only), under pressure: more wavefronts than the pool
-    can serve at once, pools too small for the long sentences, reservations that prove too small (redo);
-    whatever fits no pool ends in the HBM-scratch kernel."""
+    wavefronts sharing it [: pages of 64 a sentence may take] ('0' = no pool kernel), under pressure: more wavefronts than the pool can serve
+    at once, pools too small for the long sentences, reservations that prove too small (redo).  KGPU_LONG =
+    KiB of LDS of the long-sentence kernel (HBM lattice, LDS-blocked sweep; '0' = off, tiny = most positions
+    fall back to the global-memory step).  Whatever is left ends in the plain HBM-scratch kernel."""
     from kanpyo_amd import Tokenizer, synth
 
     _, oracle = libs
     monkeypatch.setenv("KGPU_POOL", pool)
+    monkeypatch.setenv("KGPU_LONG", long_kib)
     sd = synth.build_dict(20000, seed=11)
     tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
     sents = synth.make_corpus(sd, 3000, 3, "cfg2") + synth.make_corpus(sd, 300, 4, "cfg3") + synth.make_corpus(sd, 2, 6, "cfg5") + ["", "あ", "ア" * 1500]
-    for _ in range(3):  # the reservation estimate and the second-pool heuristic adapt between calls
+    for _ in range(3):  # the reservation estimate and the optional-launch heuristics adapt between calls
         assert_same(tok, orc, sents)
     assert_same(tok, orc, ["", "", "", "あ", "", "すもも", ""])
 
