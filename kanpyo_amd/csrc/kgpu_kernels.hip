@@ -32,6 +32,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "kgpu_device.h"
 
@@ -370,12 +371,55 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                 }
                 wave_fence();
                 // the chain: position r of the block, pair (ti, j) on lane ti * 2^lg + j when it fits 64 lanes
+                // two packed descriptor words per position (broadcast by v_readlane + scalar bit-field extracts):
+                // d0 = first target | first bucket slot << 16, d1 = pair offset (17 bits) | T (7) | P (5) |
+                // ceil(log2 P) (3; 7 = not the straight-line shape 2^lg * T <= 64, P <= 16)
+                const uint32_t lgv = P > 1 ? 32 - __clz(P - 1) : 0;
+                const bool fastq = lane < nq && P != 0 && T != 0 && lgv <= 4 && (T << lgv) <= 64;
+                const uint32_t d0 = (t0g - tA) | ((p0g - pA) << 16);
+                const uint32_t d1 = (cE - pairs) | (fastq ? (T << 17) | (P << 24) | (lgv << 29) : 7u << 29);
                 for (uint32_t r = 0; r < nq; ++r) {
+                    const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)r);
+                    const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)r);
+                    const uint32_t t0 = D0 & 0xFFFFu, p0 = D0 >> 16, eb = D1 & 0x1FFFFu;
+                    if ((D1 >> 29) != 7u) {
+                        const uint32_t Tq = (D1 >> 17) & 127u, Pq = (D1 >> 24) & 31u;
+                        auto fast = [&](auto LGc) {
+                            constexpr uint32_t LG = decltype(LGc)::value;
+                            const uint32_t ti = lane >> LG, j = lane & ((1u << LG) - 1);
+                            const bool tv = ti < Tq;
+                            const uint32_t tt = t0 + (tv ? ti : 0);
+                            const uint32_t cs = csL[tt];
+                            int32_t v = 0x7FFFFFFF;
+                            uint32_t nd = 0xFFFFFFFFu;
+                            if (tv && j < Pq) {
+                                v = (int32_t)dpL[p0 + j] + (int32_t)prL[eb + ti * Pq + j];
+                                nd = ndL[p0 + j];
+                            }
+                            const int32_t vmin = gmin_i32(v, LG);   // LG is a constant here: the steps fold
+                            const uint32_t nmin = gmin_u32(v == vmin ? nd : 0xFFFFFFFFu, LG);
+                            if (tv && j == 0) {
+                                const int32_t tot = vmin + (int32_t)(int16_t)cs;
+                                const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
+                                const uint32_t dpn = (uint32_t)(ok ? tot : INF);
+                                preL[tt] = ok ? nmin : NONE;
+                                dpT[tt] = dpn;
+                                const uint32_t sl = cs >> 16;
+                                if (sl != 0xFFFFu) dpL[sl] = dpn;
+                            }
+                        };
+                        switch (D1 >> 29) {
+                            case 0: fast(std::integral_constant<uint32_t, 0>{}); break;
+                            case 1: fast(std::integral_constant<uint32_t, 1>{}); break;
+                            case 2: fast(std::integral_constant<uint32_t, 2>{}); break;
+                            case 3: fast(std::integral_constant<uint32_t, 3>{}); break;
+                            default: fast(std::integral_constant<uint32_t, 4>{}); break;
+                        }
+                        wave_fence();
+                        continue;
+                    }
                     const uint32_t Tq = (uint32_t)__builtin_amdgcn_readlane((int)T, (int)r);
                     const uint32_t Pq = (uint32_t)__builtin_amdgcn_readlane((int)P, (int)r);
-                    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)(t0g - tA), (int)r);
-                    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)(p0g - pA), (int)r);
-                    const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)(cE - pairs), (int)r);
                     if (Pq == 0) {  // nothing ends here: every target stays at INF with no predecessor
                         for (uint32_t t = t0 + lane; t < t0 + Tq; t += 64) {
                             preL[t] = NONE;
