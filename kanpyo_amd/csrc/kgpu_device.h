@@ -86,6 +86,42 @@ __device__ __forceinline__ uint32_t da_walk(const DictView &d, const uint8_t *te
 }
 
 
+// The same walk, started through the first-character table (DictView::first: per BMP code point the node
+// reached after its UTF-8 bytes and that node's base, or {0, steps} when the walk dies inside the
+// character).  Each iteration then sits on node p at byte k and issues BOTH dependent-free loads
+// together: the terminator probe of p (only where a key can end: a character boundary) and the child
+// for the next byte -- one memory latency per byte instead of two.  cp = 0xFFFF (not BMP): plain walk.
+// kb / kn: byte offsets of this character and of the next one.  Returns the byte steps taken.
+template <class F>
+__device__ __forceinline__ uint32_t da_walk_first(const DictView &d, const uint8_t *text, uint32_t cp, uint32_t kb, uint32_t kn,
+                                                  uint32_t B, int32_t base_root, F &&on_match) {
+    if (cp == 0xFFFFu) return da_walk(d, text, kb, B, base_root, on_match);
+    const DaNode f = d.first[cp];
+    if (f.base == 0) return (uint32_t)f.check;
+    int32_t p = f.base, bp = f.check;
+    uint32_t k = kn, nstart = 1, steps = kn - kb;
+    for (;;) {
+        const bool more = k < B;
+        const uint32_t c = more ? text[k] : 0u;
+        const bool boundary = !more || (c & 0xC0) != 0x80;
+        const uint32_t q = (uint32_t)(bp + (int32_t)c);
+        const bool doprobe = boundary && (uint32_t)bp < d.da_len;
+        const bool donext = more && q < d.da_len;
+        DaNode t{0, 0}, nx{0, 0};
+        if (doprobe) t = d.da[bp];  // + TERMINATOR (da.rs:166)
+        if (donext) nx = d.da[q];
+        if (doprobe && t.check == p && t.base < 0) on_match((uint32_t)(-t.base), nstart);
+        if (!more) break;
+        ++steps;
+        if (!donext || nx.check != p) break;  // da.rs:162-165
+        p = (int32_t)q;
+        bp = nx.base;
+        nstart += boundary;
+        ++k;
+    }
+    return steps;
+}
+
 // Work-list plumbing shared by the tier kernels: tier k takes its sentence ids
 // from list `in_list` (nullptr = identity over [0, n)) and pushes the ones whose
 // lattice does not fit its memory budget onto the next tier's list.  Work is a

@@ -42,6 +42,8 @@ using namespace dev;
 
 namespace {
 
+constexpr uint32_t GMAXM = 8;  // trie matches parked per start position by the count walk
+
 // ---- 32/64-bit group minima over aligned groups of 2^lg lanes (lg wave-uniform, exec full) ----
 template <int CTRL>
 __device__ __forceinline__ int32_t g_dpp(int32_t x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
 
         // ---- slab A: per-char arrays (C <= B) --------------------------------
         const uint64_t na = (uint64_t)B + 4;
-        if (!slab_ensure(sa, na * 25 + 64, a, lane)) {
+        if (!slab_ensure(sa, na * (28 + 5 * GMAXM) + 64, a, lane)) {
             if (lane == 0) { a.status[s] = 2; a.tok_count[s] = 0; }
             continue;
         }
@@ -99,7 +101,11 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         uint32_t *boff = nb + na;              // bucket count, then offset, per end
         uint32_t *bfill = boff + na;           // bucket fill cursor
         uint32_t *path = bfill + na;           // backtrace
-        uint8_t *ccat = (uint8_t *)(path + na);
+        uint32_t *mid = path + na;             // [na][GMAXM] trie ids parked by the count walk (the emit phase re-walks nothing)
+        uint16_t *cp16 = (uint16_t *)(mid + na * GMAXM);  // BMP code point (0xFFFF: not BMP)
+        uint8_t *ccat = (uint8_t *)(cp16 + na);
+        uint8_t *mcnt = ccat + na;             // parked matches per start position (0xFF: more than GMAXM -> re-walk)
+        uint8_t *mnch = mcnt + na;             // [na][GMAXM] match length in chars
 
         // ---- phase 0: decode ------------------------------------------------
         uint32_t C = 0, bad = 0, lensum = 0;
@@ -126,6 +132,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                 if (l == 4 && (cp < 0x10000 || cp > 0x10FFFF)) bad = 1;
                 lensum += l;
                 cbyte[ci] = k;
+                cp16[ci] = (uint16_t)(cp < 0xFFFFu ? cp : 0xFFFFu);
                 // char_category_def.rs:33-38: table[ch] if in range else table[0]
                 ccat[ci] = bad ? 0 : (cp < d.cat_len ? d.cat[cp] : d.cat[0]);
             }
@@ -162,12 +169,16 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             const uint32_t run_end = rest ? i + (uint32_t)__ffsll((unsigned long long)rest) : carry_end;
             carry_end = bcast32(run_end);
             if (active) {
-                uint32_t cnt = 0;
-                wT += da_walk(d, text, cbyte[i], B, base_root, [&](uint32_t id, uint32_t nch) {
+                uint32_t cnt = 0, m = 0;
+                wT += da_walk_first(d, text, cp16[i], cbyte[i], cbyte[i + 1], B, base_root, [&](uint32_t id, uint32_t nch) {
+                    if (m < GMAXM && nch < 256) { mid[(size_t)i * GMAXM + m] = id; mnch[(size_t)i * GMAXM + m] = (uint8_t)nch; }
+                    else m = 0x100;  // does not fit the parking area: the emit phase walks again
+                    ++m;
                     uint32_t nrec = 1u + d.morph[id - 1].dup;  // index.rs:46-51
                     cnt += nrec;
                     atomicAdd(&cnt_e[i + nch], nrec);
                 });
+                mcnt[i] = (uint8_t)(m > GMAXM ? 0xFFu : m);
                 const CatInfo ci = d.cinfo[cat];
                 uint32_t span = 0;
                 // lattice.rs:54: !matched_known || invoke_list[cat]; lattice.rs:87-92: no unk entry -> nothing
@@ -220,11 +231,12 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         // ---- phase 3: emit -----------------------------------------------------------
         for (uint32_t i = lane; i < C; i += 64) {
             uint32_t t = nb[i];
-            da_walk(d, text, cbyte[i], B, base_root, [&](uint32_t id, uint32_t nch) {
+            auto emit_match = [&](uint32_t id, uint32_t nch) {
                 const uint32_t end = i + nch;
-                const uint32_t nrec = 1u + d.morph[id - 1].dup;
+                const Morph8 m0 = d.morph[id - 1];  // first record: carries the duplicate count (index.rs:46-51)
+                const uint32_t nrec = 1u + m0.dup;
                 for (uint32_t r = 0; r < nrec; ++r) {  // lattice.rs:177-188
-                    const Morph8 m = d.morph[id - 1 + r];
+                    const Morph8 m = r ? d.morph[id - 1 + r] : m0;
                     const uint32_t slot = boff[end] + atomicAdd(&fill_e[end], 1u);
                     nodeA[t] = make_uint4((uint16_t)m.left | ((uint32_t)(uint16_t)m.right << 16),
                                           (uint32_t)(int32_t)m.cost, slot, id + r);
@@ -232,7 +244,10 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                     bucket[slot] = make_uint4((uint32_t)INF, (uint16_t)m.right, t, 0);  // dp is filled in by the sweep
                     ++t;
                 }
-            });
+            };
+            const uint32_t nm = mcnt[i];
+            if (nm == 0xFFu) da_walk(d, text, cbyte[i], B, base_root, emit_match);
+            else for (uint32_t m = 0; m < nm; ++m) emit_match(mid[(size_t)i * GMAXM + m], mnch[(size_t)i * GMAXM + m]);
             const uint32_t span = uspan[i];
             if (span) {  // lattice.rs:87-97,190-201
                 const CatInfo ci = d.cinfo[ccat[i]];

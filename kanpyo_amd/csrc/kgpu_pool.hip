@@ -284,41 +284,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
                         cnt += nrec;
                         atomicAdd(&boff[i + nch], nrec);
                     };
-                    const uint32_t cp = cp16[i];
-                    if (cp == 0xFFFFu) {
-                        wT += da_walk(d, text, cbyte[i], B, base_root, on_match);  // non-BMP first char: byte-wise from the root
-                    } else {
-                        const DaNode f = d.first[cp];  // {.base = node, .check = base[node]} or {0, steps}
-                        if (f.base == 0) {
-                            wT += (uint32_t)f.check;  // the walk dies inside the first character
-                        } else {
-                            // Each iteration sits on node p at byte k and issues BOTH dependent-free loads
-                            // together: the terminator probe of p (only where a key can end: a character
-                            // boundary) and the child for the next byte -- one memory latency per byte.
-                            int32_t p = f.base, bp = f.check;
-                            uint32_t k = cbyte[i + 1], nstart = 1;
-                            wT += k - cbyte[i];
-                            for (;;) {
-                                const bool more = k < B;
-                                const uint32_t c = more ? text[k] : 0u;
-                                const bool boundary = !more || (c & 0xC0) != 0x80;
-                                const uint32_t q = (uint32_t)(bp + (int32_t)c);
-                                const bool doprobe = boundary && (uint32_t)bp < d.da_len;
-                                const bool donext = more && q < d.da_len;
-                                DaNode t{0, 0}, nx{0, 0};
-                                if (doprobe) t = d.da[bp];  // + TERMINATOR (da.rs:166)
-                                if (donext) nx = d.da[q];
-                                if (doprobe && t.check == p && t.base < 0) on_match((uint32_t)(-t.base), nstart);
-                                if (!more) break;
-                                ++wT;
-                                if (!donext || nx.check != p) break;  // da.rs:162-165
-                                p = (int32_t)q;
-                                bp = nx.base;
-                                nstart += boundary;
-                                ++k;
-                            }
-                        }
-                    }
+                    wT += da_walk_first(d, text, cp16[i], cbyte[i], cbyte[i + 1], B, base_root, on_match);
                     mcnt[i] = (uint8_t)(m < MAXM ? m : MAXM);
                     const CatInfo ci = d.cinfo[cat];
                     uint32_t span = 0;
