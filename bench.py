@@ -42,7 +42,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--queue", type=int, default=3, help="batches in flight (one ctx/stream each; HIP multiplexes streams onto 3 hardware queues, more only serialise behind each other)")
+    ap.add_argument("--queue", type=int, default=6, help="batches in flight (one context each)")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the contexts share round-robin (HIP multiplexes streams onto "
+                    "3 hardware queues: a 4th stream queues behind the 1st and unbalances them)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="lower bound of CPU-baseline work")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (self-test)")
@@ -93,10 +95,13 @@ def main():
     nb = len(batches)
     cap = max(b[2] for b in batches) + BATCH  # always sufficient: tokens <= chars + 1 <= bytes + 1
     K, W, Q = args.steps, args.warmup, max(1, args.queue)
-    ctxs = [DeviceContext(tok) for _ in range(Q)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, min(args.streams, Q)))]
+    ctxs = [DeviceContext(tok, streams[i % len(streams)].cuda_stream) for i in range(Q)]
     n_out = max(K, W, 1)
-    out_tok = [torch.empty((cap, 6), dtype=torch.int32, device=dev) for _ in range(max(2 * Q, 8))]
-    out_off = [torch.empty(BATCH + 1, dtype=torch.int64, device=dev) for _ in range(len(out_tok))]
+    out_tok = [torch.empty((cap, 6), dtype=torch.int32, device=dev) for _ in range(max(2 * Q, 24))]  # >= 2 gather chunks
+    NB = len(out_tok)
+    out_off_all = torch.empty((NB, BATCH + 1), dtype=torch.int64, device=dev)  # one row per output buffer
+    out_off = [out_off_all[i] for i in range(NB)]
     out_st = [torch.empty(BATCH, dtype=torch.uint8, device=dev) for _ in range(len(out_tok))]
 
     def enqueue(i):
@@ -127,6 +132,11 @@ def main():
         nt = ctxs[0].sync()
         sample_tokens = (out_tok[0][:nt].cpu().numpy().copy(), out_off[0].cpu().numpy().copy())
 
+    row_cache = {}
+    size_pg = dist.new_group(backend="gloo") if multi else None  # CPU-side size exchange of the gather
+    GC = 12  # steps per gather chunk (multi-rank): large enough that the host side of a gather (CPU-side size
+             # exchange, one grouped send/recv call) is a small part of the chunk; the contexts' queue keeps the GPU fed
+
     def run_steps(nsteps):
         """Exactly `nsteps` steps; multi-rank: plus the overlapped gather of everything produced."""
         if not multi:
@@ -134,33 +144,48 @@ def main():
                 enqueue(i)
             drain()
             return
-        # Chunks of Q steps; the token records of chunk c travel to rank 0 (flat gatherv over
-        # xGMI) while chunk c+1 is being tokenized.  Every byte produced is gathered.
-        gather = ChunkedGather(dst=0)
+        # Chunks of GC steps; the token records of chunk c travel to rank 0 (flat gatherv over xGMI) while
+        # chunk c+1 is being tokenized.  Every byte produced is gathered.  Step i writes output buffer
+        # i mod 2*GC, so chunk c's transfers are waited for before chunk c+2 starts.
+        gather = ChunkedGather(dst=0, size_group=size_pg)
         ntok_of = {}
+        chunks = []
+
+        def retire(upto):  # steps < upto are complete on the device: collect their token counts
+            for j in range(max(0, upto - Q), upto):
+                if j not in ntok_of:
+                    ntok_of[j] = ctxs[j % Q].sync()
 
         def post(lo, hi):
-            toks = torch.cat([out_tok[i % len(out_tok)][: ntok_of[i]] for i in range(lo, hi)])
-            cnts = torch.cat([out_off[i % len(out_tok)][1:] - out_off[i % len(out_tok)][:-1] for i in range(lo, hi)])
-            gather.post(toks, cnts)
+          t_post0 = time.perf_counter()
+          if True:
+            views = [out_tok[i % NB][: ntok_of[i]] for i in range(lo, hi)]  # sent as they are: no concat pass
+            key = (lo % NB, hi - lo)
+            if key not in row_cache:  # cached: no host-to-device copy (a sync behind a busy device) per chunk
+                row_cache[key] = torch.tensor([i % NB for i in range(lo, hi)], device=dev)
+            offs = out_off_all.index_select(0, row_cache[key])  # [steps, BATCH + 1] in one gather
+            t_post1 = time.perf_counter()
+            gather.post_steps(views, (offs[:, 1:] - offs[:, :-1]).reshape(-1))
+            if os.environ.get("BENCH_DEBUG_GATHER") and rank == 0:
+                print(f"[gather] steps {lo}..{hi}: prepare {1e3 * (t_post1 - t_post0):.3f} ms, post {1e3 * (time.perf_counter() - t_post1):.3f} ms", file=sys.stderr)
 
-        for c0 in range(0, nsteps, Q):
-            for i in range(c0, min(c0 + Q, nsteps)):
+
+        for c0 in range(0, nsteps, GC):
+            if c0 >= 2 * GC:
+                chunks += [(r[0].shape[0], sum(z[0] for z in r[2])) for r in gather.finish() if r is not None]  # chunk c0/GC - 2 has left its buffers
+            for i in range(c0, min(c0 + GC, nsteps)):
                 if i >= Q:
                     ntok_of[i - Q] = ctxs[i % Q].sync()  # step i-Q used this ctx: done before it is reused
                 enqueue(i)
-            if c0 >= Q:
-                for j in range(c0 - Q, c0):  # a short last chunk leaves some ctxs of the previous chunk unvisited
-                    if j not in ntok_of:
-                        ntok_of[j] = ctxs[j % Q].sync()
-                post(c0 - Q, c0)
-        last0 = ((nsteps - 1) // Q) * Q
-        for i in range(max(last0, 0), nsteps):
-            ntok_of[i] = ctxs[i % Q].sync()
-        post(last0, nsteps)
-        chunks = gather.finish()
+            if c0 >= GC:
+                retire(c0)
+                post(c0 - GC, c0)
+        last0 = ((nsteps - 1) // GC) * GC
+        retire(nsteps)
+        post(max(last0, 0), nsteps)
+        chunks += [(r[0].shape[0], sum(z[0] for z in r[2])) for r in gather.finish() if r is not None]
         if rank == 0:
-            assert sum(c[0].shape[0] for c in chunks) == sum(s[0] for c in chunks for s in c[2])
+            assert chunks and all(got == want for got, want in chunks)
 
     # ---- warmup (also brings up the RCCL channels of the gather)
     if W > 0:

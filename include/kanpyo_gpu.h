@@ -144,7 +144,9 @@ int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint64_t *offse
  * the RCCL gather).  All d_* pointers are device pointers on the dict's
  * device.  kgpu_tokenize_device only enqueues on the ctx stream;
  * kgpu_ctx_sync waits and reports the dense token count (or KGPU_ERR_CAPACITY). */
-int kgpu_ctx_create(kgpu_dict *d, void *hip_stream /* NULL: ctx-owned stream */, kgpu_ctx **out);
+int kgpu_ctx_create(kgpu_dict *d, void *hip_stream /* NULL: one of the dictionary's three shared streams */, kgpu_ctx **out);
+/* One batch in flight per ctx; keep three or more contexts busy to fill the chip.  Contexts may share a
+ * stream (each waits on its own completion event); those created with NULL share three per dictionary. */
 void kgpu_ctx_destroy(kgpu_ctx *c);
 int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n,
                          uint64_t total_bytes, kgpu_token *d_tokens, uint64_t token_capacity,

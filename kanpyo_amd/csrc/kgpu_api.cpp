@@ -91,12 +91,17 @@ struct kgpu_dict {
     // Same for the long-sentence kernel (its workgroups hold 32 KB of LDS each): issued while recent
     // batches still had sentences left after the pools.
     std::atomic<int> long_batches{0};
+    // Streams handed round-robin to contexts created without one.  HIP multiplexes streams onto three
+    // hardware queues: a 4th stream queues behind the 1st and unbalances them (measured -25 %), so any
+    // number of contexts shares three streams; each context waits on its own completion event.
+    std::vector<hipStream_t> streams;
+    unsigned next_stream = 0;
 };
 
 struct kgpu_ctx {
     kgpu_dict *dict = nullptr;
     hipStream_t stream = nullptr;
-    bool own_stream = false;
+    hipEvent_t done_ev = nullptr;  // recorded behind the batch's last kernel: contexts may share a stream
     Control *d_ctl = nullptr;
     Control *h_ctl = nullptr;  // pinned + device-mapped: the scan kernel publishes the launch's Control block here
     Control *h_ctl_dev = nullptr;  // device-side address of h_ctl
@@ -361,6 +366,7 @@ extern "C" void kgpu_dict_destroy(kgpu_dict *d) {
     (void)hipSetDevice(d->device);
     for (auto *c : d->pool) kgpu_ctx_destroy(c);
     d->pool.clear();
+    for (hipStream_t st : d->streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (void *p : d->allocs) (void)hipFree(p);
     delete d;
 }
@@ -384,14 +390,27 @@ extern "C" int kgpu_ctx_create(kgpu_dict *d, void *hip_stream, kgpu_ctx **out) {
     c->dict = d;
     if (hip_stream) c->stream = (hipStream_t)hip_stream;
     else {
-        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete c; return KGPU_ERR_HIP; }
-        c->own_stream = true;
+        std::lock_guard<std::mutex> g(d->pool_mu);
+        static const unsigned n_streams = getenv("KGPU_STREAMS") && atoi(getenv("KGPU_STREAMS")) > 0 ? (unsigned)atoi(getenv("KGPU_STREAMS")) : 3u;
+        if (d->streams.size() < n_streams) {
+            hipStream_t st = nullptr;
+            hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            if (e != hipSuccess) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete c; return KGPU_ERR_HIP; }
+            d->streams.push_back(st);
+            c->stream = st;
+        } else {
+            c->stream = d->streams[d->next_stream++ % d->streams.size()];
+        }
     }
     if (hipMalloc((void **)&c->d_ctl, sizeof(Control)) != hipSuccess ||
         hipHostMalloc((void **)&c->h_ctl, sizeof(Control), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&c->h_ctl_dev, c->h_ctl, 0) != hipSuccess) {
         set_error("kgpu_ctx_create: control block allocation failed");
+        kgpu_ctx_destroy(c);
+        return KGPU_ERR_HIP;
+    }
+    if (hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming) != hipSuccess) {
+        set_error("kgpu_ctx_create: hipEventCreate failed");
         kgpu_ctx_destroy(c);
         return KGPU_ERR_HIP;
     }
@@ -403,13 +422,13 @@ extern "C" int kgpu_ctx_create(kgpu_dict *d, void *hip_stream, kgpu_ctx **out) {
 extern "C" void kgpu_ctx_destroy(kgpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->dict->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->pending && c->done_ev) (void)hipEventSynchronize(c->done_ev);
+    if (c->done_ev) (void)hipEventDestroy(c->done_ev);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     c->arena.release(); c->ovf.release(); c->stage.release(); c->tok_count.release();
     c->in_utf8.release(); c->in_off.release(); c->out_tok.release(); c->out_off.release(); c->out_status.release();
     if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
-    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -447,6 +466,7 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
         if (e != hipSuccess) { set_error("scan/compact launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     }
     if (timed) HIPCHECK(hipEventRecord(e2, c->stream));
+    HIPCHECK(hipEventRecord(c->done_ev, c->stream));
     c->ctl_dirty = false;
     c->last = a;
     c->pending = true;
@@ -486,8 +506,8 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
     if (!c) { set_error("kgpu_ctx_sync: null ctx"); return KGPU_ERR_INVALID_ARG; }
     HIPCHECK(hipSetDevice(c->dict->device));
     for (;;) {
-        HIPCHECK(hipStreamSynchronize(c->stream));
         if (!c->pending) { if (n_tokens) *n_tokens = 0; return KGPU_OK; }
+        HIPCHECK(hipEventSynchronize(c->done_ev));  // this context's batch only: later work on a shared stream is not waited for
         if (c->h_ctl->arena_overflow) {
             // a lattice did not fit the scratch arena: grow it and redo the batch
             size_t want = c->arena.bytes * 2;

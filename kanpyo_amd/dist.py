@@ -81,6 +81,29 @@ def gather_tokens(tokens, counts, dst: int = 0, group=None):
     return None, None, sizes
 
 
+def _exchange_sizes(n_tok: int, n_cnt: int, device, world: int, group, size_group=None):
+    """Every rank's (token rows, count entries).  With `size_group` (a CPU/gloo group over the same ranks)
+    the exchange never touches the GPU -- no wait behind the kernels queued on a busy device; otherwise
+    one small all-gather on `group` and ONE device-to-host read."""
+    import torch
+    import torch.distributed as dist
+
+    if size_group is not None:
+        meta = torch.tensor([n_tok, n_cnt], dtype=torch.int64)
+        metas = [torch.zeros_like(meta) for _ in range(world)]
+        dist.all_gather(metas, meta, group=size_group)
+        return [(int(m[0]), int(m[1])) for m in metas]
+    meta = torch.tensor([n_tok, n_cnt], dtype=torch.int64, device=device)
+    allm = torch.empty((world, 2), dtype=torch.int64, device=device)
+    try:
+        dist.all_gather_into_tensor(allm, meta, group=group)
+    except (RuntimeError, NotImplementedError):  # backend without the flat form
+        metas = [torch.zeros_like(meta) for _ in range(world)]
+        dist.all_gather(metas, meta, group=group)
+        allm = torch.stack(metas)
+    return [(int(a), int(b)) for a, b in allm.cpu().tolist()]
+
+
 class ChunkedGather:
     """The same flat gatherv, posted chunk by chunk so that it overlaps the tokenization of
     the following chunk (the root's seven inbound xGMI links work while the CUs compute).
@@ -89,8 +112,8 @@ class ChunkedGather:
     all transfers and, on `dst`, returns the rank-major (tokens, counts, sizes) of each chunk.
     """
 
-    def __init__(self, dst: int = 0, group=None):
-        self.dst, self.group = dst, group
+    def __init__(self, dst: int = 0, group=None, size_group=None):
+        self.dst, self.group, self.size_group = dst, group, size_group
         self._inflight = []  # (works, result-or-None, keepalive)
 
     def post(self, tokens, counts):
@@ -98,10 +121,7 @@ class ChunkedGather:
         import torch.distributed as dist
 
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
-        meta = torch.tensor([tokens.shape[0], counts.shape[0]], dtype=torch.int64, device=tokens.device)
-        metas = [torch.zeros_like(meta) for _ in range(world)]
-        dist.all_gather(metas, meta, group=self.group)
-        sizes = [(int(m[0]), int(m[1])) for m in metas]
+        sizes = _exchange_sizes(tokens.shape[0], counts.shape[0], tokens.device, world, self.group, self.size_group)
         ops, result = [], None
         tokens, counts = tokens.contiguous(), counts.contiguous()
         if rank == self.dst:
@@ -128,6 +148,61 @@ class ChunkedGather:
                 ops.append(dist.P2POp(dist.isend, counts, self.dst, self.group))
         works = dist.batch_isend_irecv(ops) if ops else []
         self._inflight.append((works, result, (tokens, counts)))
+
+    def post_steps(self, token_views, counts):
+        """Same gather for a chunk made of several steps whose token records live in separate buffers:
+        no concatenation on the senders (each view is sent as it is, all sends of the chunk in one
+        grouped call), the root receives every view straight into its place of the rank-major
+        stream and copies its own views there in one pass.  `token_views`: list of [k_i, 6] tensors
+        (the same number of steps on every rank); `counts`: [n_local] tokens per local sentence."""
+        import torch
+        import torch.distributed as dist
+
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        mine = [int(v.shape[0]) for v in token_views] + [int(counts.shape[0])]
+        if self.size_group is not None:
+            meta = torch.tensor(mine, dtype=torch.int64)
+            metas = [torch.zeros_like(meta) for _ in range(world)]
+            dist.all_gather(metas, meta, group=self.size_group)
+            table = [m.tolist() for m in metas]
+        else:
+            meta = torch.tensor(mine, dtype=torch.int64, device=counts.device)
+            metas = [torch.zeros_like(meta) for _ in range(world)]
+            dist.all_gather(metas, meta, group=self.group)
+            table = torch.stack(metas).cpu().tolist()
+        sizes = [(sum(row[:-1]), row[-1]) for row in table]
+        ops, result = [], None
+        counts = counts.contiguous()
+        if rank == self.dst:
+            dev = counts.device
+            tok_all = torch.empty((sum(s[0] for s in sizes), 6), dtype=token_views[0].dtype if token_views else torch.int32, device=dev)
+            cnt_all = torch.empty(sum(s[1] for s in sizes), dtype=counts.dtype, device=dev)
+            t0 = c0 = 0
+            for r, row in enumerate(table):
+                nt, nc = sizes[r]
+                if r == rank:
+                    if nt:
+                        torch.cat([v for v in token_views if v.shape[0]], out=tok_all[t0 : t0 + nt])
+                    cnt_all[c0 : c0 + nc].copy_(counts)
+                else:
+                    at = t0
+                    for k in row[:-1]:
+                        if k:
+                            ops.append(dist.P2POp(dist.irecv, tok_all[at : at + k], r, self.group))
+                        at += k
+                    if nc:
+                        ops.append(dist.P2POp(dist.irecv, cnt_all[c0 : c0 + nc], r, self.group))
+                t0 += nt
+                c0 += nc
+            result = (tok_all, cnt_all, sizes)
+        else:
+            for v in token_views:
+                if v.shape[0]:
+                    ops.append(dist.P2POp(dist.isend, v, self.dst, self.group))
+            if counts.shape[0]:
+                ops.append(dist.P2POp(dist.isend, counts, self.dst, self.group))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        self._inflight.append((works, result, (token_views, counts)))
 
     def finish(self):
         out = []

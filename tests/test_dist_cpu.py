@@ -106,3 +106,49 @@ def test_chunked_overlapped_gather_gloo(tmp_path):
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_worker_chunked, args=(3, port, str(tmp_path)), nprocs=3, join=True)
     assert open(tmp_path / "chunked").read() == "ok"
+
+
+def _worker_steps(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from kanpyo_amd.dist import ChunkedGather
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    for size_group in (None, dist.new_group(backend="gloo")):
+        g = ChunkedGather(dst=0, size_group=size_group)
+        for c in range(3):  # chunks of 4 steps each, ragged, with empty steps
+            views = []
+            for j in range(4):
+                nt = 0 if (rank + j + c) % 4 == 0 else 3 * (rank + 1) + j
+                views.append(torch.full((nt, 6), 100 * c + 10 * j + rank, dtype=torch.int32))
+            g.post_steps(views, torch.full((2 + rank,), c, dtype=torch.int64))
+        res = g.finish()
+        if rank == 0:
+            for c, (tok_all, cnt_all, sizes) in enumerate(res):
+                exp = []
+                for r in range(world):
+                    for j in range(4):
+                        nt = 0 if (r + j + c) % 4 == 0 else 3 * (r + 1) + j
+                        exp.append(torch.full((nt, 6), 100 * c + 10 * j + r, dtype=torch.int32))
+                ok = ok and torch.equal(tok_all, torch.cat(exp)) and cnt_all.tolist() == sum(([c] * (2 + r) for r in range(world)), [])
+                ok = ok and sizes == [(sum(0 if (r + j + c) % 4 == 0 else 3 * (r + 1) + j for j in range(4)), 2 + r) for r in range(world)]
+        else:
+            ok = ok and all(r is None for r in res)
+    if rank == 0:
+        open(os.path.join(tmpdir, "steps"), "w").write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stepwise_gather_without_concat_gloo(tmp_path):
+    """ChunkedGather.post_steps: every step's records sent as they are, received in place on the root."""
+    import torch.multiprocessing as mp
+
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker_steps, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert open(tmp_path / "steps").read() == "ok"
