@@ -671,7 +671,7 @@ TierPlan default_tier_plan(int device) {
     int cus = 256;
     if (hipGetDeviceProperties(&p, device) == hipSuccess) cus = p.multiProcessorCount;
     TierPlan t{};
-    t.general_workgroups = cus * 8;
+    t.general_workgroups = cus * 2;  // the last resort is rarely needed: few workgroups, so that an empty launch drains quickly on a busy chip
     // long-sentence kernel (HBM lattice, LDS-blocked sweep): KGPU_LONG="<KiB>" per single-wavefront workgroup, "0" = off
     {
         const char *e = getenv("KGPU_LONG");
