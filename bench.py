@@ -266,15 +266,31 @@ def main():
 
     # ---- host-buffer entry point (H2D + kernels + D2H per batch): the PCIe-inclusive rate, never `value`
     if world == 1:
-        tok.tokenize_packed(batches[0][3], batches[0][4], token_capacity=cap)  # untimed: the pool ctx allocates its scratch
+        from kanpyo_amd.tokenizer import TOKEN_DTYPE, pinned_empty
+        h_out = (np.empty(cap, dtype=TOKEN_DTYPE), np.empty(BATCH + 1, dtype=np.uint64), np.empty(BATCH, dtype=np.uint8))
+        tok.tokenize_packed(batches[0][3], batches[0][4], out=h_out)  # untimed: the pool ctx allocates its scratch, pages get touched
         t1 = time.perf_counter()
         done = 0
         for i in range(min(nb, 12)):
             _, _, _, utf8_h, offs_h = batches[i]
-            tok.tokenize_packed(utf8_h, offs_h, token_capacity=cap)
+            tok.tokenize_packed(utf8_h, offs_h, out=h_out)
             done += BATCH
         result["pcie_inclusive"] = {"value": done / (time.perf_counter() - t1), "unit": "sentences/s",
                                     "what": "kgpu_tokenize_batch: pageable host buffers in, dense tokens out, one batch at a time"}
+        # the same entry point given the 24 batches in ONE call (it pipelines 16384-sentence chunks over three
+        # contexts), with pageable and with pinned (kgpu_host_alloc) buffers
+        utf8_all, offs_all = pack_sentences(corpus[: nb * BATCH])
+        capall = int(offs_all[-1]) // 2 + nb * BATCH  # tokens <= chars + 1 per sentence; the text is 3 bytes per char
+        for name, alloc in (("large_call_pageable", np.empty), ("large_call_pinned", pinned_empty)):
+            u = alloc(utf8_all.shape, dtype=np.uint8); u[:] = utf8_all
+            o = alloc(offs_all.shape, dtype=np.uint64); o[:] = offs_all
+            big = (alloc(capall, dtype=TOKEN_DTYPE), alloc(nb * BATCH + 1, dtype=np.uint64), alloc(nb * BATCH, dtype=np.uint8))
+            tok.tokenize_packed(u, o, out=big)  # untimed: scratch allocation, pages touched
+            t1 = time.perf_counter()
+            for _ in range(3):
+                tok.tokenize_packed(u, o, out=big)
+            result["pcie_inclusive"][name] = 3 * nb * BATCH / (time.perf_counter() - t1)
+            del big
 
     # ---- CPU baseline (rank 0, N==1 only): the oracle restatement on the host cores
     if world == 1 and not args.no_cpu:

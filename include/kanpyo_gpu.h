@@ -140,6 +140,11 @@ int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint64_t *offse
                         kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets,
                         uint8_t *status, uint64_t *n_tokens);
 
+/* Pinned host memory for the buffers of kgpu_tokenize_batch (optional): with it the host<->device copies of a
+ * large call run as DMA and overlap the kernels of its other chunks; pageable buffers work, more slowly. */
+void *kgpu_host_alloc(uint64_t bytes);
+void kgpu_host_free(void *p);
+
 /* Device-resident form (inputs already in HBM, outputs left in HBM, e.g. for
  * the RCCL gather).  All d_* pointers are device pointers on the dict's
  * device.  kgpu_tokenize_device only enqueues on the ctx stream;

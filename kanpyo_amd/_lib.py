@@ -22,6 +22,7 @@ SYMBOLS = [
     "kgpu_last_error", "kgpu_device_count", "kgpu_dict_create", "kgpu_dict_destroy", "kgpu_dict_get_info",
     "kgpu_tokenize_batch", "kgpu_ctx_create", "kgpu_ctx_destroy", "kgpu_tokenize_device", "kgpu_ctx_sync",
     "kgpu_ctx_set_profiling", "kgpu_ctx_get_profile", "kgpu_ctx_get_work", "kgpu_ctx_get_phase_cycles", "kgpu_index_build", "kgpu_free",
+    "kgpu_host_alloc", "kgpu_host_free",
 ]
 
 
@@ -88,6 +89,10 @@ def lib():
         L.kgpu_index_build.argtypes = [vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.kgpu_free.argtypes = [vp]
         L.kgpu_free.restype = None
+        L.kgpu_host_alloc.argtypes = [C.c_uint64]
+        L.kgpu_host_alloc.restype = vp
+        L.kgpu_host_free.argtypes = [vp]
+        L.kgpu_host_free.restype = None
         _lib = L
     return _lib
 

@@ -605,32 +605,58 @@ extern "C" int kgpu_ctx_get_profile(kgpu_ctx *c, kgpu_profile *out, int reset) {
 // ------------------------------------------------------- host-buffer entry point
 
 // One chunk of the host-buffer entry point: H2D, tier chain, D2H on the ctx stream.
-static int tokenize_host_chunk(kgpu_ctx *c, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
-                               kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets,
-                               uint8_t *status, uint64_t *n_tokens) {
-    const uint64_t base = offsets[0], total = offsets[n] - base;
-    std::vector<uint64_t> rel((size_t)n + 1);
-    for (uint64_t i = 0; i <= n; ++i) rel[(size_t)i] = offsets[i] - base;
+// ---- host-buffer entry point ---------------------------------------------------------------------------
+// One chunk of a host call in flight on one pooled context: H2D + kernels enqueued, results still on the device.
+struct HostJob {
+    kgpu_ctx *c = nullptr;
+    uint64_t lo = 0, m = 0;        // sentences [lo, lo + m) of the call
+    std::vector<uint64_t> rel;     // chunk-relative byte offsets (must outlive the asynchronous H2D copy)
+    bool active = false;
+};
+
+static int host_job_submit(HostJob &j, const uint8_t *utf8, const uint64_t *offsets) {
+    kgpu_ctx *c = j.c;
+    const uint64_t *off = offsets + j.lo;
+    const uint64_t n = j.m, base = off[0], total = off[n] - base;
+    j.rel.resize((size_t)n + 1);
+    for (uint64_t i = 0; i <= n; ++i) j.rel[(size_t)i] = off[i] - base;
+    const uint64_t cap = total + n + 1;  // tokens <= chars + 1 <= bytes + 1 per sentence: never too small
     int rc;
     if ((rc = c->in_utf8.ensure((size_t)total + 16)) || (rc = c->in_off.ensure((size_t)(n + 1) * 8)) ||
-        (rc = c->out_tok.ensure((size_t)token_capacity * sizeof(kgpu_token) + 64)) ||
+        (rc = c->out_tok.ensure((size_t)cap * sizeof(kgpu_token) + 64)) ||
         (rc = c->out_off.ensure((size_t)(n + 1) * 8)) || (rc = c->out_status.ensure((size_t)n + 16)))
         return rc;
     hipError_t e;
     if (total && (e = hipMemcpyAsync(c->in_utf8.p, utf8 + base, (size_t)total, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { set_error("H2D utf8: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
-    if ((e = hipMemcpyAsync(c->in_off.p, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { set_error("H2D offsets: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
-    // `rel` must stay alive until the copy is done: the sync below covers it
+    if ((e = hipMemcpyAsync(c->in_off.p, j.rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { set_error("H2D offsets: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     if ((rc = kgpu_tokenize_device(c, (const uint8_t *)c->in_utf8.p, (const uint64_t *)c->in_off.p, n, total,
-                                   (kgpu_token *)c->out_tok.p, token_capacity, (uint64_t *)c->out_off.p,
-                                   (uint8_t *)c->out_status.p)))
+                                   (kgpu_token *)c->out_tok.p, cap, (uint64_t *)c->out_off.p, (uint8_t *)c->out_status.p)))
         return rc;
+    j.active = true;
+    return KGPU_OK;
+}
+
+// Wait for the job, copy its results behind the `tok_done` tokens already delivered (or only count, once the
+// caller's buffer has overflowed) and make the chunk-local token offsets global.
+static int host_job_finish(HostJob &j, kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets, uint8_t *status,
+                           uint64_t &tok_done, bool &overflow) {
+    kgpu_ctx *c = j.c;
+    j.active = false;
     uint64_t got = 0;
-    rc = kgpu_ctx_sync(c, &got);
-    *n_tokens = got;
+    int rc = kgpu_ctx_sync(c, &got);
     if (rc) return rc;
-    if (got && (e = hipMemcpy(tokens, c->out_tok.p, (size_t)got * sizeof(kgpu_token), hipMemcpyDeviceToHost)) != hipSuccess) { set_error("D2H tokens: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
-    if ((e = hipMemcpy(tok_offsets, c->out_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost)) != hipSuccess) { set_error("D2H offsets: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
-    if (status && n && (e = hipMemcpy(status, c->out_status.p, (size_t)n, hipMemcpyDeviceToHost)) != hipSuccess) { set_error("D2H status: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    if (tok_done + got > token_capacity) overflow = true;
+    hipError_t e;
+    if (!overflow) {
+        if (got && (e = hipMemcpyAsync(tokens + tok_done, c->out_tok.p, (size_t)got * sizeof(kgpu_token), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) { set_error("D2H tokens: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+        if ((e = hipMemcpyAsync(tok_offsets + j.lo, c->out_off.p, (size_t)(j.m + 1) * 8, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) { set_error("D2H offsets: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    }
+    if (status && j.m && (e = hipMemcpyAsync(status + j.lo, c->out_status.p, (size_t)j.m, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) { set_error("D2H status: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    // pageable destinations make these copies synchronous; pinned ones (kgpu_host_alloc) run at DMA speed while the
+    // next chunks' kernels execute.  The offsets fix-up below needs the data, so wait for this stream's copies here.
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) { set_error("D2H sync: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    if (!overflow) for (uint64_t i = 0; i <= j.m; ++i) tok_offsets[j.lo + i] += tok_done;  // chunk-local -> global
+    tok_done += got;
     return KGPU_OK;
 }
 
@@ -646,39 +672,52 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
     if (offsets[n] - offsets[0] && !utf8) { set_error("kgpu_tokenize_batch: null utf8"); return KGPU_ERR_INVALID_ARG; }
     HIPCHECK(hipSetDevice(d->device));
 
-    kgpu_ctx *c = nullptr;
-    {
-        std::lock_guard<std::mutex> g(d->pool_mu);
-        if (!d->pool.empty()) { c = d->pool.back(); d->pool.pop_back(); }
-    }
-    int rc = KGPU_OK;
-    if (!c && (rc = kgpu_ctx_create(d, nullptr, &c))) return rc;
-
-    // Large inputs go through in chunks of at most HOST_CHUNK_BYTES / HOST_CHUNK_SENTS so that the
-    // device staging (24 B per input byte) stays bounded; tokens stay dense across chunks.
-    const uint64_t HOST_CHUNK_BYTES = getenv("KGPU_HOST_CHUNK_BYTES") ? strtoull(getenv("KGPU_HOST_CHUNK_BYTES"), nullptr, 10) : (64ull << 20);
-    const uint64_t HOST_CHUNK_SENTS = 1ull << 20;
+    // A large call goes through in chunks (bounded device staging: 24 B per input byte), three of them in
+    // flight on pooled contexts: while chunk k's results travel to the host, chunk k+1's kernels run and
+    // chunk k+2's input is on its way.  Results are delivered in order, so the tokens stay dense.
+    const uint64_t CHUNK_BYTES = getenv("KGPU_HOST_CHUNK_BYTES") ? strtoull(getenv("KGPU_HOST_CHUNK_BYTES"), nullptr, 10) : (4ull << 20);
+    const uint64_t CHUNK_SENTS = getenv("KGPU_HOST_CHUNK_SENTS") ? strtoull(getenv("KGPU_HOST_CHUNK_SENTS"), nullptr, 10) : 16384;
+    constexpr int DEPTH = 3;
+    HostJob jobs[DEPTH];
+    int rc = KGPU_OK, njobs = 0;
     uint64_t done = 0, tok_done = 0;
     bool overflow = false;
     tok_offsets[0] = 0;
-    while (done < n || (n == 0 && done == 0)) {
+    int head = 0, inflight = 0;  // jobs[head .. head + inflight) (mod DEPTH) are active, oldest first
+    while (!rc && (done < n || (n == 0 && done == 0 && inflight == 0))) {
+        if (inflight == DEPTH) {
+            rc = host_job_finish(jobs[head], tokens, token_capacity, tok_offsets, status, tok_done, overflow);
+            head = (head + 1) % DEPTH; --inflight;
+            if (rc) break;
+        }
+        HostJob &j = jobs[(head + inflight) % DEPTH];
+        if (!j.c) {
+            {
+                std::lock_guard<std::mutex> g(d->pool_mu);
+                if (!d->pool.empty()) { j.c = d->pool.back(); d->pool.pop_back(); }
+            }
+            if (!j.c && (rc = kgpu_ctx_create(d, nullptr, &j.c))) break;
+            ++njobs;
+        }
         uint64_t m = 0;
-        while (done + m < n && m < HOST_CHUNK_SENTS && (m == 0 || offsets[done + m + 1] - offsets[done] <= HOST_CHUNK_BYTES)) ++m;
-        const uint64_t cap = token_capacity > tok_done ? token_capacity - tok_done : 0;
-        uint64_t got = 0;
-        rc = tokenize_host_chunk(c, utf8, offsets + done, m, tokens ? tokens + (overflow ? 0 : tok_done) : nullptr, overflow ? 0 : cap,
-                                 tok_offsets + done, status ? status + done : nullptr, &got);
-        if (rc == KGPU_ERR_CAPACITY) { overflow = true; rc = KGPU_OK; }
-        if (rc) break;
-        if (!overflow) for (uint64_t i = 0; i <= m; ++i) tok_offsets[done + i] += tok_done;  // chunk-local -> global
-        tok_done += got;
+        while (done + m < n && m < CHUNK_SENTS && (m == 0 || offsets[done + m + 1] - offsets[done] <= CHUNK_BYTES)) ++m;
+        j.lo = done; j.m = m;
+        if ((rc = host_job_submit(j, utf8, offsets))) break;
+        ++inflight;
         done += m;
         if (n == 0) break;
     }
+    while (inflight) {  // drain in order (also after an error: the contexts go back to the pool idle)
+        int r2 = host_job_finish(jobs[head], tokens, token_capacity, tok_offsets, status, tok_done, overflow);
+        if (!rc) rc = r2;
+        head = (head + 1) % DEPTH; --inflight;
+    }
     {
         std::lock_guard<std::mutex> g(d->pool_mu);
-        d->pool.push_back(c);
+        for (int k = 0; k < DEPTH; ++k)
+            if (jobs[k].c) d->pool.push_back(jobs[k].c);
     }
+    (void)njobs;
     if (n_tokens) *n_tokens = tok_done;
     if (!rc && overflow) {
         set_error("token buffer too small: need %llu, capacity %llu", (unsigned long long)tok_done, (unsigned long long)token_capacity);
@@ -686,3 +725,12 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
     }
     return rc;
 }
+
+// Pinned, device-visible host memory for the buffers of kgpu_tokenize_batch: the copies then run as DMA
+// at PCIe speed and overlap the kernels (pageable memory is staged by the runtime, synchronously).
+extern "C" void *kgpu_host_alloc(uint64_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, (size_t)(bytes ? bytes : 1), hipHostMallocDefault) != hipSuccess) { set_error("kgpu_host_alloc: %llu bytes failed", (unsigned long long)bytes); return nullptr; }
+    return p;
+}
+extern "C" void kgpu_host_free(void *p) { if (p) (void)hipHostFree(p); }

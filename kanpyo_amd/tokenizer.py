@@ -23,6 +23,22 @@ TOKEN_DTYPE = np.dtype(
 )
 
 
+def pinned_empty(shape, dtype=np.uint8) -> np.ndarray:
+    """np.empty in pinned host memory (kgpu_host_alloc); freed when the array (and its views) are collected."""
+    import weakref
+
+    dt = np.dtype(dtype)
+    count = int(np.prod(shape)) if not np.isscalar(shape) else int(shape)
+    nbytes = max(count * dt.itemsize, 1)
+    L = _lib.lib()
+    p = L.kgpu_host_alloc(nbytes)
+    if not p:
+        raise MemoryError(L.kgpu_last_error().decode("utf-8", "replace"))
+    buf = (C.c_uint8 * nbytes).from_address(p)
+    weakref.finalize(buf, L.kgpu_host_free, p)
+    return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
+
+
 def pack_sentences(sentences: Sequence) -> tuple:
     """list of str/bytes -> (uint8 concatenation, uint64 offsets[n+1])."""
     enc = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in sentences]
@@ -73,8 +89,13 @@ class Tokenizer:
         return {n: int(getattr(i, n)) for n, _ in i._fields_ if n != "reserved"}
 
     # ---- packed batch: the form the C ABI speaks -------------------------------
-    def tokenize_packed(self, utf8: np.ndarray, offsets: np.ndarray, token_capacity: int | None = None):
-        """-> (tokens[TOKEN_DTYPE], tok_offsets[uint64 n+1], status[uint8 n])."""
+    def tokenize_packed(self, utf8: np.ndarray, offsets: np.ndarray, token_capacity: int | None = None, pinned: bool = False,
+                        out=None):
+        """-> (tokens[TOKEN_DTYPE], tok_offsets[uint64 n+1], status[uint8 n]).
+        pinned=True: the output arrays live in pinned host memory (kgpu_host_alloc), so the device-to-host
+        copies of a large call run as DMA and overlap its kernels; pass inputs made with `pinned_empty` for
+        the same effect on the way in.  out=(tokens, tok_offsets, status): caller-owned result arrays to reuse
+        (a fresh 100 MB array costs more in page faults than the tokenization)."""
         utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = offsets.size - 1
@@ -84,9 +105,18 @@ class Tokenizer:
         cap = int(token_capacity) if token_capacity is not None else total // 2 + n + 64
         L = _lib.lib()
         while True:
-            tokens = np.empty(cap, dtype=TOKEN_DTYPE)
-            toff = np.zeros(n + 1, dtype=np.uint64)
-            status = np.zeros(max(n, 1), dtype=np.uint8)
+            if out is not None:
+                tokens, toff, status = out
+                if tokens.dtype != TOKEN_DTYPE or toff.dtype != np.uint64 or status.dtype != np.uint8 or toff.size < n + 1 or status.size < n:
+                    raise ValueError("out=(tokens[TOKEN_DTYPE], tok_offsets[uint64 >= n+1], status[uint8 >= n])")
+                cap = tokens.size
+                token_capacity = cap  # no silent reallocation of caller-owned arrays
+            else:
+                alloc = pinned_empty if pinned else np.empty
+                tokens = alloc(cap, dtype=TOKEN_DTYPE)
+                toff = alloc(n + 1, dtype=np.uint64)
+                status = alloc(max(n, 1), dtype=np.uint8)
+            status[: max(n, 1)] = 0
             got = C.c_uint64(0)
             rc = L.kgpu_tokenize_batch(
                 self._h, utf8.ctypes.data if utf8.size else None, offsets.ctypes.data, n, tokens.ctypes.data, cap,
@@ -96,7 +126,7 @@ class Tokenizer:
                 cap = int(got.value) + 64  # exact size reported by the device
                 continue
             _lib.check(rc)
-            return tokens[: int(got.value)], toff, status[:n]
+            return tokens[: int(got.value)], toff[: n + 1], status[:n]
 
     # ---- reference-shaped API --------------------------------------------------
     def tokenize_batch(self, sentences: Sequence[str]) -> List[List[Token]]:

@@ -331,6 +331,24 @@ def test_host_entry_point_chunks_and_capacity(small, monkeypatch):
     assert np.array_equal(t2, exp.tokens)
 
 
+def test_large_host_call_is_pipelined_and_pinned_buffers_work(small):
+    """One host call larger than a chunk (three chunks in flight, results delivered in order) with pageable and
+    with pinned (kgpu_host_alloc) buffers."""
+    from kanpyo_amd import synth
+    from kanpyo_amd.tokenizer import pack_sentences, pinned_empty
+
+    sd, tok, orc = small
+    sents = synth.make_corpus(sd, 40000, 41, "cfg2") + [""] + synth.make_corpus(sd, 500, 42, "cfg3")
+    utf8, offs = pack_sentences(sents)
+    exp = orc.tokenize_batch(utf8, offs, 8)
+    t, toff, st = tok.tokenize_packed(utf8, offs)
+    assert np.array_equal(toff, exp.offsets) and np.array_equal(t, exp.tokens) and not st.any()
+    pu = pinned_empty(utf8.shape, np.uint8); pu[:] = utf8
+    po = pinned_empty(offs.shape, np.uint64); po[:] = offs
+    t2, toff2, st2 = tok.tokenize_packed(pu, po, pinned=True)
+    assert np.array_equal(toff2, exp.offsets) and np.array_equal(t2, exp.tokens) and not st2.any()
+
+
 def test_concurrent_callers_share_one_dictionary(small):
     """Tokenizer::tokenize takes &self: concurrent calls on one dictionary are legal (src/tokenizer.rs:16)."""
     import threading
