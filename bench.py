@@ -165,7 +165,7 @@ def main():
                 row_cache[key] = torch.tensor([i % NB for i in range(lo, hi)], device=dev)
             offs = out_off_all.index_select(0, row_cache[key])  # [steps, BATCH + 1] in one gather
             t_post1 = time.perf_counter()
-            gather.post_steps(views, (offs[:, 1:] - offs[:, :-1]).reshape(-1))
+            gather.post_steps(views, (offs[:, 1:] - offs[:, :-1]).reshape(-1), copy_own=False)  # rank 0's own records are already on rank 0
             if os.environ.get("BENCH_DEBUG_GATHER") and rank == 0:
                 print(f"[gather] steps {lo}..{hi}: prepare {1e3 * (t_post1 - t_post0):.3f} ms, post {1e3 * (time.perf_counter() - t_post1):.3f} ms", file=sys.stderr)
 
@@ -173,10 +173,15 @@ def main():
         for c0 in range(0, nsteps, GC):
             if c0 >= 2 * GC:
                 chunks += [(r[0].shape[0], sum(z[0] for z in r[2])) for r in gather.finish() if r is not None]  # chunk c0/GC - 2 has left its buffers
+            t_l0 = time.perf_counter(); t_sync = 0.0
             for i in range(c0, min(c0 + GC, nsteps)):
                 if i >= Q:
+                    t_s0 = time.perf_counter()
                     ntok_of[i - Q] = ctxs[i % Q].sync()  # step i-Q used this ctx: done before it is reused
+                    t_sync += time.perf_counter() - t_s0
                 enqueue(i)
+            if os.environ.get("BENCH_DEBUG_GATHER") and rank == 0:
+                print(f"[loop] chunk at {c0}: {1e3 * (time.perf_counter() - t_l0):.3f} ms, of which waiting in sync {1e3 * t_sync:.3f} ms", file=sys.stderr)
             if c0 >= GC:
                 retire(c0)
                 post(c0 - GC, c0)
@@ -186,6 +191,18 @@ def main():
         chunks += [(r[0].shape[0], sum(z[0] for z in r[2])) for r in gather.finish() if r is not None]
         if rank == 0:
             assert chunks and all(got == want for got, want in chunks)
+
+    if multi:  # untimed set-up of the gather path: index tensors of every chunk shape, allocator blocks of the chunk sizes
+        for c0 in range(0, max(K, W, 1), GC):
+            for total_steps in (K, W):
+                n_st = min(c0 + GC, total_steps) - c0
+                if n_st > 0 and (c0 % NB, n_st) not in row_cache:
+                    row_cache[(c0 % NB, n_st)] = torch.tensor([i % NB for i in range(c0, c0 + n_st)], device=dev)
+        if rank == 0:
+            warm = [torch.empty((world * GC * cap // 3, 6), dtype=torch.int32, device=dev) for _ in range(2)]
+            warm += [torch.empty(world * GC * BATCH, dtype=torch.int64, device=dev) for _ in range(2)]
+            del warm  # stays in torch's caching allocator: no hipMalloc inside the timed region
+        torch.cuda.synchronize()
 
     # ---- warmup (also brings up the RCCL channels of the gather)
     if W > 0:

@@ -149,12 +149,15 @@ class ChunkedGather:
         works = dist.batch_isend_irecv(ops) if ops else []
         self._inflight.append((works, result, (tokens, counts)))
 
-    def post_steps(self, token_views, counts):
+    def post_steps(self, token_views, counts, copy_own: bool = True):
         """Same gather for a chunk made of several steps whose token records live in separate buffers:
         no concatenation on the senders (each view is sent as it is, all sends of the chunk in one
         grouped call), the root receives every view straight into its place of the rank-major
         stream and copies its own views there in one pass.  `token_views`: list of [k_i, 6] tensors
-        (the same number of steps on every rank); `counts`: [n_local] tokens per local sentence."""
+        (the same number of steps on every rank); `counts`: [n_local] tokens per local sentence.
+        copy_own=False: the root's own records are already where the gather wants them (on the root), so
+        they are left in their buffers -- the root's slice of the returned stream is then uninitialised and
+        its views are returned as a fourth element instead."""
         import torch
         import torch.distributed as dist
 
@@ -181,7 +184,7 @@ class ChunkedGather:
             for r, row in enumerate(table):
                 nt, nc = sizes[r]
                 if r == rank:
-                    if nt:
+                    if nt and copy_own:
                         torch.cat([v for v in token_views if v.shape[0]], out=tok_all[t0 : t0 + nt])
                     cnt_all[c0 : c0 + nc].copy_(counts)
                 else:
@@ -194,7 +197,7 @@ class ChunkedGather:
                         ops.append(dist.P2POp(dist.irecv, cnt_all[c0 : c0 + nc], r, self.group))
                 t0 += nt
                 c0 += nc
-            result = (tok_all, cnt_all, sizes)
+            result = (tok_all, cnt_all, sizes) if copy_own else (tok_all, cnt_all, sizes, list(token_views))
         else:
             for v in token_views:
                 if v.shape[0]:

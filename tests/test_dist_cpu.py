@@ -126,10 +126,13 @@ def _worker_steps(rank, world, port, tmpdir):
             for j in range(4):
                 nt = 0 if (rank + j + c) % 4 == 0 else 3 * (rank + 1) + j
                 views.append(torch.full((nt, 6), 100 * c + 10 * j + rank, dtype=torch.int32))
-            g.post_steps(views, torch.full((2 + rank,), c, dtype=torch.int64))
+            g.post_steps(views, torch.full((2 + rank,), c, dtype=torch.int64), copy_own=size_group is None)
         res = g.finish()
         if rank == 0:
-            for c, (tok_all, cnt_all, sizes) in enumerate(res):
+            for c, r_ in enumerate(res):
+                tok_all, cnt_all, sizes = r_[0], r_[1], r_[2]
+                if len(r_) == 4:  # copy_own=False: the root's slice is left to the caller
+                    torch.cat([v for v in r_[3] if v.shape[0]], out=tok_all[: sizes[0][0]]) if sizes[0][0] else None
                 exp = []
                 for r in range(world):
                     for j in range(4):
