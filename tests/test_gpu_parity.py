@@ -114,6 +114,18 @@ def test_cfg5_long_documents(full):
     assert_same(tok, orc, sents)
 
 
+def test_cfg3_and_cfg5_at_scale(full):
+    """The routing between the pool kernel and the long-sentence kernel under a realistic mix, several batches
+    deep (the reservation estimate and the optional-launch heuristics adapt from batch to batch)."""
+    from kanpyo_amd import synth
+
+    sd, tok, orc = full
+    mixed = synth.make_corpus(sd, 20000, 7, "cfg3")
+    for lo in range(0, len(mixed), 4096):
+        assert_same(tok, orc, mixed[lo : lo + 4096], nthreads=16)
+    assert_same(tok, orc, synth.make_corpus(sd, 300, 8, "cfg5") + synth.make_corpus(sd, 3000, 9, "cfg2"), nthreads=16)
+
+
 def test_edge_cases(full):
     sd, tok, orc = full
     kata = "ア" * 1500  # one groupable run beyond MAXIMUM_UNKNOWN_WORD_LENGTH (lattice.rs:55,80)
