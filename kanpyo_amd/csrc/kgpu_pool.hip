@@ -487,13 +487,12 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
                             const uint32_t cs = nCS[tt];  // finalisation operands ride in the same round trip
                             const int32_t cost = (int32_t)(int16_t)cs;
                             const uint32_t sl = cs >> 16;
-                            int32_t v = 0x7FFFFFFF;  // a real total is at most INF + 32767
-                            uint32_t nd = 0xFFFFFFFFu;
-                            if (tv && j < P) {
-                                const uint2 e = bk[p0 + j];
-                                v = (int32_t)e.x + (int32_t)mpair[eb + ti * P + j];
-                                nd = e.y >> 16;
-                            }
+                            // unconditional loads at clamped (always valid) indices: no exec-mask region in the chain
+                            const bool valid = tv && j < P;
+                            const uint2 e = bk[p0 + (valid ? j : 0u)];
+                            const int32_t pc = (int32_t)mpair[eb + (valid ? ti * P + j : 0u)];
+                            const int32_t v = valid ? (int32_t)e.x + pc : 0x7FFFFFFF;  // a real total is at most INF + 32767
+                            const uint32_t nd = e.y >> 16;
                             const int32_t vmin = group_min_i32<LG>(v);
                             const uint32_t nmin = group_min_u32<LG>(v == vmin ? nd : 0xFFFFFFFFu);
                             if (tv && j == 0) {
