@@ -143,11 +143,16 @@ def build_dict(n_records: int = 392_000, seed: int = SEED_DICT, n_context: int =
     nrec[:n_single_hira] = rng.integers(3, 9, size=n_single_hira)
     diff = n_records - int(nrec.sum())
     i = n_single_hira
+    idle = 0
     while diff != 0:  # hit the record count exactly
         if diff > 0 and nrec[i] < 8:
-            nrec[i] += 1; diff -= 1
+            nrec[i] += 1; diff -= 1; idle = 0
         elif diff < 0 and nrec[i] > 1:
-            nrec[i] -= 1; diff += 1
+            nrec[i] -= 1; diff += 1; idle = 0
+        else:
+            idle += 1
+            if idle > len(words):
+                raise ValueError(f"build_dict: {n_records} records cannot be met with {len(words)} surfaces (use >= 5000 records)")
         i = i + 1 if i + 1 < len(words) else n_single_hira
     total = int(nrec.sum())
     surf_of = np.repeat(np.arange(len(words)), nrec)

@@ -131,8 +131,11 @@ class OracleTokenizer:
         return cls(d.index_dict, d.connection_dict, d.morph_dict, d.unk_dict, d.char_category, d.invoke_list, d.group_list)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().korc_dict_free(self._h)
+        if getattr(self, "_h", None) and lib is not None:  # `lib` is gone during interpreter shutdown
+            try:
+                lib().korc_dict_free(self._h)
+            except Exception:
+                pass
             self._h = None
 
     def common_prefix(self, text):

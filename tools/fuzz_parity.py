@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Randomised GPU-vs-oracle parity sweep (GPU box): random dictionary sizes, corpus mixes, pool / long-kernel
+shapes, batch sizes.  usage: python tools/fuzz_parity.py [seconds] [seed]"""
+import os
+import random
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa: F401  (first: shares one HIP runtime)
+
+from kanpyo_amd import Tokenizer, synth
+from kanpyo_amd.tokenizer import pack_sentences
+from oracle import oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t_end = time.time() + budget
+rounds = sentences = 0
+EDGE = ["", "あ", "ア" * 700, "a" * 300, "𠮷野家で𩸽", "すもももももももものうち", "　　", "1234567890" * 40, "。" * 65]
+while time.time() < t_end:
+    nkeys = rng.choice([6000, 12000, 20000, 60000])
+    pool = rng.choice(["0", "8:2:64", "16:4:32", "40:8:20", "80:8:20", "80:10:64", "160:16:64", "80:8:20,160:4:64", "24:3:48"])
+    long_kib = rng.choice(["0", "4", "12", "32", "160"])
+    os.environ["KGPU_POOL"], os.environ["KGPU_LONG"] = pool, long_kib
+    sd = synth.build_dict(nkeys, seed=rng.randrange(1 << 30))
+    tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
+    print(f"[{time.time() - (t_end - budget):6.1f}s] keys={nkeys} pool={pool} long={long_kib}", flush=True)
+    for _ in range(3):
+        mix = []
+        mix += synth.make_corpus(sd, rng.choice([1, 50, 700, 4096, 9000]), rng.randrange(1 << 30), "cfg2")
+        if rng.random() < 0.7:
+            mix += synth.make_corpus(sd, rng.choice([3, 100, 600]), rng.randrange(1 << 30), "cfg3")
+        if rng.random() < 0.3:
+            mix += synth.make_corpus(sd, rng.choice([1, 4]), rng.randrange(1 << 30), "cfg5")
+        mix += rng.sample(EDGE, rng.randrange(len(EDGE)))
+        rng.shuffle(mix)
+        utf8, offs = pack_sentences(mix)
+        exp = orc.tokenize_batch(utf8, offs, 16)
+        print(f"    n={len(mix)} bytes={int(offs[-1])} ...", end="", flush=True)
+        got_t, got_off, status = tok.tokenize_packed(utf8, offs)
+        print(" done", flush=True)
+        ok = np.array_equal(got_off, exp.offsets) and np.array_equal(got_t, exp.tokens) and not status.any()
+        if not ok:
+            print(f"MISMATCH keys={nkeys} pool={pool} long={long_kib} n={len(mix)}")
+            sys.exit(1)
+        rounds += 1
+        sentences += len(mix)
+print(f"fuzz ok: {rounds} batches, {sentences} sentences, bit-exact")
