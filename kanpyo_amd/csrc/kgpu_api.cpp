@@ -116,7 +116,7 @@ struct kgpu_ctx {
     // last enqueued batch (for the arena-overflow retry and for sync)
     BatchArgs last{};
     bool pending = false;
-    TierPlan plan{};
+    LaunchPlan plan{};
     DevBuf ovf;
     // profiling
     bool profiling = false;   // KGPU_PROFILE_EVENTS
@@ -414,7 +414,7 @@ extern "C" int kgpu_ctx_create(kgpu_dict *d, void *hip_stream, kgpu_ctx **out) {
         kgpu_ctx_destroy(c);
         return KGPU_ERR_HIP;
     }
-    c->plan = default_tier_plan(d->device);
+    c->plan = default_launch_plan(d->device);
     *out = c;
     return KGPU_OK;
 }
@@ -604,7 +604,6 @@ extern "C" int kgpu_ctx_get_profile(kgpu_ctx *c, kgpu_profile *out, int reset) {
 
 // ------------------------------------------------------- host-buffer entry point
 
-// One chunk of the host-buffer entry point: H2D, tier chain, D2H on the ctx stream.
 // ---- host-buffer entry point ---------------------------------------------------------------------------
 // One chunk of a host call in flight on one pooled context: H2D + kernels enqueued, results still on the device.
 struct HostJob {

@@ -122,22 +122,22 @@ __device__ __forceinline__ uint32_t da_walk_first(const DictView &d, const uint8
     return steps;
 }
 
-// Work-list plumbing shared by the tier kernels: tier k takes its sentence ids
-// from list `in_list` (nullptr = identity over [0, n)) and pushes the ones whose
-// lattice does not fit its memory budget onto the next tier's list.  Work is a
-// static grid-stride over the list: the list length is final when the tier's
+// Work-list plumbing shared by the kernels of a launch chain: launch k takes its sentence ids
+// from list `in_list` (nullptr = identity over [0, n)) and pushes the ones it does not
+// serve (LDS budget, routing) onto the next launch's list.  Work is a
+// static grid-stride over the list: the list length is final when the
 // kernel starts (same stream), and there is no hot dequeue word -- a single
 // contended atomic serialises at ~90 ops/us chip-wide, which is most of a
 // 4096-sentence batch.
-struct TierIO {
+struct WorkIO {
     const uint32_t *in_list;        // nullptr: sentence id == work index
     const unsigned int *in_count;   // nullptr: a.n
-    uint32_t *out_list;             // overflow list for the next tier (nullptr: none)
+    uint32_t *out_list;             // work list of the next launch (nullptr: none)
     unsigned int *out_count;
     unsigned int *late_count;       // deferrals that happened after the walk (feeds the routing estimate)
 };
 
-__device__ __forceinline__ bool tier_next(const TierIO &io, const BatchArgs &a, uint32_t iter, uint64_t &s) {
+__device__ __forceinline__ bool work_next(const WorkIO &io, const BatchArgs &a, uint32_t iter, uint64_t &s) {
     const uint64_t i = (uint64_t)blockIdx.x + (uint64_t)iter * gridDim.x;
     if (!io.in_list) { s = i; return i < a.n; }
     const uint64_t n = (uint64_t)bcast32(__hip_atomic_load(io.in_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -146,14 +146,14 @@ __device__ __forceinline__ bool tier_next(const TierIO &io, const BatchArgs &a, 
     return true;
 }
 // Same, for kernels whose workers are wavefronts of larger workgroups: the caller supplies the work index.
-__device__ __forceinline__ bool tier_next_at(const TierIO &io, const BatchArgs &a, uint64_t i, uint64_t &s) {
+__device__ __forceinline__ bool work_next_at(const WorkIO &io, const BatchArgs &a, uint64_t i, uint64_t &s) {
     if (!io.in_list) { s = i; return i < a.n; }
     const uint64_t n = (uint64_t)bcast32(__hip_atomic_load(io.in_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (i >= n) return false;
     s = (uint64_t)bcast32(io.in_list[i]);
     return true;
 }
-__device__ __forceinline__ void tier_defer(const TierIO &io, uint32_t lane, uint64_t s) {
+__device__ __forceinline__ void work_defer(const WorkIO &io, uint32_t lane, uint64_t s) {
     if (lane == 0) {
         unsigned int k = atomicAdd(io.out_count, 1u);
         io.out_list[k] = (uint32_t)s;

@@ -43,7 +43,7 @@ struct DictView {
 
 // ---- per-ctx control block in device memory (zeroed before every batch) ---
 struct Control {
-    unsigned int ovf_count[4];        // sentences deferred from tier k to tier k+1
+    unsigned int ovf_count[4];        // sentences handed from launch k to launch k+1
     unsigned int late_count[4];       // ... of which only after the trie walk had been paid for
     unsigned long long arena_cursor;  // bump allocator over the scratch arena (bytes)
     unsigned int arena_overflow;      // a slab request did not fit
@@ -65,15 +65,15 @@ struct BatchArgs {
     kgpu_token *out;  uint64_t out_cap;      // dense output
     uint64_t *tok_offsets;        // n+1
     uint32_t count_work;          // accumulate kgpu_work into ctl->work (slow; off in timed runs)
-    uint32_t *ovf[4];             // n entries each: work lists of tiers 1.. (filled by the tier before)
-    uint32_t est_q8;              // expected LDS bytes per input byte (x256): early tier routing
+    uint32_t *ovf[4];             // n entries each: work lists of launches 1.. (filled by the launch before)
+    uint32_t est_q8;              // expected LDS bytes per input byte (x256): reservation size and length routing
 };
 
 // Launch plan of one batch: the LDS page-pool kernel (kgpu_pool.hip) once or twice -- W independent
 // wavefronts per workgroup share pool_bytes of LDS, each sentence takes what it needs -- then the
 // general kernel, whose lattices live in HBM scratch, for whatever fits no pool.  A sentence that
 // a launch cannot serve is pushed onto the next launch's work list.
-struct TierPlan {
+struct LaunchPlan {
     int n_pools;
     uint32_t pool_bytes[2];
     uint32_t pool_waves[2];
@@ -87,8 +87,8 @@ struct TierPlan {
 // Launchers (kgpu_kernels.hip).  `stream` is a hipStream_t.
 // n_pools_now <= plan.n_pools: how many of the pool launches to issue for this batch (the chain
 // stays complete without the later ones: their work falls through to the next launch).
-int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan, int n_pools_now, bool long_now, void *stream);
+int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now, void *stream);
 int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream);  // host_ctl: device pointer of the pinned result block
-TierPlan default_tier_plan(int device);
+LaunchPlan default_launch_plan(int device);
 
 }  // namespace kgpu

@@ -73,7 +73,7 @@ __device__ __forceinline__ void wave_fence() {
 }  // namespace
 
 template <bool LDS_SWEEP>
-__global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a, TierIO io, uint32_t lds_bytes,
+__global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a, WorkIO io, uint32_t lds_bytes,
                                                           uint32_t stop_after /* ablation timing only */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
 
     for (uint32_t iter = 0;; ++iter) {
         uint64_t s = 0;
-        if (!tier_next(io, a, iter, s)) break;
+        if (!work_next(io, a, iter, s)) break;
 
         const uint64_t b0 = a.offsets[s];
         const uint32_t B = (uint32_t)(a.offsets[s + 1] - b0);
@@ -612,19 +612,19 @@ __global__ __launch_bounds__(256) void k_compact(BatchArgs a) {
     }
 }
 
-int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t pool_bytes, uint32_t waves,
+int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t pool_bytes, uint32_t waves,
                          uint32_t max_pages, int n_workgroups, void *stream);  // kgpu_pool.hip
 int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
 
 // Launch chain: pool kernel(s), then the general (HBM scratch) kernel.  Every launch is a
 // persistent grid over its work list (the first one: the identity over [0, n)).
-int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan, int n_pools_now, bool long_now, void *stream) {
+int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now, void *stream) {
     Control *ctl = a.ctl;
     const uint32_t *in_list = nullptr;
     const unsigned int *in_count = nullptr;
     int li = 0;  // next free work list
     for (int k = 0; k < plan.n_pools && k < n_pools_now; ++k, ++li) {
-        TierIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], &ctl->late_count[li]};
+        WorkIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], &ctl->late_count[li]};
         uint64_t wg = plan.pool_workgroups[k];
         const uint64_t want = (a.n + plan.pool_waves[k] - 1) / plan.pool_waves[k];
         if (!in_list && want < wg) wg = want;
@@ -636,7 +636,7 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan,
     if (getenv("KGPU_DEBUG_SKIP_GENERAL")) return 0;
     static const uint32_t stop_after = getenv("KGPU_DEBUG_STOP") ? (uint32_t)atoi(getenv("KGPU_DEBUG_STOP")) : 0u;
     if (long_now && plan.long_lds_bytes) {  // HBM lattice + LDS-blocked sweep; takes its whole list, leaves none
-        TierIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], nullptr};
+        WorkIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], nullptr};
         uint64_t wg = plan.long_workgroups;
         if (!in_list && a.n < wg) wg = a.n;
         if (plan.long_lds_bytes > 64 * 1024) {
@@ -649,7 +649,7 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const TierPlan &plan,
         in_count = &ctl->ovf_count[li];
         ++li;
     }
-    TierIO io{in_list, in_count, nullptr, nullptr, nullptr};
+    WorkIO io{in_list, in_count, nullptr, nullptr, nullptr};
     uint64_t wg = plan.general_workgroups;
     if (!in_list && a.n < wg) wg = a.n;
     hipLaunchKernelGGL(k_tokenize_general<false>, dim3((unsigned)(wg ? wg : 1)), dim3(64), 0, (hipStream_t)stream, d, a, io, 0u, stop_after);
@@ -666,11 +666,11 @@ int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream) {
     return (int)hipGetLastError();
 }
 
-TierPlan default_tier_plan(int device) {
+LaunchPlan default_launch_plan(int device) {
     hipDeviceProp_t p;
     int cus = 256;
     if (hipGetDeviceProperties(&p, device) == hipSuccess) cus = p.multiProcessorCount;
-    TierPlan t{};
+    LaunchPlan t{};
     t.general_workgroups = cus * 2;  // the last resort is rarely needed: few workgroups, so that an empty launch drains quickly on a busy chip
     // long-sentence kernel (HBM lattice, LDS-blocked sweep): KGPU_LONG="<KiB>" per single-wavefront workgroup, "0" = off
     {

@@ -141,7 +141,7 @@ __device__ __forceinline__ uint32_t pool_wait_alloc(uint64_t *bm, uint32_t k, ui
 // instantiation, because the 16 wave-uniform u64 accumulators + 9 ticks cost ~50 of the 102 SGPRs
 // and push the plain kernel into SGPR spilling (v_readlane / v_writelane traffic on the VALU).
 template <bool PROF>
-__global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a, TierIO io, uint32_t pool_bytes, uint32_t max_pages,
+__global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a, WorkIO io, uint32_t pool_bytes, uint32_t max_pages,
                                                         uint32_t stop_after /* ablation timing only; 0 = run everything */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t pool[];
     const uint32_t lane = threadIdx.x & 63u, wave = bcast32(threadIdx.x >> 6) /* SGPR: everything per-sentence is wave-uniform */, W = blockDim.x >> 6;
@@ -157,11 +157,11 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
     for (uint32_t iter = 0;; ++iter) {
         uint64_t s = 0;
         // sentence i of the work list -> workgroup i mod G, wavefront (i / G) mod W
-        if (!tier_next_at(io, a, (uint64_t)blockIdx.x + (uint64_t)gridDim.x * (wave + (uint64_t)W * iter), s)) break;
+        if (!work_next_at(io, a, (uint64_t)blockIdx.x + (uint64_t)gridDim.x * (wave + (uint64_t)W * iter), s)) break;
         const uint64_t b0 = a.offsets[s];
         const uint64_t Bl = a.offsets[s + 1] - b0;
         const uint32_t pool_cap = page * POOL_PAGES;
-        if (Bl + 64 > pool_cap || Bl > 0xFFF0) { tier_defer(io, lane, s); continue; }
+        if (Bl + 64 > pool_cap || Bl > 0xFFF0) { work_defer(io, lane, s); continue; }
         const uint32_t B = (uint32_t)Bl;
         const uint8_t *gtext = a.utf8 + b0;
         // chars of the sentence (sizes the per-position arrays); the bytes are re-read from L1 below
@@ -179,9 +179,9 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         uint32_t npg = (est + page - 1) / page;
         // routing: a sentence expected to need more than max_pages would hold a large part of the pool for a long
         // time (LDS x time grows with the square of the length); it is better served by the long-sentence kernel
-        if (npg > max_pages) { tier_defer(io, lane, s); continue; }
+        if (npg > max_pages) { work_defer(io, lane, s); continue; }
         uint32_t pg = pool_wait_alloc(bm, npg, lane);
-        if (pg == NONE) { tier_defer(io, lane, s); continue; }
+        if (pg == NONE) { work_defer(io, lane, s); continue; }
         for (uint32_t attempt = 0;; ++attempt) {  // at most one redo, with the exact size
         uint8_t *smem = pool + POOL_HDR + pg * page;
         const uint32_t lds_bytes = npg * page;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
                 }
             }
         }
-        if (__ballot(ovf != 0) != 0) { tier_defer(io, lane, s); break; }
+        if (__ballot(ovf != 0) != 0) { work_defer(io, lane, s); break; }
         if (lane == 0) {
             nb[C] = 1;       // EOS starts at C (lattice.rs:165-175)
             nb[C + 1] = 0;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         const uint32_t off_emit_end = off;                          // everything above is written by emit
         uint16_t *pre = (uint16_t *)(smem + off);   off += align_up(2 * N, 4);  // may overlay the match buffer
         int16_t *mpair = (int16_t *)(smem + off);
-        if (N > 0xFFFF) { tier_defer(io, lane, s); break; }
+        if (N > 0xFFFF) { work_defer(io, lane, s); break; }
         // exact requirement: emit-written arrays stay below the match buffer; afterwards pre + the
         // pair table (whole, so that the sweep is one block) overlay it
         const uint32_t need_emit = off_emit_end + mbytes + 16, need_full = off + min(2 * E, max(2 * maxpairs, PAIR_CAP));
@@ -352,10 +352,10 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
             pool_free(bm, pg, 0, npg, lane);
             if (lane == 0) atomicAdd(io.late_count, 1u);
             pg = NONE;
-            if ((max(need_emit, off + 2 * maxpairs) + page - 1) / page > max_pages || attempt != 0) { tier_defer(io, lane, s); break; }
+            if ((max(need_emit, off + 2 * maxpairs) + page - 1) / page > max_pages || attempt != 0) { work_defer(io, lane, s); break; }
             npg = min(max_pages, (max(need_emit, need_full) + page - 1) / page);
             pg = pool_wait_alloc(bm, npg, lane);
-            if (pg == NONE) { tier_defer(io, lane, s); break; }
+            if (pg == NONE) { work_defer(io, lane, s); break; }
             continue;
         }
         wave_sync();
@@ -612,7 +612,7 @@ int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves) {
     return n;
 }
 
-int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const TierIO &io, uint32_t pool_bytes, uint32_t waves,
+int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t pool_bytes, uint32_t waves,
                          uint32_t max_pages, int n_workgroups, void *stream) {
     static const uint32_t stop_after = getenv("KGPU_DEBUG_STOP") ? (uint32_t)atoi(getenv("KGPU_DEBUG_STOP")) : 0u;
     if (pool_bytes > 64 * 1024) {  // beyond the default dynamic-LDS cap the kernel has to opt in
