@@ -37,6 +37,16 @@ def algorithmic_bytes(w):
     return a, b, c
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,6 +291,22 @@ def main():
         },
     }
 
+    # ---- the box's own streaming-read bandwidth (a 4 GiB int64 reduction, best of 5): second denominator of the roofline
+    if world == 1:
+        try:
+            x = torch.empty(1 << 29, dtype=torch.int64, device=dev).fill_(1)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            best = 0.0
+            for _ in range(6):
+                ev0.record(); x.sum(); ev1.record(); ev1.synchronize()
+                best = max(best, x.numel() * 8 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9)
+            del x
+            result["roofline"]["peak_measured_read"] = best
+            result["roofline"]["frac_of_measured_read"] = achieved / best
+        except Exception as e:  # never let the auxiliary measurement break the bench line
+            result["roofline"]["peak_measured_read"] = None
+            print(f"streaming-read measurement skipped: {e}", file=sys.stderr)
+
     # ---- host-buffer entry point (H2D + kernels + D2H per batch): the PCIe-inclusive rate, never `value`
     if world == 1:
         from kanpyo_amd.tokenizer import TOKEN_DTYPE, pinned_empty
@@ -332,7 +358,7 @@ def main():
         exact = bool(np.array_equal(g_off.astype(np.uint64), exp0.offsets[: BATCH + 1])
                      and np.array_equal(g_tok.reshape(-1), exp0.tokens[:n0].view(np.int32).reshape(-1).astype(np.int32)))
         result["cpu_baseline"] = {
-            "value": done / t_cpu, "unit": "sentences/s", "cores": 1, "kind": "port",
+            "value": done / t_cpu, "unit": "sentences/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"the same 100k-sentence cfg2 corpus, {done // len(corpus)} pass(es), {t_cpu:.1f} s, "
                       "oracle/kanpyo_oracle.c (CPU restatement of Kanpyo's algorithm, gcc -O2), single thread",
             "all_cores": {"value": len(corpus) / t_all, "cores": ncores},
