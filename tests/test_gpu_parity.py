@@ -126,6 +126,18 @@ def test_cfg3_and_cfg5_at_scale(full):
     assert_same(tok, orc, synth.make_corpus(sd, 300, 8, "cfg5") + synth.make_corpus(sd, 3000, 9, "cfg2"), nthreads=16)
 
 
+def test_one_very_long_sentence(full):
+    """100 000 characters in one sentence (over a million lattice nodes: 32-bit node indices, global
+    counters instead of the LDS cursors, many backtrace windows) next to ordinary ones."""
+    from kanpyo_amd import synth
+
+    sd, tok, orc = full
+    parts = synth.make_corpus(sd, 2600, 13, "cfg2")
+    long_one = "".join(parts)[:100000]
+    assert len(long_one) == 100000
+    assert_same(tok, orc, ["短い文", long_one, "", "もう一つ"], nthreads=2)
+
+
 def test_edge_cases(full):
     sd, tok, orc = full
     kata = "ア" * 1500  # one groupable run beyond MAXIMUM_UNKNOWN_WORD_LENGTH (lattice.rs:55,80)
