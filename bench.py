@@ -4,13 +4,26 @@ Tokenizer::tokenize on MI355X, synthetic IPADIC-shaped dictionary.
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
-A "step" is one pass of the hot path over one batch of 4096 sentences
-(BASELINE.json configs[1]: 100k synthetic ~40-char sentences, batch=4096), with
-the batch already resident in HBM and the dense token stream left in HBM.
-Multi-GPU is weak scaling: every rank owns its own 100k-sentence shard
-(sentences shard with no data-path collective); the only communication is one
-gatherv of the token records to rank 0 at the end of the timed region.
-Rank 0 prints ONE JSON line.
+A STEP is one pass of the hot path over one whole 100 000-sentence corpus in
+batches of 4096 (24 full batches and the 1 696-sentence tail), inputs resident in
+HBM, dense token streams left in HBM.
+
+  N = 1   BASELINE configs[1] (SURVEY 8d cfg 2): the seed-1 corpus, every step.
+  N > 1   BASELINE configs[3] (cfg 4): step k is the corpus of seed 100 + k (cycled
+          over the corpora generated), sentence i -> GPU i mod N, dictionary
+          replicated, no data-path collective; the token records of every step are
+          gathered to rank 0 (flat gatherv over xGMI) inside the timed region, so
+          `value` is the whole job's rate and `scaling` is "strong" (the work of a
+          step does not grow with N).
+
+Rank 0 prints ONE JSON line.  At N = 1 it also carries: the per-launch and per-stage
+roofline (HIP events around the kernels; stage split by the runtime's measurement-only
+ablation mode), the other single-GPU configs as `extra` lines (cfg 3, cfg 5), call
+latencies of the host-buffer entry point, and the CPU baseline (the oracle restatement
+timed single-pass on the host cores).
+
+run_job() / Workload are importable: tests/test_dist_cpu.py drives them with world
+size 2 over gloo and a CPU engine.
 """
 import argparse
 import json
@@ -26,6 +39,7 @@ sys.path.insert(0, ROOT)
 BATCH = 4096
 N_SENT = 100_000
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CHIP_SIMDS, CHIP_CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md)
 
 
 def algorithmic_bytes(w):
@@ -47,16 +61,255 @@ def cpu_model():
     return "unknown"
 
 
+# ------------------------------------------------------------------ workload
+
+class Workload:
+    """The batches one rank owns: for every corpus, the sentences i with i mod world == rank
+    (kanpyo_amd.dist.shard_indices) in ascending order, cut into batches of at most `batch`."""
+
+    def __init__(self, corpora, rank=0, world=1, batch=BATCH):
+        from kanpyo_amd.dist import shard_indices
+        from kanpyo_amd.tokenizer import pack_sentences
+
+        self.rank, self.world, self.batch = rank, world, batch
+        self.n_total = [len(c) for c in corpora]
+        self.packed = []  # [corpus][b] = (utf8 uint8[], offsets uint64[n+1])
+        for c in corpora:
+            mine = shard_indices(len(c), rank, world)
+            local = [c[i] for i in mine]
+            self.packed.append([pack_sentences(local[lo : lo + batch]) for lo in range(0, max(len(local), 1), batch)])
+
+    def n_corpora(self):
+        return len(self.packed)
+
+    def nb(self, step):
+        return len(self.packed[step % len(self.packed)])
+
+    def sentences(self, step):  # local
+        return sum(len(o) - 1 for _, o in self.packed[step % len(self.packed)])
+
+    def bytes_in(self, step):
+        return sum(int(o[-1]) for _, o in self.packed[step % len(self.packed)])
+
+    def cap(self):  # tokens <= chars + 1 <= bytes + 1 per sentence: never too small
+        return max(int(o[-1]) + len(o) - 1 for p in self.packed for _, o in p) + 8
+
+
+class GpuEngine:
+    """Q device contexts over shared streams; inputs uploaded once, every batch's dense tokens stay in HBM in
+    a ring of output buffers (`ring` steps deep: a step's records must survive until its gather is through)."""
+
+    def __init__(self, tok, dev, wl, queue=6, streams=3, ring=1):
+        import torch
+
+        from kanpyo_amd.device import DeviceContext
+
+        self.torch, self.dev, self.wl, self.Q, self.ring = torch, dev, wl, max(1, queue), ring
+        self.inputs = [[(torch.from_numpy(u.copy()).to(dev), torch.from_numpy(o.astype(np.int64)).to(dev), len(o) - 1, int(o[-1]))
+                        for u, o in p] for p in wl.packed]
+        self.cap = wl.cap()
+        nbmax = max(len(p) for p in wl.packed)
+        self.out = [[(torch.empty((self.cap, 6), dtype=torch.int32, device=dev),
+                      torch.empty(wl.batch + 1, dtype=torch.int64, device=dev),
+                      torch.empty(wl.batch, dtype=torch.uint8, device=dev)) for _ in range(nbmax)] for _ in range(ring)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, min(streams, self.Q)))]
+        self.ctxs = [DeviceContext(tok, self.streams[i % len(self.streams)].cuda_stream) for i in range(self.Q)]
+        self.seq, self.occupant, self.where, self.ntok = 0, [None] * self.Q, {}, {}
+
+    def nb(self, step):
+        return self.wl.nb(step)
+
+    def enqueue(self, step, b):
+        i = self.seq % self.Q
+        self.seq += 1
+        if self.occupant[i] is not None:
+            self.ntok[self.occupant[i]] = self.ctxs[i].sync()
+        d_utf8, d_off, n, total = self.inputs[step % len(self.inputs)][b]
+        t, o, st = self.out[step % self.ring][b]
+        self.ctxs[i].tokenize(d_utf8.data_ptr(), d_off.data_ptr(), n, total, t.data_ptr(), self.cap, o.data_ptr(), st.data_ptr())
+        self.occupant[i] = (step, b)
+        self.where[(step, b)] = i
+
+    def _retire(self, key):
+        if key not in self.ntok:
+            i = self.where[key]
+            self.ntok[key] = self.ctxs[i].sync()
+            self.occupant[i] = None
+        self.where.pop(key, None)
+        return self.ntok.pop(key)
+
+    def results(self, step):
+        """Waits for the step's batches; -> (token views [k, 6] int32, per-sentence token counts int64), all in HBM."""
+        views, counts = [], []
+        for b in range(self.nb(step)):
+            k = self._retire((step, b))
+            t, o, _ = self.out[step % self.ring][b]
+            n = self.inputs[step % len(self.inputs)][b][2]
+            views.append(t[:k])
+            counts.append(o[1 : n + 1] - o[:n])
+        return views, (self.torch.cat(counts) if counts else self.torch.zeros(0, dtype=self.torch.int64, device=self.dev))
+
+    def after_gather(self):
+        """Order the contexts' streams behind the transfers just waited for: on the RCCL backend work.wait() only makes
+        torch's current stream wait, neither the host nor the streams the tokenize kernels run on."""
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.dev))
+        for st in self.streams:
+            st.wait_event(ev)
+
+    def drain(self):
+        for i, c in enumerate(self.ctxs):
+            if self.occupant[i] is not None:
+                self.ntok[self.occupant[i]] = c.sync()
+                self.occupant[i] = None
+        self.where.clear()
+        self.ntok.clear()
+        self.torch.cuda.synchronize()
+
+    def close(self):
+        self.drain()
+        for c in self.ctxs:
+            c.close()
+
+
+def run_job(engine, nsteps, gather=None, chunk_steps=1, on_chunk=None):
+    """Exactly `nsteps` steps.  With `gather` (a kanpyo_amd.dist.ChunkedGather; every rank passes one): the token
+    records of every step travel to the root in chunks of `chunk_steps` steps -- chunk c is posted once chunk
+    c + 1 has been enqueued (so it travels while c + 1 is tokenized) and must have left its buffers before chunk
+    c + 3 is enqueued (the engine's output ring is three chunks deep).  on_chunk(first_step, result) is called on
+    every rank for every finished chunk (result is None off the root)."""
+    if gather is None:
+        for s in range(nsteps):
+            for b in range(engine.nb(s)):
+                engine.enqueue(s, b)
+        engine.drain()
+        return
+    posted = []  # first step of every chunk posted, in order; finished ones are consumed from the front
+
+    def post(c0):
+        views, counts = [], []
+        for s in range(c0, min(c0 + chunk_steps, nsteps)):
+            v, c = engine.results(s)
+            views += v
+            counts.append(c)
+        import torch
+
+        gather.post_steps(views, torch.cat(counts), copy_own=True)
+        posted.append(c0)
+
+    def finish_all():
+        for c0, r in zip(posted, gather.finish()):
+            if on_chunk is not None:
+                on_chunk(c0, r)
+        posted.clear()
+        engine.after_gather()  # the engine may overwrite those chunks' buffers only behind the transfers
+
+    starts = list(range(0, nsteps, chunk_steps))
+    for k, c0 in enumerate(starts):
+        if k >= 2:
+            finish_all()  # chunks <= k - 2: their buffers are free again (chunk k reuses chunk k - 3's ring slot)
+        for s in range(c0, min(c0 + chunk_steps, nsteps)):
+            for b in range(engine.nb(s)):
+                engine.enqueue(s, b)
+        if k >= 1:
+            post(starts[k - 1])
+    if starts:
+        post(starts[-1])
+    finish_all()
+    engine.drain()
+
+
+def chunk_steps_for(nb_per_step):
+    """Steps per gather chunk: about a dozen batches, so that the host side of a gather (size exchange, one
+    grouped send/recv call) stays a small part of the chunk whatever the rank count."""
+    return max(1, -(-12 // max(nb_per_step, 1)))
+
+
+# ------------------------------------------------------------------ extras (N = 1)
+
+def _extras_child(sd, outdir, cfg3_n):
+    """Forked before any GPU state exists: generates the other single-GPU configs' corpora while the parent
+    runs the headline legs (the generator is a pure-Python loop: ~1 minute per million cfg 3 sentences)."""
+    from kanpyo_amd import synth
+    from kanpyo_amd.tokenizer import pack_sentences
+
+    for kind, n, seed in (("cfg5", 1000, 5), ("cfg3", cfg3_n, 2)):
+        sents = synth.make_corpus(sd, n, seed, kind)
+        utf8, offs = pack_sentences(sents)
+        np.save(os.path.join(outdir, kind + "_utf8.npy"), utf8)
+        np.save(os.path.join(outdir, kind + "_offs.npy"), offs)
+        np.save(os.path.join(outdir, kind + "_chars.npy"), np.array([sum(map(len, sents))], dtype=np.int64))
+        os.rename(os.path.join(outdir, kind + "_chars.npy"), os.path.join(outdir, kind + "_done.npy"))
+
+
+class PackedWorkload(Workload):
+    """A Workload over one already packed corpus (the extras arrive as arrays from the generator process)."""
+
+    def __init__(self, utf8, offs, batch=BATCH):
+        self.rank, self.world, self.batch = 0, 1, batch
+        n = len(offs) - 1
+        self.n_total = [n]
+        p = []
+        for lo in range(0, max(n, 1), batch):
+            hi = min(lo + batch, n)
+            p.append((utf8[int(offs[lo]) : int(offs[hi])], (offs[lo : hi + 1] - offs[lo]).astype(np.uint64)))
+        self.packed = [p]
+
+
+def measure_config(tok, dev, wl, n_chars, passes, queue, streams, label):
+    """One extra config: algorithmic bytes from the device work counters, then `passes` timed passes."""
+    import torch
+
+    from kanpyo_amd.device import PROFILE_OFF, PROFILE_WORK
+
+    eng = GpuEngine(tok, dev, wl, queue=queue, streams=streams, ring=1)
+    for c in eng.ctxs:
+        c.set_profiling(PROFILE_WORK)
+    run_job(eng, 1)
+    work = {k: 0 for k in ("sentences", "B", "C", "T", "N", "E", "K")}
+    for c in eng.ctxs:
+        for k, v in c.work().items():
+            work[k] += v
+        c.set_profiling(PROFILE_OFF)
+        c.profile(reset=True)
+    run_job(eng, 1)  # warm (routing estimate settled)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_job(eng, passes)
+    dt = (time.perf_counter() - t0) / passes
+    prof = {"batches": 0, "sentences": 0, "deferred": [0] * 4, "redone": [0] * 4, "long_launches": 0, "arena_regrows": 0}
+    for c in eng.ctxs:
+        p = c.profile(reset=True)
+        for k in prof:
+            prof[k] = [x + y for x, y in zip(prof[k], p[k])] if isinstance(prof[k], list) else prof[k] + p[k]
+    eng.close()
+    n = wl.sentences(0)
+    a, b, c_ = algorithmic_bytes(work)
+    return {
+        "workload": label, "sentences": n, "chars_per_sentence": n_chars / max(n, 1), "value": n / dt, "unit": "sentences/s",
+        "Mchar_per_s": n_chars / dt / 1e6, "input_MiB_per_s": wl.bytes_in(0) / dt / 2**20, "ms_per_pass": dt * 1e3, "passes": passes,
+        "work_per_sentence": {k: work[k] / max(work["sentences"], 1) for k in ("B", "C", "T", "N", "E", "K")},
+        "algorithmic_bytes_per_pass": a + b + c_,
+        "roofline_at_job_rate": {"achieved": (a + b + c_) / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (a + b + c_) / dt / 1e9 / HBM_PEAK_GBS},
+        "routing": prof,
+    }
+
+
+# ------------------------------------------------------------------ main
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--queue", type=int, default=6, help="batches in flight (one context each)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the contexts share round-robin (HIP multiplexes streams onto "
                     "3 hardware queues: a 4th stream queues behind the 1st and unbalances them)")
+    ap.add_argument("--corpora", type=int, default=4, help="N>1: distinct cfg 4 corpora (seeds 100..) generated and cycled; 100 = all of cfg 4")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="lower bound of CPU-baseline work")
+    ap.add_argument("--cfg3-sentences", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cfg 3 / cfg 5 / latency / stage legs")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (self-test)")
     args = ap.parse_args()
 
@@ -73,6 +326,20 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    multi = world > 1 or args.force_dist
+    K, W = args.steps, args.warmup
+
+    from kanpyo_amd import synth
+
+    sd = synth.build_dict()
+    extras_dir, extras_proc = None, None
+    if world == 1 and not args.no_extras:  # before torch / HIP exist in this process: fork is safe
+        import multiprocessing as mp
+        import tempfile
+
+        extras_dir = tempfile.mkdtemp(prefix="kanpyo_bench_")
+        extras_proc = mp.get_context("fork").Process(target=_extras_child, args=(sd, extras_dir, args.cfg3_sentences), daemon=True)
+        extras_proc.start()
 
     import torch
     import torch.distributed as dist
@@ -80,7 +347,6 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X: the HIP path has no CPU fallback"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    multi = world > 1 or args.force_dist
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -88,146 +354,96 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from kanpyo_amd import Tokenizer, synth
-    from kanpyo_amd.device import PROFILE_EVENTS, PROFILE_OFF, PROFILE_SAMPLED, PROFILE_WORK, DeviceContext
-    from kanpyo_amd.dist import ChunkedGather
+    from kanpyo_amd import Tokenizer
+    from kanpyo_amd.device import PROFILE_EVENTS, PROFILE_OFF, PROFILE_SAMPLED, PROFILE_WORK, STAGE_ALL, STAGE_LATTICE, STAGE_VITERBI, DeviceContext
+    from kanpyo_amd.dist import ChunkedGather, reassemble
     from kanpyo_amd.tokenizer import pack_sentences
 
-    # ---- workload: dictionary replicated per GPU, one 100k-sentence shard per rank
-    sd = synth.build_dict()
-    corpus = synth.make_corpus(sd, N_SENT, seed=1 if world == 1 else 100 + rank, kind="cfg2")
+    # ---- workload
+    if world == 1:
+        corpora = [synth.make_corpus(sd, N_SENT, seed=1, kind="cfg2")]
+        label = "BASELINE configs[1] (cfg 2): 100k synthetic ~40-char sentences (seed 1)"
+    else:
+        ncorp = max(1, min(args.corpora, 100, max(K, W, 1)))
+        corpora = [synth.make_corpus(sd, N_SENT, seed=100 + k, kind="cfg2") for k in range(ncorp)]
+        label = (f"BASELINE configs[3] (cfg 4): 100k-sentence corpora of seeds 100..{99 + ncorp} cycled, sentence i -> GPU i mod {world}, "
+                 "token records gathered to rank 0 over xGMI")
+    wl = Workload(corpora, rank if world > 1 else 0, world)
     tok = Tokenizer(sd.dict, device=local_rank)
-    batches = []
-    for lo in range(0, N_SENT - BATCH + 1, BATCH):  # the 24 full batches (the 1696-sentence tail is a parity-test case)
-        utf8, offs = pack_sentences(corpus[lo : lo + BATCH])
-        batches.append((torch.from_numpy(utf8.copy()).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev),
-                        int(offs[-1]), utf8, offs))
-    nb = len(batches)
-    cap = max(b[2] for b in batches) + BATCH  # always sufficient: tokens <= chars + 1 <= bytes + 1
-    K, W, Q = args.steps, args.warmup, max(1, args.queue)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, min(args.streams, Q)))]
-    ctxs = [DeviceContext(tok, streams[i % len(streams)].cuda_stream) for i in range(Q)]
-    n_out = max(K, W, 1)
-    out_tok = [torch.empty((cap, 6), dtype=torch.int32, device=dev) for _ in range(max(2 * Q, 24))]  # >= 2 gather chunks
-    NB = len(out_tok)
-    out_off_all = torch.empty((NB, BATCH + 1), dtype=torch.int64, device=dev)  # one row per output buffer
-    out_off = [out_off_all[i] for i in range(NB)]
-    out_st = [torch.empty(BATCH, dtype=torch.uint8, device=dev) for _ in range(len(out_tok))]
+    cs = chunk_steps_for(wl.nb(0))
+    eng = GpuEngine(tok, dev, wl, queue=args.queue, streams=args.streams, ring=3 * cs if multi else 1)
+    Q = eng.Q
 
-    def enqueue(i):
-        d_utf8, d_off, total, _, _ = batches[i % nb]
-        o = i % len(out_tok)
-        ctxs[i % Q].tokenize(d_utf8.data_ptr(), d_off.data_ptr(), BATCH, total, out_tok[o].data_ptr(), cap,
-                             out_off[o].data_ptr(), out_st[o].data_ptr())
-
-    def drain():
-        return [c.sync() for c in ctxs]
-
-    # ---- untimed: device-side work counters of every distinct batch (algorithmic bytes)
+    # ---- untimed: device-side work counters of every distinct batch of corpus 0 (algorithmic bytes)
     work = {k: 0 for k in ("sentences", "B", "C", "T", "N", "E", "K")}
-    ctxs[0].set_profiling(PROFILE_WORK)
-    for i in range(nb):
-        d_utf8, d_off, total, _, _ = batches[i]
-        ctxs[0].tokenize(d_utf8.data_ptr(), d_off.data_ptr(), BATCH, total, out_tok[0].data_ptr(), cap,
-                         out_off[0].data_ptr(), out_st[0].data_ptr())
-        ctxs[0].sync()
-    for k, v in ctxs[0].work().items():
-        work[k] += v
-    ctxs[0].set_profiling(PROFILE_OFF)
+    for c in eng.ctxs:
+        c.set_profiling(PROFILE_WORK)
+    run_job(eng, 1)
+    for c in eng.ctxs:
+        for k, v in c.work().items():
+            work[k] += v
+        c.set_profiling(PROFILE_OFF)
     sample_tokens = None
-    if rank == 0:  # keep batch 0's GPU result for the bit-exact check in the cpu_baseline leg
-        d_utf8, d_off, total, _, _ = batches[0]
-        ctxs[0].tokenize(d_utf8.data_ptr(), d_off.data_ptr(), BATCH, total, out_tok[0].data_ptr(), cap,
-                         out_off[0].data_ptr(), out_st[0].data_ptr())
-        nt = ctxs[0].sync()
-        sample_tokens = (out_tok[0][:nt].cpu().numpy().copy(), out_off[0].cpu().numpy().copy())
+    if rank == 0 and world == 1:  # keep batch 0's GPU result for the bit-exact check in the cpu_baseline leg
+        eng.enqueue(0, 0)
+        k = eng._retire((0, 0))
+        t, o, _ = eng.out[0][0]
+        sample_tokens = (t[:k].cpu().numpy().copy(), o.cpu().numpy().copy())
+        eng.drain()
 
-    row_cache = {}
+    # ---- multi-rank: the gather, and (untimed) the check of one gathered + reassembled step against one GPU
     size_pg = dist.new_group(backend="gloo") if multi else None  # CPU-side size exchange of the gather
-    GC = 12  # steps per gather chunk (multi-rank): large enough that the host side of a gather (CPU-side size
-             # exchange, one grouped send/recv call) is a small part of the chunk; the contexts' queue keeps the GPU fed
+    gathered = {"tokens": 0, "sentences": 0, "chunks": 0}
 
-    def run_steps(nsteps):
-        """Exactly `nsteps` steps; multi-rank: plus the overlapped gather of everything produced."""
+    def count_chunk(c0, r):
+        if r is not None:
+            gathered["tokens"] += int(r[0].shape[0])
+            gathered["sentences"] += int(r[1].shape[0])
+            gathered["chunks"] += 1
+
+    def job(nsteps, on_chunk=count_chunk):
         if not multi:
-            for i in range(nsteps):
-                enqueue(i)
-            drain()
-            return
-        # Chunks of GC steps; the token records of chunk c travel to rank 0 (flat gatherv over xGMI) while
-        # chunk c+1 is being tokenized.  Every byte produced is gathered.  Step i writes output buffer
-        # i mod 2*GC, so chunk c's transfers are waited for before chunk c+2 starts.
-        gather = ChunkedGather(dst=0, size_group=size_pg)
-        ntok_of = {}
-        chunks = []
+            run_job(eng, nsteps)
+        else:
+            run_job(eng, nsteps, ChunkedGather(dst=0, size_group=size_pg), cs, on_chunk)
 
-        def retire(upto):  # steps < upto are complete on the device: collect their token counts
-            for j in range(max(0, upto - Q), upto):
-                if j not in ntok_of:
-                    ntok_of[j] = ctxs[j % Q].sync()
-
-        def post(lo, hi):
-          t_post0 = time.perf_counter()
-          if True:
-            views = [out_tok[i % NB][: ntok_of[i]] for i in range(lo, hi)]  # sent as they are: no concat pass
-            key = (lo % NB, hi - lo)
-            if key not in row_cache:  # cached: no host-to-device copy (a sync behind a busy device) per chunk
-                row_cache[key] = torch.tensor([i % NB for i in range(lo, hi)], device=dev)
-            offs = out_off_all.index_select(0, row_cache[key])  # [steps, BATCH + 1] in one gather
-            t_post1 = time.perf_counter()
-            gather.post_steps(views, (offs[:, 1:] - offs[:, :-1]).reshape(-1), copy_own=False)  # rank 0's own records are already on rank 0
-            if os.environ.get("BENCH_DEBUG_GATHER") and rank == 0:
-                print(f"[gather] steps {lo}..{hi}: prepare {1e3 * (t_post1 - t_post0):.3f} ms, post {1e3 * (time.perf_counter() - t_post1):.3f} ms", file=sys.stderr)
-
-
-        for c0 in range(0, nsteps, GC):
-            if c0 >= 2 * GC:
-                chunks += [(r[0].shape[0], sum(z[0] for z in r[2])) for r in gather.finish() if r is not None]  # chunk c0/GC - 2 has left its buffers
-            t_l0 = time.perf_counter(); t_sync = 0.0
-            for i in range(c0, min(c0 + GC, nsteps)):
-                if i >= Q:
-                    t_s0 = time.perf_counter()
-                    ntok_of[i - Q] = ctxs[i % Q].sync()  # step i-Q used this ctx: done before it is reused
-                    t_sync += time.perf_counter() - t_s0
-                enqueue(i)
-            if os.environ.get("BENCH_DEBUG_GATHER") and rank == 0:
-                print(f"[loop] chunk at {c0}: {1e3 * (time.perf_counter() - t_l0):.3f} ms, of which waiting in sync {1e3 * t_sync:.3f} ms", file=sys.stderr)
-            if c0 >= GC:
-                retire(c0)
-                post(c0 - GC, c0)
-        last0 = ((nsteps - 1) // GC) * GC
-        retire(nsteps)
-        post(max(last0, 0), nsteps)
-        chunks += [(r[0].shape[0], sum(z[0] for z in r[2])) for r in gather.finish() if r is not None]
+    gather_check = None
+    if multi:
+        got = {}
+        job(1, lambda c0, r: got.update(r=r))
         if rank == 0:
-            assert chunks and all(got == want for got, want in chunks)
-
-    if multi:  # untimed set-up of the gather path: index tensors of every chunk shape, allocator blocks of the chunk sizes
-        for c0 in range(0, max(K, W, 1), GC):
-            for total_steps in (K, W):
-                n_st = min(c0 + GC, total_steps) - c0
-                if n_st > 0 and (c0 % NB, n_st) not in row_cache:
-                    row_cache[(c0 % NB, n_st)] = torch.tensor([i % NB for i in range(c0, c0 + n_st)], device=dev)
-        if rank == 0:
-            warm = [torch.empty((world * GC * cap // 3, 6), dtype=torch.int32, device=dev) for _ in range(2)]
-            warm += [torch.empty(world * GC * BATCH, dtype=torch.int64, device=dev) for _ in range(2)]
-            del warm  # stays in torch's caching allocator: no hipMalloc inside the timed region
+            tok_all, cnt_all, _ = got["r"][:3]
+            g_tok, g_off = reassemble(tok_all.cpu().numpy(), cnt_all.cpu().numpy(), len(corpora[0]), world)
+            full = GpuEngine(tok, dev, Workload(corpora[:1], 0, 1), queue=2, streams=1, ring=1)
+            for b in range(full.nb(0)):
+                full.enqueue(0, b)
+            fv, fc = full.results(0)
+            f_tok = torch.cat(fv).cpu().numpy()
+            f_off = np.concatenate([[0], np.cumsum(fc.cpu().numpy())])
+            gather_check = bool(np.array_equal(g_off, f_off) and np.array_equal(g_tok, f_tok))
+            full.close()
+            del full
+        if rank == 0 and world > 1:  # allocator blocks of the chunk sizes: no hipMalloc inside the timed region
+            warm = [torch.empty((cs * N_SENT * 40, 6), dtype=torch.int32, device=dev) for _ in range(3)]
+            del warm
         torch.cuda.synchronize()
 
     # ---- warmup (also brings up the RCCL channels of the gather)
     if W > 0:
-        run_steps(W)
-    for c in ctxs:
+        job(W)
+    for c in eng.ctxs:
         if not os.environ.get("BENCH_NO_EVENTS"):
-            c.set_profiling(PROFILE_EVENTS | PROFILE_SAMPLED)  # HIP events around every 4th launch
+            c.set_profiling(PROFILE_EVENTS | PROFILE_SAMPLED)  # HIP events around every 4th launch chain
         c.profile(reset=True)
+    for k in gathered:
+        gathered[k] = 0
 
     # ---- timed region: exactly K steps
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(K)
+    job(K)
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -237,59 +453,132 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    prof = {"launches": 0, "tokenize_ms": 0.0, "aux_ms": 0.0}
-    for c in ctxs:
+    prof = {"launches": 0, "tokenize_ms": 0.0, "aux_ms": 0.0, "batches": 0, "sentences": 0, "deferred": [0] * 4, "redone": [0] * 4,
+            "long_launches": 0, "arena_regrows": 0}
+    for c in eng.ctxs:
         p = c.profile(reset=True)
         for k in prof:
-            prof[k] += p[k]
+            prof[k] = [x + y for x, y in zip(prof[k], p[k])] if isinstance(prof[k], list) else prof[k] + p[k]
         c.set_profiling(PROFILE_OFF)
 
     if rank != 0:
         dist.destroy_process_group()
         return
 
-    sentences = K * BATCH * world
-    bytes_in = sum(batches[i % nb][2] for i in range(K)) * world
-    a, b, c_ = algorithmic_bytes(work)
-    per_launch_bytes = (a + b + c_) / nb
+    sentences = sum(len(corpora[s % len(corpora)]) for s in range(K))  # whole job: all ranks' shards
+    per_corpus_bytes = [sum(len(x.encode("utf-8")) for x in c) for c in corpora]
+    bytes_in = sum(per_corpus_bytes[s % len(corpora)] for s in range(K))
+    a, b, c_ = algorithmic_bytes(work)  # of this rank's shard of corpus 0 (world 1: the whole corpus)
+    n_work = max(work["sentences"], 1)
+    full_batches = [i for i in range(wl.nb(0)) if len(wl.packed[0][i][1]) - 1 == BATCH]
+    per_sentence_bytes = (a + b + c_) / n_work
+    per_launch_bytes = per_sentence_bytes * BATCH
     avg_kernel_s = prof["tokenize_ms"] / max(prof["launches"], 1) / 1e3
-    achieved = per_launch_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    # every 4th launch chain is timed, tail batches included: scale the bytes to the average timed launch
+    avg_launch_sentences = wl.sentences(0) / wl.nb(0)
+    achieved = per_sentence_bytes * avg_launch_sentences / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    job_rate_bytes = per_sentence_bytes * sentences / elapsed / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from a separate rocprofv3 --pmc pass
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")  # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, see file
+            traffic = json.load(open(tpath))
         except Exception:
             traffic = None
 
     result = {
         "metric": "sentences/sec", "value": sentences / elapsed, "unit": "sentences/s", "n_gpus": world,
-        "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "i32", "data": "synthetic",
         "config": {
-            "workload": "BASELINE configs[1]: 100k synthetic ~40-char sentences per GPU, synthetic IPADIC-shaped "
-                        "dictionary (392k records, 1316x1316 i16 matrix, 11 categories, 40 unk rows), batch=4096 "
-                        "(the 24 full batches cycled), inputs resident in HBM, dense tokens left in HBM",
-            "batch": BATCH, "sentences_per_gpu": N_SENT, "batches_in_flight": Q,
-            "sharding": "sentences round-robin, dictionary replicated, one gatherv of token records to rank 0",
+            "workload": label + "; synthetic IPADIC-shaped dictionary (392k records, 1316x1316 i16 matrix, 11 categories, 40 unk rows); "
+                        "batch=4096 (24 full batches + the 1696-sentence tail per 100k sentences at N=1); one step = one whole corpus; "
+                        "inputs resident in HBM, dense tokens left in HBM",
+            "batch": BATCH, "sentences_per_step": N_SENT, "batches_per_step_per_gpu": wl.nb(0), "batches_in_flight": Q,
+            "sharding": "sentence i -> GPU i mod N, dictionary replicated, one gatherv of token records to rank 0 per chunk of "
+                        f"{cs} step(s)" if multi else "single GPU",
         },
         "input_MiB_per_s": bytes_in / elapsed / 2**20,
-        "work_per_sentence": {k: work[k] / work["sentences"] for k in ("B", "C", "T", "N", "E", "K")},
+        "work_per_sentence": {k: work[k] / n_work for k in ("B", "C", "T", "N", "E", "K")},
+        "routing": {k: prof[k] for k in ("batches", "sentences", "deferred", "redone", "long_launches", "arena_regrows")},
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": "k_tokenize_pool (fused lattice build + Viterbi + backtrace, LDS page pool)",
+            "traffic": traffic.get("hbm_bytes_per_launch") if traffic else None,
+            "traffic_source": (traffic.get("source", "profiles/pmc_traffic.json") + " -- separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, "
+                               "per launch), NOT measured inside this run") if traffic else None,
+            "kernel": "k_tokenize_pool (fused lattice build + Viterbi + backtrace, LDS page pool)",
+            "algorithmic_bytes_per_sentence": per_sentence_bytes,
             "algorithmic_bytes_per_launch": per_launch_bytes,
-            "stage_bytes_per_launch": {"A_lattice": a / nb, "B_viterbi": b / nb, "C_emit": c_ / nb},
+            "stage_bytes_per_launch": {"A_lattice": a / n_work * BATCH, "B_viterbi": b / n_work * BATCH, "C_emit": c_ / n_work * BATCH},
             "avg_kernel_ms": avg_kernel_s * 1e3, "launches_timed": prof["launches"],
+            "avg_kernel_what": f"HIP events on the ctx stream around the tokenize launches of every 4th batch, {Q} batches in flight on the chip "
+                               "(a launch therefore lasts several times its share of the chip's work; see kernel_alone_ms and frac_at_job_rate)",
             "aux_kernels_avg_ms": prof["aux_ms"] / max(prof["launches"], 1),
-            # `achieved` divides by the duration of ONE launch while `batches_in_flight` launches share the
-            # chip (each therefore lasts ~that many times longer than its share of the work); the same
-            # algorithmic bytes at the measured whole-job rate:
             "launches_in_flight": Q,
-            "achieved_at_job_rate": per_launch_bytes * (sentences / world / BATCH) / elapsed / 1e9,
-            "frac_at_job_rate": per_launch_bytes * (sentences / world / BATCH) / elapsed / 1e9 / HBM_PEAK_GBS,
+            "achieved_at_job_rate": job_rate_bytes, "frac_at_job_rate": job_rate_bytes / HBM_PEAK_GBS,
         },
     }
+    if multi:
+        result["gather"] = {"chunks": gathered["chunks"], "tokens": gathered["tokens"], "sentences": gathered["sentences"],
+                            "complete": gathered["sentences"] == sentences, "reassembled_step_equals_one_gpu": gather_check,
+                            "chunk_steps": cs}
+        assert gathered["sentences"] == sentences, (gathered, sentences)
+        assert gather_check, "gathered + reassembled token stream differs from the single-GPU stream"
+
+    if world == 1:
+        # ---- the dominant kernel alone on the chip: one batch at a time, HIP events around every launch
+        c0 = eng.ctxs[0]
+        c0.set_profiling(PROFILE_EVENTS)
+        for rep in range(2):
+            c0.profile(reset=True)
+            for bi in full_batches:
+                d_utf8, d_off, n, total = eng.inputs[0][bi]
+                t, o, st = eng.out[0][bi]
+                c0.tokenize(d_utf8.data_ptr(), d_off.data_ptr(), n, total, t.data_ptr(), eng.cap, o.data_ptr(), st.data_ptr())
+                c0.sync()
+        p = c0.profile(reset=True)
+        c0.set_profiling(PROFILE_OFF)
+        alone_ms = p["tokenize_ms"] / max(p["launches"], 1)
+        result["roofline"]["kernel_alone_ms"] = alone_ms
+        result["roofline"]["achieved_alone"] = per_launch_bytes / (alone_ms * 1e-3) / 1e9 if alone_ms > 0 else None
+        result["roofline"]["frac_alone"] = per_launch_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if alone_ms > 0 else None
+
+    if world == 1 and not args.no_extras:
+        # ---- per-stage roofline: the same pipeline with every sentence stopped after a stage (measurement-only mode of
+        # the runtime); a stage's time is the difference of consecutive stop levels at full occupancy
+        stage_ms = {}
+        for name, stop in (("A", STAGE_LATTICE), ("AB", STAGE_VITERBI), ("ABC", STAGE_ALL)):
+            for c in eng.ctxs:
+                c.set_ablation(stop)
+            run_job(eng, 1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_job(eng, 3)
+            stage_ms[name] = (time.perf_counter() - t1) / 3 * 1e3
+        for c in eng.ctxs:
+            c.set_ablation(STAGE_ALL)
+        sb = {"A_lattice": a, "B_viterbi": b, "C_emit": c_}  # bytes per step (whole corpus)
+        sm = {"A_lattice": stage_ms["A"], "B_viterbi": stage_ms["AB"] - stage_ms["A"], "C_emit": stage_ms["ABC"] - stage_ms["AB"]}
+        result["roofline"]["stages"] = {
+            k: {"bytes_per_step": sb[k], "ms_per_step": sm[k],
+                "achieved": sb[k] / (sm[k] * 1e-3) / 1e9 if sm[k] > 0 else None,
+                "frac": sb[k] / (sm[k] * 1e-3) / 1e9 / HBM_PEAK_GBS if sm[k] > 0 else None} for k in sb}
+        result["roofline"]["stages"]["how"] = ("kgpu_ctx_set_ablation: steps timed with every sentence stopped after the lattice build / after the sweep / "
+                                                "not at all, full pipeline; stage time = difference of consecutive levels (B_viterbi = connection-cost gather + sweep)")
+        # ---- instruction roofline: the ceiling this kernel is actually near.  Instruction counts per sentence come from a separate
+        # rocprofv3 --pmc pass (profiles/); the rate is this run's.
+        ipath = os.path.join(ROOT, "profiles", "pmc_instructions.json")
+        if os.path.exists(ipath):
+            try:
+                ins = json.load(open(ipath))
+                valu, salu = ins["valu_per_sentence"], ins["salu_per_sentence"]
+                rate = result["value"]
+                result["roofline"]["instruction"] = {
+                    "valu_per_sentence": valu, "salu_per_sentence": salu, "source": ins.get("source", "profiles/pmc_instructions.json"),
+                    "valu_issue_frac": valu * 2 * rate / (CHIP_SIMDS * CHIP_CLOCK_HZ),  # a wave64 VALU op occupies its SIMD-32 for 2 cycles
+                    "what": "wave-VALU-instructions per sentence x 2 cycles x sentences/s / (1024 SIMDs x 2.4 GHz)"}
+            except Exception as e:
+                print(f"instruction roofline skipped: {e}", file=sys.stderr)
 
     # ---- the box's own streaming-read bandwidth (a 4 GiB int64 reduction, best of 5): second denominator of the roofline
     if world == 1:
@@ -307,70 +596,119 @@ def main():
             result["roofline"]["peak_measured_read"] = None
             print(f"streaming-read measurement skipped: {e}", file=sys.stderr)
 
-    # ---- host-buffer entry point (H2D + kernels + D2H per batch): the PCIe-inclusive rate, never `value`
+    # ---- host-buffer entry point (H2D + kernels + D2H per call): PCIe-inclusive rates and call latencies, never `value`
     if world == 1:
         from kanpyo_amd.tokenizer import TOKEN_DTYPE, pinned_empty
+        utf8_0, offs_0 = wl.packed[0][0]
+        cap = eng.cap
         h_out = (np.empty(cap, dtype=TOKEN_DTYPE), np.empty(BATCH + 1, dtype=np.uint64), np.empty(BATCH, dtype=np.uint8))
-        tok.tokenize_packed(batches[0][3], batches[0][4], out=h_out)  # untimed: the pool ctx allocates its scratch, pages get touched
+        tok.tokenize_packed(utf8_0, offs_0, out=h_out)  # untimed: the pool ctx allocates its scratch, pages get touched
         t1 = time.perf_counter()
         done = 0
-        for i in range(min(nb, 12)):
-            _, _, _, utf8_h, offs_h = batches[i]
-            tok.tokenize_packed(utf8_h, offs_h, out=h_out)
-            done += BATCH
+        for i in range(min(wl.nb(0), 12)):
+            u, o = wl.packed[0][i]
+            tok.tokenize_packed(u, o, out=h_out)
+            done += len(o) - 1
         result["pcie_inclusive"] = {"value": done / (time.perf_counter() - t1), "unit": "sentences/s",
-                                    "what": "kgpu_tokenize_batch: pageable host buffers in, dense tokens out, one batch at a time"}
-        # the same entry point given the 24 batches in ONE call (it pipelines 16384-sentence chunks over three
-        # contexts), with pageable and with pinned (kgpu_host_alloc) buffers
-        utf8_all, offs_all = pack_sentences(corpus[: nb * BATCH])
-        capall = int(offs_all[-1]) // 2 + nb * BATCH  # tokens <= chars + 1 per sentence; the text is 3 bytes per char
-        for name, alloc in (("large_call_pageable", np.empty), ("large_call_pinned", pinned_empty)):
-            u = alloc(utf8_all.shape, dtype=np.uint8); u[:] = utf8_all
-            o = alloc(offs_all.shape, dtype=np.uint64); o[:] = offs_all
-            big = (alloc(capall, dtype=TOKEN_DTYPE), alloc(nb * BATCH + 1, dtype=np.uint64), alloc(nb * BATCH, dtype=np.uint8))
-            tok.tokenize_packed(u, o, out=big)  # untimed: scratch allocation, pages touched
-            t1 = time.perf_counter()
-            for _ in range(3):
-                tok.tokenize_packed(u, o, out=big)
-            result["pcie_inclusive"][name] = 3 * nb * BATCH / (time.perf_counter() - t1)
-            del big
+                                    "what": "kgpu_tokenize_batch: pageable host buffers in, dense tokens out, one 4096-sentence call at a time"}
+        lat = {}
+        for n_call in (1, 64, 4096):  # the reference's call shape is n = 1: Tokenizer::tokenize(&str), once per CLI line
+            o = offs_0[: n_call + 1].copy()
+            u = utf8_0[: int(o[-1])]
+            for _ in range(20):
+                tok.tokenize_packed(u, o, out=h_out)
+            ts = []
+            for _ in range(200 if n_call < 4096 else 50):
+                t1 = time.perf_counter()
+                tok.tokenize_packed(u, o, out=h_out)
+                ts.append(time.perf_counter() - t1)
+            ts.sort()
+            lat[f"n{n_call}"] = {"median_us": ts[len(ts) // 2] * 1e6, "p10_us": ts[len(ts) // 10] * 1e6,
+                                 "sentences_per_s_at_median": n_call / ts[len(ts) // 2]}
+        result["pcie_inclusive"]["call_latency"] = lat
+        result["pcie_inclusive"]["call_latency_what"] = ("kgpu_tokenize_batch through the ctypes mirror (Tokenizer.tokenize_packed, caller-owned "
+                                                         "result arrays), host buffers in and out, wall time per call")
+        if not args.no_extras:
+            nbf = len(full_batches)
+            utf8_all, offs_all = pack_sentences(corpora[0][: nbf * BATCH])
+            capall = int(offs_all[-1]) // 2 + nbf * BATCH  # tokens <= chars + 1 per sentence; the text is 3 bytes per char
+            for name, alloc in (("large_call_pageable", np.empty), ("large_call_pinned", pinned_empty)):
+                u = alloc(utf8_all.shape, dtype=np.uint8); u[:] = utf8_all
+                o = alloc(offs_all.shape, dtype=np.uint64); o[:] = offs_all
+                big = (alloc(capall, dtype=TOKEN_DTYPE), alloc(nbf * BATCH + 1, dtype=np.uint64), alloc(nbf * BATCH, dtype=np.uint8))
+                tok.tokenize_packed(u, o, out=big)  # untimed: scratch allocation, pages touched
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    tok.tokenize_packed(u, o, out=big)
+                result["pcie_inclusive"][name] = 3 * nbf * BATCH / (time.perf_counter() - t1)
+                del big
 
-    # ---- CPU baseline (rank 0, N==1 only): the oracle restatement on the host cores
+    # ---- CPU baseline (rank 0, N==1 only): the oracle restatement on the host cores, every sentence tokenized once
     if world == 1 and not args.no_cpu:
         from oracle import oracle
 
         orc = oracle.OracleTokenizer.from_dict(sd.dict)
-        utf8, offs = pack_sentences(corpus)
-        done, t_cpu, exp0 = 0, 0.0, None
+        utf8, offs = pack_sentences(corpora[0])
+        n_c = len(corpora[0])
+        bufs = (np.zeros(int(offs[-1]) + n_c, dtype=oracle.TOKEN_DTYPE), np.zeros(n_c + 1, dtype=np.uint64))
+        exp0 = orc.tokenize_batch(utf8, offs, 1, out=bufs, copy=False)  # untimed: pages touched
+        done, t_cpu = 0, 0.0
         while t_cpu < args.cpu_seconds:
             t1 = time.perf_counter()
-            r = orc.tokenize_batch(utf8, offs, 1)
+            exp0 = orc.tokenize_batch(utf8, offs, 1, out=bufs, copy=False)
             t_cpu += time.perf_counter() - t1
-            done += len(corpus)
-            exp0 = r
+            done += n_c
         ncores = os.cpu_count() or 1
-        t1 = time.perf_counter()
-        orc.tokenize_batch(utf8, offs, ncores)
-        t_all = time.perf_counter() - t1
         # bit-exact check of the GPU's batch 0 against the same sentences from the oracle
         n0 = int(exp0.offsets[BATCH])
         g_tok, g_off = sample_tokens
         exact = bool(np.array_equal(g_off.astype(np.uint64), exp0.offsets[: BATCH + 1])
                      and np.array_equal(g_tok.reshape(-1), exp0.tokens[:n0].view(np.int32).reshape(-1).astype(np.int32)))
+        orc.tokenize_batch(utf8, offs, ncores, out=bufs, copy=False)
+        reps_all = 3
+        t1 = time.perf_counter()
+        for _ in range(reps_all):
+            orc.tokenize_batch(utf8, offs, ncores, out=bufs, copy=False)
+        t_all = (time.perf_counter() - t1) / reps_all
         result["cpu_baseline"] = {
             "value": done / t_cpu, "unit": "sentences/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
-            "sample": f"the same 100k-sentence cfg2 corpus, {done // len(corpus)} pass(es), {t_cpu:.1f} s, "
-                      "oracle/kanpyo_oracle.c (CPU restatement of Kanpyo's algorithm, gcc -O2), single thread",
-            "all_cores": {"value": len(corpus) / t_all, "cores": ncores},
+            "sample": f"the same 100k-sentence cfg2 corpus, {done // n_c} pass(es), {t_cpu:.1f} s, single pass per sentence into a "
+                      "preallocated worst-case buffer, oracle/kanpyo_oracle.c (CPU restatement of Kanpyo's algorithm, gcc -O2), single thread",
+            "all_cores": {"value": n_c / t_all, "cores": ncores, "what": "one contiguous sentence range per hardware thread"},
             "gpu_batch0_bit_exact": exact,
         }
         result["speedup_vs_cpu_1thread"] = result["value"] / result["cpu_baseline"]["value"]
+
+    # ---- the other single-GPU configs (SURVEY 8d cfg 3, cfg 5) as extra lines
+    if world == 1 and not args.no_extras:
+        eng.close()
+        extra = []
+        for kind, passes, lab in (("cfg5", 5, "BASELINE configs[4] (cfg 5): 1k sentences of 2048 chars, each with a same-category run > 1024 chars"),
+                                  ("cfg3", 2, f"BASELINE configs[2] (cfg 3): {args.cfg3_sentences} mixed-length (8-512 char) sentences incl. unknown-word path")):
+            flag = os.path.join(extras_dir, kind + "_done.npy")
+            t_wait = time.perf_counter()
+            while not os.path.exists(flag) and extras_proc.is_alive() and time.perf_counter() - t_wait < 600:
+                time.sleep(0.2)
+            if not os.path.exists(flag):
+                print(f"{kind}: corpus generator did not finish; skipped", file=sys.stderr)
+                continue
+            u = np.load(os.path.join(extras_dir, kind + "_utf8.npy"))
+            o = np.load(os.path.join(extras_dir, kind + "_offs.npy"))
+            n_chars = int(np.load(flag)[0])
+            try:
+                extra.append(measure_config(tok, dev, PackedWorkload(u, o), n_chars, passes, args.queue, args.streams, lab))
+            except Exception as e:
+                print(f"{kind} leg failed: {e}", file=sys.stderr)
+        result["extra"] = extra
+        import shutil
+
+        shutil.rmtree(extras_dir, ignore_errors=True)
+
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
     print(json.dumps(result), flush=True)
     if multi:
         os.dup2(2, 1)
-    if multi:
         dist.destroy_process_group()
 
 

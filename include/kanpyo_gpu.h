@@ -36,6 +36,11 @@ extern "C" {
 #define KGPU_SENT_INVALID_UTF8 1 /* Rust's &str cannot carry this; the C boundary checks
                                     (reference src/tokenizer.rs:16 takes &str).  The
                                     sentence yields zero tokens.                        */
+#define KGPU_SENT_NO_SCRATCH 2   /* transient: the lattice did not fit the scratch arena;
+                                    kgpu_ctx_sync grows it and reruns the batch, callers
+                                    never see this value                                 */
+#define KGPU_SENT_TRUNCATED 3    /* measurement mode only (kgpu_ctx_set_ablation): the
+                                    sentence was stopped after a stage, zero tokens      */
 
 /* TokenClass (reference src/token.rs:3-8). */
 #define KGPU_CLASS_DUMMY 0
@@ -96,6 +101,18 @@ typedef struct kgpu_profile {
     uint64_t launches;     /* tokenize kernel launches timed                  */
     double tokenize_ms;    /* sum of the fused lattice+Viterbi kernel durations */
     double aux_ms;         /* sum of scan + compaction kernel durations         */
+    /* Routing counters, always on (they cost nothing: read from the batch's control block at
+     * kgpu_ctx_sync).  A dictionary or text whose lattices outgrow the LDS-resident kernel shows up
+     * here long before it shows up as a throughput cliff. */
+    uint64_t batches;         /* batches completed                                            */
+    uint64_t sentences;       /* sentences in them                                            */
+    uint64_t deferred[4];     /* sentences handed from launch k of the chain to launch k+1
+                                 ([0]: left the LDS-resident kernel for the long-sentence /
+                                 HBM-scratch kernels)                                         */
+    uint64_t redone[4];       /* ... of which only after the trie walk had been paid for
+                                 (LDS reservation too small: the sentence was redone)         */
+    uint64_t long_launches;   /* batches for which the long-sentence kernel was launched      */
+    uint64_t arena_regrows;   /* batches rerun because the HBM scratch arena was too small    */
 } kgpu_profile;
 
 /* Work counters of one or more batches, counted on the device when
@@ -125,6 +142,13 @@ int kgpu_device_count(void);
  * of bounds: src/lattice.rs:54,182,195, connection.rs:13) is rejected here with
  * KGPU_ERR_BAD_DICT instead. */
 int kgpu_dict_create(const kgpu_dict_blobs *blobs, int device, kgpu_dict **out);
+/* Create-time validation is stricter than the reference's lazy panics, on purpose (a device kernel
+ * cannot panic): a dictionary is rejected as a whole if ANY morph carries a negative context id, if
+ * the largest (left, right) id pair of the dictionary indexes outside the matrix, if a duplicate
+ * count exceeds 65535 or names a missing record, or if a category that occurs in char_category has
+ * no invoke_list entry -- even when the offending entry could never be reached by a lattice. */
+/* The handle may be destroyed while contexts made from it are alive: the tables and the shared
+ * streams are released when the last such context is destroyed. */
 void kgpu_dict_destroy(kgpu_dict *d);
 int kgpu_dict_get_info(const kgpu_dict *d, kgpu_dict_info *out);
 
@@ -159,6 +183,16 @@ int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_o
 int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens);
 int kgpu_ctx_set_profiling(kgpu_ctx *c, int mode /* KGPU_PROFILE_* bit mask */);
 int kgpu_ctx_get_profile(kgpu_ctx *c, kgpu_profile *out, int reset);
+/* Measurement only (bench.py's per-stage roofline): every sentence of the following batches stops
+ * after the given stage of the fused kernel, yields zero tokens and status KGPU_SENT_TRUNCATED.
+ * 0 = off (normal operation).  Stages: 5 = lattice built (SURVEY.md 8d Stage A: load, decode, trie
+ * walk, numbering, node emission), 7 = Viterbi sweep done (Stage B: connection-cost gather + sweep);
+ * the remainder is Stage C (backtrace + token records). */
+#define KGPU_STAGE_ALL 0
+#define KGPU_STAGE_LATTICE 5
+#define KGPU_STAGE_GATHER 6
+#define KGPU_STAGE_VITERBI 7
+int kgpu_ctx_set_ablation(kgpu_ctx *c, int stop_after_stage);
 int kgpu_ctx_get_work(kgpu_ctx *c, kgpu_work *out, int reset);
 /* Sum over sentences of shader-clock cycles spent per phase of the LDS-resident
  * kernel (KGPU_PROFILE_WORK runs only): load, decode, walk, scan, emit, gather,

@@ -16,12 +16,13 @@ KGPU_ERR_NO_DEVICE = 5
 KGPU_ERR_INTERNAL = 6
 KGPU_SENT_OK = 0
 KGPU_SENT_INVALID_UTF8 = 1
+KGPU_SENT_TRUNCATED = 3
 
 # every symbol include/kanpyo_gpu.h declares
 SYMBOLS = [
     "kgpu_last_error", "kgpu_device_count", "kgpu_dict_create", "kgpu_dict_destroy", "kgpu_dict_get_info",
     "kgpu_tokenize_batch", "kgpu_ctx_create", "kgpu_ctx_destroy", "kgpu_tokenize_device", "kgpu_ctx_sync",
-    "kgpu_ctx_set_profiling", "kgpu_ctx_get_profile", "kgpu_ctx_get_work", "kgpu_ctx_get_phase_cycles", "kgpu_index_build", "kgpu_free",
+    "kgpu_ctx_set_profiling", "kgpu_ctx_set_ablation", "kgpu_ctx_get_profile", "kgpu_ctx_get_work", "kgpu_ctx_get_phase_cycles", "kgpu_index_build", "kgpu_free",
     "kgpu_host_alloc", "kgpu_host_free",
 ]
 
@@ -48,7 +49,9 @@ class DictInfo(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("launches", C.c_uint64), ("tokenize_ms", C.c_double), ("aux_ms", C.c_double)]
+    _fields_ = [("launches", C.c_uint64), ("tokenize_ms", C.c_double), ("aux_ms", C.c_double),
+                ("batches", C.c_uint64), ("sentences", C.c_uint64), ("deferred", C.c_uint64 * 4), ("redone", C.c_uint64 * 4),
+                ("long_launches", C.c_uint64), ("arena_regrows", C.c_uint64)]
 
 
 class Work(C.Structure):
@@ -83,6 +86,7 @@ def lib():
         L.kgpu_tokenize_device.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, vp]
         L.kgpu_ctx_sync.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.kgpu_ctx_set_profiling.argtypes = [vp, C.c_int]
+        L.kgpu_ctx_set_ablation.argtypes = [vp, C.c_int]
         L.kgpu_ctx_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
         L.kgpu_ctx_get_work.argtypes = [vp, C.POINTER(Work), C.c_int]
         L.kgpu_ctx_get_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64 * 10), C.c_int]

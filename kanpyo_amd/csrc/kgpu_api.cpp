@@ -96,7 +96,18 @@ struct kgpu_dict {
     // number of contexts shares three streams; each context waits on its own completion event.
     std::vector<hipStream_t> streams;
     unsigned next_stream = 0;
+    // One reference for the handle the caller holds plus one per live context: the tables and the shared
+    // streams go when the last one does (a context outliving kgpu_dict_destroy keeps working).
+    std::atomic<int> refs{1};
 };
+
+static void dict_release(kgpu_dict *d) {
+    if (d->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+    (void)hipSetDevice(d->device);
+    for (hipStream_t st : d->streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (void *p : d->allocs) (void)hipFree(p);
+    delete d;
+}
 
 struct kgpu_ctx {
     kgpu_dict *dict = nullptr;
@@ -121,6 +132,7 @@ struct kgpu_ctx {
     // profiling
     bool profiling = false;   // KGPU_PROFILE_EVENTS
     bool count_work = false;  // KGPU_PROFILE_WORK
+    uint32_t stop_after = 0;  // kgpu_ctx_set_ablation: measurement mode, 0 = off
     kgpu_work work{};
     uint64_t phase[10] = {0};
     std::vector<hipEvent_t> ev_pool;
@@ -364,11 +376,13 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
 extern "C" void kgpu_dict_destroy(kgpu_dict *d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
-    for (auto *c : d->pool) kgpu_ctx_destroy(c);
-    d->pool.clear();
-    for (hipStream_t st : d->streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-    for (void *p : d->allocs) (void)hipFree(p);
-    delete d;
+    std::vector<kgpu_ctx *> pooled;
+    {
+        std::lock_guard<std::mutex> g(d->pool_mu);
+        pooled.swap(d->pool);
+    }
+    for (auto *c : pooled) kgpu_ctx_destroy(c);
+    dict_release(d);
 }
 
 extern "C" int kgpu_dict_get_info(const kgpu_dict *d, kgpu_dict_info *out) {
@@ -388,6 +402,7 @@ extern "C" int kgpu_ctx_create(kgpu_dict *d, void *hip_stream, kgpu_ctx **out) {
     HIPCHECK(hipSetDevice(d->device));
     kgpu_ctx *c = new kgpu_ctx();
     c->dict = d;
+    d->refs.fetch_add(1, std::memory_order_relaxed);
     if (hip_stream) c->stream = (hipStream_t)hip_stream;
     else {
         std::lock_guard<std::mutex> g(d->pool_mu);
@@ -395,7 +410,7 @@ extern "C" int kgpu_ctx_create(kgpu_dict *d, void *hip_stream, kgpu_ctx **out) {
         if (d->streams.size() < n_streams) {
             hipStream_t st = nullptr;
             hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-            if (e != hipSuccess) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); delete c; return KGPU_ERR_HIP; }
+            if (e != hipSuccess) { set_error("hipStreamCreate: %s", hipGetErrorString(e)); kgpu_ctx_destroy(c); return KGPU_ERR_HIP; }
             d->streams.push_back(st);
             c->stream = st;
         } else {
@@ -429,7 +444,9 @@ extern "C" void kgpu_ctx_destroy(kgpu_ctx *c) {
     c->in_utf8.release(); c->in_off.release(); c->out_tok.release(); c->out_off.release(); c->out_status.release();
     if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    kgpu_dict *d = c->dict;
     delete c;
+    dict_release(d);
 }
 
 static int next_event(kgpu_ctx *c, hipEvent_t *ev) {
@@ -457,7 +474,7 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
         const int pools_now = c->dict->big_pool_batches.load(std::memory_order_relaxed) > 0 ? c->plan.n_pools : std::min(c->plan.n_pools, 1);
         c->last_pools = pools_now;
         c->last_long = c->plan.long_lds_bytes && (c->plan.n_pools == 0 || c->dict->long_batches.load(std::memory_order_relaxed) > 0);
-        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->last_long, c->stream);
+        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->last_long, c->stop_after, c->stream);
         if (e != hipSuccess) { set_error("k_tokenize launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     }
     if (timed) HIPCHECK(hipEventRecord(e1, c->stream));
@@ -516,22 +533,21 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
             if (rc) { c->pending = false; return rc; }
             BatchArgs a = c->last;
             a.arena = (uint8_t *)c->arena.p; a.arena_bytes = c->arena.bytes;
+            c->prof.arena_regrows++;
             if ((rc = enqueue(c, a))) { c->pending = false; return rc; }
             continue;
         }
         break;
     }
     c->pending = false;
+    c->prof.batches++; c->prof.sentences += c->last.n;
+    for (int k = 0; k < 4; ++k) { c->prof.deferred[k] += c->h_ctl->ovf_count[k]; c->prof.redone[k] += c->h_ctl->late_count[k]; }
+    if (c->last_long && c->last.n) c->prof.long_launches++;
     if (c->last.n && c->plan.n_pools) {
         // The pool kernel reserves est LDS bytes per input byte up front: a reservation that proves
         // too small costs a redo (late_count), one that is too large only idles pages until the
         // lattice is known -- steer for a redo rate of 1-3 %.  Applied to the value the batch ran with; races between
         // contexts only lose an adjustment.
-        static const bool debug_print = getenv("KGPU_DEBUG_PRINT") != nullptr;
-        if (debug_print)
-            fprintf(stderr, "[kgpu] n=%llu pools=%d est=%.1f B/B deferred={%u,%u,%u} redone={%u,%u}\n", (unsigned long long)c->last.n,
-                    c->last_pools, c->last.est_q8 / 256.0, c->h_ctl->ovf_count[0], c->h_ctl->ovf_count[1], c->h_ctl->ovf_count[2],
-                    c->h_ctl->late_count[0], c->h_ctl->late_count[1]);
         if (c->last_pools > 0 && c->plan.long_lds_bytes) {  // sentences that no pool could take
             if (c->h_ctl->ovf_count[c->last_pools - 1] > 0) c->dict->long_batches.store(64, std::memory_order_relaxed);
             else if (c->last_long) c->dict->long_batches.fetch_sub(1, std::memory_order_relaxed);
@@ -579,6 +595,12 @@ extern "C" int kgpu_ctx_set_profiling(kgpu_ctx *c, int mode) {
     c->event_every = (mode & KGPU_PROFILE_SAMPLED) ? 4u : 1u;
     c->launch_seq = 0;
     c->count_work = (mode & KGPU_PROFILE_WORK) != 0;
+    return KGPU_OK;
+}
+
+extern "C" int kgpu_ctx_set_ablation(kgpu_ctx *c, int stop_after_stage) {
+    if (!c || stop_after_stage < 0 || stop_after_stage > 7) { set_error("kgpu_ctx_set_ablation: bad argument"); return KGPU_ERR_INVALID_ARG; }
+    c->stop_after = (uint32_t)stop_after_stage;
     return KGPU_OK;
 }
 

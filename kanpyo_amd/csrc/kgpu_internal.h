@@ -87,7 +87,8 @@ struct LaunchPlan {
 // Launchers (kgpu_kernels.hip).  `stream` is a hipStream_t.
 // n_pools_now <= plan.n_pools: how many of the pool launches to issue for this batch (the chain
 // stays complete without the later ones: their work falls through to the next launch).
-int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now, void *stream);
+int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now,
+                    uint32_t stop_after /* kgpu_ctx_set_ablation; 0 = run everything */, void *stream);
 int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream);  // host_ctl: device pointer of the pinned result block
 LaunchPlan default_launch_plan(int device);
 

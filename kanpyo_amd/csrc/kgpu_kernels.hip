@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         // ---- slab A: per-char arrays (C <= B) --------------------------------
         const uint64_t na = (uint64_t)B + 4;
         if (!slab_ensure(sa, na * (28 + 5 * GMAXM) + 64, a, lane)) {
-            if (lane == 0) { a.status[s] = 2; a.tok_count[s] = 0; }
+            if (lane == 0) { a.status[s] = KGPU_SENT_NO_SCRATCH; a.tok_count[s] = 0; }
             continue;
         }
         uint32_t *cbyte = (uint32_t *)sa.ptr;  // char -> byte offset, [C] = B
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         }
         __syncthreads();
 
-#define KGPU_GSTOP(k) if (stop_after == (k)) { if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = 0; } continue; }
+#define KGPU_GSTOP(k) if (stop_after == (k)) { if (lane == 0) { a.status[s] = KGPU_SENT_TRUNCATED; a.tok_count[s] = 0; } continue; }
         KGPU_GSTOP(3)
         // ---- phase 2: prefix sums ------------------------------------------------
         uint32_t ncarry = 1, bcarry = 0;  // node 0 is BOS
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
 
         // ---- slab N: per-node arrays -----------------------------------------------
         if (!slab_ensure(sn, (uint64_t)N * 44 + 64, a, lane)) {
-            if (lane == 0) { a.status[s] = 2; a.tok_count[s] = 0; }
+            if (lane == 0) { a.status[s] = KGPU_SENT_NO_SCRATCH; a.tok_count[s] = 0; }
             continue;
         }
         uint4 *nodeA = (uint4 *)sn.ptr;   // {left | right << 16, cost, bucket slot, signed id}
@@ -613,12 +613,12 @@ __global__ __launch_bounds__(256) void k_compact(BatchArgs a) {
 }
 
 int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t pool_bytes, uint32_t waves,
-                         uint32_t max_pages, int n_workgroups, void *stream);  // kgpu_pool.hip
+                         uint32_t max_pages, int n_workgroups, uint32_t stop_after, void *stream);  // kgpu_pool.hip
 int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
 
 // Launch chain: pool kernel(s), then the general (HBM scratch) kernel.  Every launch is a
 // persistent grid over its work list (the first one: the identity over [0, n)).
-int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now, void *stream) {
+int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now, uint32_t stop_after, void *stream) {
     Control *ctl = a.ctl;
     const uint32_t *in_list = nullptr;
     const unsigned int *in_count = nullptr;
@@ -628,13 +628,11 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
         uint64_t wg = plan.pool_workgroups[k];
         const uint64_t want = (a.n + plan.pool_waves[k] - 1) / plan.pool_waves[k];
         if (!in_list && want < wg) wg = want;
-        int e = launch_tokenize_pool(d, a, io, plan.pool_bytes[k], plan.pool_waves[k], plan.pool_max_pages[k], (int)(wg ? wg : 1), stream);
+        int e = launch_tokenize_pool(d, a, io, plan.pool_bytes[k], plan.pool_waves[k], plan.pool_max_pages[k], (int)(wg ? wg : 1), stop_after, stream);
         if (e) return e;
         in_list = a.ovf[li];
         in_count = &ctl->ovf_count[li];
     }
-    if (getenv("KGPU_DEBUG_SKIP_GENERAL")) return 0;
-    static const uint32_t stop_after = getenv("KGPU_DEBUG_STOP") ? (uint32_t)atoi(getenv("KGPU_DEBUG_STOP")) : 0u;
     if (long_now && plan.long_lds_bytes) {  // HBM lattice + LDS-blocked sweep; takes its whole list, leaves none
         WorkIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], nullptr};
         uint64_t wg = plan.long_workgroups;
@@ -658,7 +656,6 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
 
 int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream) {
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, host_ctl);
-    if (getenv("KGPU_DEBUG_SKIP_AUX")) return (int)hipGetLastError();
     uint64_t blocks = (a.n + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         uint64_t tick[9];
         constexpr bool prof = PROF;
 #define KGPU_TICK(k) do { if (prof) tick[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#define KGPU_STOP(k) if (stop_after == (k)) { if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = 0; } break; }
+#define KGPU_STOP(k) if (stop_after == (k)) { if (lane == 0) { a.status[s] = KGPU_SENT_TRUNCATED; a.tok_count[s] = 0; } break; }
         KGPU_TICK(0);
         // ---- phase 0a: stage the sentence in LDS, count chars -----------------
         uint8_t *text = smem;
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
                 const uint32_t ti = t - nb[q];
                 const uint32_t base = ebase[q] - eb0 + ti * P;  // pair (ti, j) lives at ti*P + j
                 const uint32_t stride = 1u;
-                const int16_t *col = d.conn + (stop_after == 8 ? (size_t)0 : (size_t)d.conn_rows * nLeft[t]);  // 8: timing experiment (one hot row)
+                const int16_t *col = d.conn + (size_t)d.conn_rows * nLeft[t];
                 uint32_t j = 0;
                 for (; j + 4 <= P; j += 4) {  // 4 independent gathers in flight per lane
                     const uint32_t r0 = bk[p0 + j].y & 0xFFFFu, r1 = bk[p0 + j + 1].y & 0xFFFFu;
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
             }
             wave_sync();
             if (prof) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
-            if (stop_after == 6) break;
+            if (stop_after == 6) break;  // (the KGPU_STOP(6) below then ends the sentence)
 
             // -- 4: Viterbi sweep over the block (lattice.rs:116-142), LDS only.
             // The sweep is one dependent chain per position, so what counts is the length of that
@@ -613,8 +613,7 @@ int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves) {
 }
 
 int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t pool_bytes, uint32_t waves,
-                         uint32_t max_pages, int n_workgroups, void *stream) {
-    static const uint32_t stop_after = getenv("KGPU_DEBUG_STOP") ? (uint32_t)atoi(getenv("KGPU_DEBUG_STOP")) : 0u;
+                         uint32_t max_pages, int n_workgroups, uint32_t stop_after, void *stream) {
     if (pool_bytes > 64 * 1024) {  // beyond the default dynamic-LDS cap the kernel has to opt in
         hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
         if (e != hipSuccess) return (int)e;

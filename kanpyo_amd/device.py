@@ -11,6 +11,7 @@ import ctypes as C
 from . import _lib
 
 PROFILE_OFF, PROFILE_EVENTS, PROFILE_WORK, PROFILE_SAMPLED = 0, 1, 2, 4
+STAGE_ALL, STAGE_LATTICE, STAGE_GATHER, STAGE_VITERBI = 0, 5, 6, 7  # kgpu_ctx_set_ablation
 
 
 class DeviceContext:
@@ -52,7 +53,14 @@ class DeviceContext:
     def profile(self, reset: bool = True) -> dict:
         p = _lib.Profile()
         _lib.check(_lib.lib().kgpu_ctx_get_profile(self._h, C.byref(p), int(reset)))
-        return {"launches": int(p.launches), "tokenize_ms": float(p.tokenize_ms), "aux_ms": float(p.aux_ms)}
+        return {"launches": int(p.launches), "tokenize_ms": float(p.tokenize_ms), "aux_ms": float(p.aux_ms),
+                "batches": int(p.batches), "sentences": int(p.sentences), "deferred": [int(x) for x in p.deferred],
+                "redone": [int(x) for x in p.redone], "long_launches": int(p.long_launches),
+                "arena_regrows": int(p.arena_regrows)}
+
+    def set_ablation(self, stop_after_stage: int):
+        """Measurement only: following batches stop after the given stage (STAGE_*), zero tokens; 0 = off."""
+        _lib.check(_lib.lib().kgpu_ctx_set_ablation(self._h, int(stop_after_stage)))
 
     def work(self, reset: bool = True) -> dict:
         w = _lib.Work()

@@ -472,32 +472,27 @@ int64_t korc_tokenize(const korc_dict *d, const uint8_t *utf8, size_t len, korc_
 
 /* ------------------------------------------------------------------ batch */
 
+/* One pass: every sentence is tokenized exactly once.  A thread owns a contiguous sentence range and
+ * writes its tokens densely -- straight into the caller's buffer when it is the only thread, else into
+ * a scratch buffer of worst-case size (tokens <= chars + 1 <= bytes + 1 per sentence) that is copied to
+ * its final place once the per-thread totals are known. */
 typedef struct {
     const korc_dict *d; const uint8_t *utf8; const uint64_t *off; uint64_t lo, hi;
-    korc_token *out; uint64_t *tok_off; /* pass 2 */
-    uint64_t *counts;                   /* pass 1 */
-    korc_counters ctr; int err; int pass;
+    korc_token *buf; uint64_t cap, used; /* dense tokens of [lo, hi) */
+    uint64_t *tok_off;                   /* tok_off[i + 1] = tokens of sentence i (prefix-summed later) */
+    korc_counters ctr; int err;
 } job_t;
 
 static void *job_run(void *arg) {
     job_t *j = (job_t *)arg;
     ws_t w; memset(&w, 0, sizeof w);
-    korc_token *tmp = NULL; size_t tcap = 0;
     for (uint64_t i = j->lo; i < j->hi; i++) {
         size_t n = (size_t)(j->off[i + 1] - j->off[i]);
-        const uint8_t *s = j->utf8 + j->off[i];
-        if (j->pass == 1) {
-            if (n + 1 > tcap) { tcap = (n + 1) * 2; tmp = (korc_token *)realloc(tmp, sizeof(korc_token) * tcap); }
-            int64_t k = tokenize_ws(j->d, s, n, tmp, tcap, &j->ctr, &w);
-            if (k < 0) { j->err = (int)k; k = 0; }
-            j->counts[i] = (uint64_t)k;
-        } else {
-            uint64_t k = j->tok_off[i + 1] - j->tok_off[i];
-            int64_t r = tokenize_ws(j->d, s, n, j->out + j->tok_off[i], (size_t)k, NULL, &w);
-            if (r < 0 && r != KORC_INVALID_UTF8) j->err = (int)r;
-        }
+        int64_t k = tokenize_ws(j->d, j->utf8 + j->off[i], n, j->buf + j->used, (size_t)(j->cap - j->used), &j->ctr, &w);
+        if (k < 0) { if (k != KORC_INVALID_UTF8 || !j->err) j->err = (int)k; if (k == KORC_CAPACITY) break; k = 0; }
+        j->tok_off[i + 1] = (uint64_t)k;
+        j->used += (uint64_t)k;
     }
-    free(tmp);
     ws_free(&w);
     return NULL;
 }
@@ -509,32 +504,38 @@ int korc_tokenize_batch(const korc_dict *d, const uint8_t *utf8, const uint64_t 
     if ((uint64_t)nthreads > n) nthreads = n ? (int)n : 1;
     job_t *jobs = (job_t *)calloc((size_t)nthreads, sizeof(job_t));
     pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
-    uint64_t *counts = (uint64_t *)calloc((size_t)(n + 1), 8);
     int err = 0;
-    for (int pass = 1; pass <= 2 && !err; pass++) {
-        for (int t = 0; t < nthreads; t++) {
-            job_t *j = &jobs[t];
-            j->d = d; j->utf8 = utf8; j->off = offsets;
-            j->lo = n * (uint64_t)t / (uint64_t)nthreads; j->hi = n * (uint64_t)(t + 1) / (uint64_t)nthreads;
-            j->out = out; j->tok_off = tok_offsets; j->counts = counts; j->pass = pass; j->err = 0;
-            if (pass == 1) memset(&j->ctr, 0, sizeof j->ctr);
-            if (nthreads == 1) job_run(j); else pthread_create(&th[t], NULL, job_run, j);
+    tok_offsets[0] = 0;
+    for (int t = 0; t < nthreads; t++) {
+        job_t *j = &jobs[t];
+        j->d = d; j->utf8 = utf8; j->off = offsets; j->tok_off = tok_offsets;
+        j->lo = n * (uint64_t)t / (uint64_t)nthreads; j->hi = n * (uint64_t)(t + 1) / (uint64_t)nthreads;
+        if (nthreads == 1) { j->buf = out; j->cap = cap; }
+        else {
+            j->cap = (offsets[j->hi] - offsets[j->lo]) + (j->hi - j->lo);
+            j->buf = (korc_token *)malloc(sizeof(korc_token) * (size_t)(j->cap ? j->cap : 1));
         }
-        for (int t = 0; t < nthreads; t++) {
-            if (nthreads > 1) pthread_join(th[t], NULL);
-            if (jobs[t].err && jobs[t].err != KORC_INVALID_UTF8) err = jobs[t].err;
-        }
-        if (pass == 1) {
-            tok_offsets[0] = 0;
-            for (uint64_t i = 0; i < n; i++) tok_offsets[i + 1] = tok_offsets[i] + counts[i];
-            if (tok_offsets[n] > cap) err = KORC_CAPACITY;
-            if (ctr) for (int t = 0; t < nthreads; t++) {
-                ctr->sentences += jobs[t].ctr.sentences; ctr->B += jobs[t].ctr.B; ctr->C += jobs[t].ctr.C;
-                ctr->T += jobs[t].ctr.T; ctr->N += jobs[t].ctr.N; ctr->E += jobs[t].ctr.E; ctr->K += jobs[t].ctr.K;
-            }
-        }
+        if (nthreads == 1) job_run(j); else pthread_create(&th[t], NULL, job_run, j);
     }
-    free(jobs); free(th); free(counts);
+    uint64_t total = 0;
+    for (int t = 0; t < nthreads; t++) {
+        if (nthreads > 1) pthread_join(th[t], NULL);
+        if (jobs[t].err && jobs[t].err != KORC_INVALID_UTF8) err = jobs[t].err;
+        total += jobs[t].used;
+    }
+    if (!err && total > cap) err = KORC_CAPACITY;
+    if (!err) {
+        for (uint64_t i = 0; i < n; i++) tok_offsets[i + 1] += tok_offsets[i];
+        if (nthreads > 1)
+            for (int t = 0; t < nthreads; t++)
+                memcpy(out + tok_offsets[jobs[t].lo], jobs[t].buf, sizeof(korc_token) * (size_t)jobs[t].used);
+    }
+    if (ctr) for (int t = 0; t < nthreads; t++) {
+        ctr->sentences += jobs[t].ctr.sentences; ctr->B += jobs[t].ctr.B; ctr->C += jobs[t].ctr.C;
+        ctr->T += jobs[t].ctr.T; ctr->N += jobs[t].ctr.N; ctr->E += jobs[t].ctr.E; ctr->K += jobs[t].ctr.K;
+    }
+    if (nthreads > 1) for (int t = 0; t < nthreads; t++) free(jobs[t].buf);
+    free(jobs); free(th);
     return err;
 }
 

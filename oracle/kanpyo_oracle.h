@@ -78,8 +78,9 @@ int64_t korc_tokenize(const korc_dict *d, const uint8_t *utf8, size_t len,
 /* Batch form used by the tests / CPU baseline: sentence i is
  * utf8[offsets[i]..offsets[i+1]).  Tokens are written densely; tok_offsets has
  * n+1 entries.  nthreads > 1 splits the sentence range contiguously over
- * pthreads (first pass counts, second pass writes).  Returns 0 or a negative
- * error. */
+ * pthreads; every sentence is tokenized exactly once (one thread writes straight
+ * into `out`, several write into per-thread worst-case buffers that are copied
+ * into place once the totals are known).  Returns 0 or a negative error. */
 int korc_tokenize_batch(const korc_dict *d, const uint8_t *utf8, const uint64_t *offsets,
                         uint64_t n, korc_token *out, uint64_t cap, uint64_t *tok_offsets,
                         int nthreads, korc_counters *ctr);

@@ -161,18 +161,26 @@ class OracleTokenizer:
             raise RuntimeError("oracle: reference would panic: " + lib().korc_last_error().decode())
         return out[:k].copy(), ctr.as_dict()
 
-    def tokenize_batch(self, utf8: np.ndarray, offsets: np.ndarray, nthreads: int = 1) -> OracleResult:
+    def tokenize_batch(self, utf8: np.ndarray, offsets: np.ndarray, nthreads: int = 1, out=None, copy: bool = True) -> OracleResult:
+        """out=(tokens[TOKEN_DTYPE, >= bytes + n], tok_offsets[uint64, n + 1]): caller-owned, reusable result
+        arrays (a timed caller keeps the allocation and its page faults out of the measurement);
+        copy=False returns views of the result arrays instead of copies."""
         utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = offsets.size - 1
         cap = int(offsets[-1] - offsets[0]) + n
-        out = np.zeros(cap, dtype=TOKEN_DTYPE)
-        toff = np.zeros(n + 1, dtype=np.uint64)
+        if out is None:
+            out_t, toff = np.zeros(cap, dtype=TOKEN_DTYPE), np.zeros(n + 1, dtype=np.uint64)
+        else:
+            out_t, toff = out
+            if out_t.dtype != TOKEN_DTYPE or toff.dtype != np.uint64 or out_t.size < cap or toff.size < n + 1:
+                raise ValueError("out=(tokens[TOKEN_DTYPE, >= bytes + n], tok_offsets[uint64, >= n + 1])")
         ctr = Counters()
         rc = lib().korc_tokenize_batch(
-            self._h, utf8.ctypes.data if utf8.size else None, offsets.ctypes.data, n, out.ctypes.data, cap,
+            self._h, utf8.ctypes.data if utf8.size else None, offsets.ctypes.data, n, out_t.ctypes.data, out_t.size,
             toff.ctypes.data, int(nthreads), C.byref(ctr),
         )
         if rc != 0:
             raise RuntimeError(f"oracle batch failed rc={rc}: " + lib().korc_last_error().decode())
-        return OracleResult(out[: int(toff[-1])].copy(), toff, ctr.as_dict())
+        toks = out_t[: int(toff[n])]
+        return OracleResult(toks.copy() if copy else toks, toff[: n + 1].copy() if copy and out is not None else toff[: n + 1], ctr.as_dict())

@@ -155,3 +155,99 @@ def test_stepwise_gather_without_concat_gloo(tmp_path):
     port = 33500 + (os.getpid() % 2000)
     mp.spawn(_worker_steps, args=(3, port, str(tmp_path)), nprocs=3, join=True)
     assert open(tmp_path / "steps").read() == "ok"
+
+
+class _OracleEngine:
+    """CPU stand-in for bench.GpuEngine (same protocol): tokens come from the oracle, tensors live on the CPU."""
+
+    def __init__(self, orc, wl):
+        self.orc, self.wl, self.done = orc, wl, {}
+
+    def nb(self, step):
+        return self.wl.nb(step)
+
+    def enqueue(self, step, b):
+        utf8, offs = self.wl.packed[step % len(self.wl.packed)][b]
+        self.done[(step, b)] = self.orc.tokenize_batch(utf8, offs, 1)
+
+    def results(self, step):
+        import torch
+
+        views, counts = [], []
+        for b in range(self.nb(step)):
+            r = self.done.pop((step, b))
+            views.append(torch.from_numpy(r.tokens.view(np.int32).reshape(-1, 6).copy()))
+            counts.append(torch.from_numpy((r.offsets[1:] - r.offsets[:-1]).astype(np.int64)))
+        return views, torch.cat(counts)
+
+    def after_gather(self):
+        pass
+
+    def drain(self):
+        assert not self.done
+
+
+def _worker_bench_job(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import bench
+    from kanpyo_amd import synth
+    from kanpyo_amd.dist import ChunkedGather, reassemble
+    from kanpyo_amd.tokenizer import pack_sentences
+    from oracle import oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sd = synth.build_dict(6000, seed=5)
+    corpora = [synth.make_corpus(sd, 301 + 7 * k, 100 + k, "cfg2") + ([""] if k == 1 else []) for k in range(3)]  # ragged shards and batches
+    orc = oracle.OracleTokenizer.from_dict(sd.dict)
+    wl = bench.Workload(corpora, rank, world, batch=64)
+    ok = True
+    for chunk_steps, nsteps in ((1, 4), (2, 5), (3, 2)):
+        chunks = {}
+        bench.run_job(_OracleEngine(orc, wl), nsteps, ChunkedGather(dst=0), chunk_steps, lambda c0, r: chunks.__setitem__(c0, r))
+        ok = ok and sorted(chunks) == list(range(0, nsteps, chunk_steps))
+        if rank != 0:
+            ok = ok and all(r is None for r in chunks.values())
+            continue
+        for c0, (tok_all, cnt_all, sizes) in chunks.items():
+            steps = range(c0, min(c0 + chunk_steps, nsteps))
+            if chunk_steps == 1:  # one step per chunk: the reassembled stream is the unsharded corpus's stream
+                n = len(corpora[c0 % 3])
+                got_t, got_off = reassemble(tok_all.numpy(), cnt_all.numpy(), n, world)
+                full = orc.tokenize_batch(*pack_sentences(corpora[c0 % 3]), 1)
+                ok = ok and np.array_equal(got_off.astype(np.uint64), full.offsets)
+                ok = ok and np.array_equal(got_t.reshape(-1), full.tokens.view(np.int32).reshape(-1))
+            exp_t, exp_c = [], []  # rank-major: every rank's steps of the chunk, in order
+            for r in range(world):
+                for s in steps:
+                    c = corpora[s % 3]
+                    e = orc.tokenize_batch(*pack_sentences([c[i] for i in range(r, len(c), world)]), 1)
+                    exp_t.append(e.tokens.view(np.int32).reshape(-1, 6))
+                    exp_c.append((e.offsets[1:] - e.offsets[:-1]).astype(np.int64))
+            ok = ok and np.array_equal(tok_all.numpy(), np.concatenate(exp_t)) and np.array_equal(cnt_all.numpy(), np.concatenate(exp_c))
+    if rank == 0:
+        open(os.path.join(tmpdir, "benchjob"), "w").write("ok" if ok else "mismatch")
+    else:
+        assert ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_job_shards_and_gathers_gloo(tmp_path):
+    """bench.py's own run_job / Workload (cfg 4: sentence i -> rank i mod G, chunked gather to rank 0) with world
+    size 2 over gloo and oracle-produced tokens: the gathered stream of every chunk is the rank-major
+    concatenation, and a one-step chunk reassembles to the unsharded corpus's token stream."""
+    import torch.multiprocessing as mp
+
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_worker_bench_job, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "benchjob").read() == "ok"
+
+
+def test_bench_chunking_rule():
+    import bench
+
+    assert [bench.chunk_steps_for(nb) for nb in (25, 13, 7, 4, 1)] == [1, 1, 2, 3, 12]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Cumulative phase cost of the LDS kernel by early-stop ablation (KGPU_DEBUG_STOP=k),
+"""Cumulative phase cost of the LDS kernel by early-stop ablation (kgpu_ctx_set_ablation),
 measured with HIP events at real occupancy.  Each value = kernel time when every
 sentence stops after phase k (1 load, 2 decode, 3 walk, 4 scan, 5 emit, 6 gather,
 7 sweep, 0 everything).  usage: python tools/ablate.py [cfg2] [n]"""
@@ -29,6 +29,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     d_toff = torch.empty(n + 1, dtype=torch.int64, device=dev)
     d_st = torch.empty(n, dtype=torch.uint8, device=dev)
     ctx = DeviceContext(tok)
+    ctx.set_ablation(int(os.environ.get("ABLATE_STOP", "0")))
     ctx.set_profiling(PROFILE_EVENTS)
     for rep in range(12):
         ctx.tokenize(d_utf8.data_ptr(), d_off.data_ptr(), n, int(offs[-1]), d_tok.data_ptr(), cap, d_toff.data_ptr(), d_st.data_ptr())
@@ -44,7 +45,7 @@ n = sys.argv[2] if len(sys.argv) > 2 else "4096"
 names = {1: "load", 2: "decode", 3: "walk", 4: "scan", 5: "emit", 6: "gather", 7: "sweep", 0: "all (+backtrace/tokens)"}
 prev = 0.0
 for k in (1, 2, 3, 4, 5, 6, 7, 0):
-    env = dict(os.environ, KGPU_DEBUG_STOP=str(k))
+    env = dict(os.environ, ABLATE_STOP=str(k))
     r = subprocess.run([sys.executable, __file__, "child", kind, n], env=env, capture_output=True, text=True, timeout=300)
     us = [float(l.split()[1]) for l in r.stdout.splitlines() if l.startswith("RESULT")]
     if not us:
