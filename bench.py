@@ -329,20 +329,20 @@ def main():
     multi = world > 1 or args.force_dist
     K, W = args.steps, args.warmup
 
+    import torch  # before libkanpyo_gpu.so (build_dict loads it): torch bundles its own libamdhip64 and must win
+    import torch.distributed as dist
+
     from kanpyo_amd import synth
 
     sd = synth.build_dict()
     extras_dir, extras_proc = None, None
-    if world == 1 and not args.no_extras:  # before torch / HIP exist in this process: fork is safe
+    if world == 1 and not args.no_extras:  # before the HIP runtime is initialised in this process: fork is safe
         import multiprocessing as mp
         import tempfile
 
         extras_dir = tempfile.mkdtemp(prefix="kanpyo_bench_")
         extras_proc = mp.get_context("fork").Process(target=_extras_child, args=(sd, extras_dir, args.cfg3_sentences), daemon=True)
         extras_proc.start()
-
-    import torch
-    import torch.distributed as dist
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X: the HIP path has no CPU fallback"
     torch.cuda.set_device(local_rank)
