@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkanpyo_gpu.so")
+# KGPU_LIB: another build of the same library (kernel experiments, tools/ only); the default is the in-tree build
+LIB_PATH = os.environ.get("KGPU_LIB") or os.path.join(_HERE, "libkanpyo_gpu.so")
 
 KGPU_OK = 0
 KGPU_ERR_INVALID_ARG = 1

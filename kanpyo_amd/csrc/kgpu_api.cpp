@@ -574,6 +574,13 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
         }
         c->ev_used = 0;
     }
+#ifdef KGPU_STEP_TIMING
+    if (!c->last.count_work) {
+        for (int k = 0; k < 10; ++k) c->phase[k] += c->h_ctl->phase[k];
+        const unsigned long long *w = c->h_ctl->work;  // measurement build: per-phase ticks ride in the work counters
+        c->work.sentences += w[0]; c->work.B += w[1]; c->work.C += w[2]; c->work.T += w[3]; c->work.N += w[4]; c->work.E += w[5]; c->work.K += w[6];
+    }
+#endif
     if (c->last.count_work) {
         const unsigned long long *w = c->h_ctl->work;
         c->work.sentences += w[0]; c->work.B += w[1]; c->work.C += w[2]; c->work.T += w[3];

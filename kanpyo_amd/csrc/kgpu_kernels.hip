@@ -713,6 +713,7 @@ LaunchPlan default_launch_plan(int device) {
         }
     }
     if (const char *e = getenv("KGPU_GENERAL_WG")) { int v = atoi(e); if (v > 0) t.general_workgroups = v; }
+    if (const char *e = getenv("KGPU_POOL_WG")) { int v = atoi(e); if (v > 0 && t.n_pools) t.pool_workgroups[0] = v; }
     return t;
 }
 

@@ -153,6 +153,13 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
     // profiling accumulators of this workgroup (flushed once at exit: per-sentence
     // atomics on a handful of hot words distort what they measure)
     uint64_t accW[7] = {0, 0, 0, 0, 0, 0, 0}, accP[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef KGPU_STEP_TIMING  // measurement build only (make timing): s_memtime ticks of the sweep, its slow-path steps, the whole sentence, the wait for pages
+    uint64_t tmS = 0, tmSteps = 0, tmSlow = 0, tmSlowSteps = 0, tmSent = 0, tmPool = 0, tmN = 0, tmDesc = 0;
+    uint64_t tmPh[7] = {0, 0, 0, 0, 0, 0, 0};  // load, decode, walk, scan, emit, gather + sweep, backtrace + tokens
+#define KGPU_TM(...) __VA_ARGS__
+#else
+#define KGPU_TM(...)
+#endif
 
     for (uint32_t iter = 0;; ++iter) {
         uint64_t s = 0;
@@ -180,14 +187,20 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         // routing: a sentence expected to need more than max_pages would hold a large part of the pool for a long
         // time (LDS x time grows with the square of the length); it is better served by the long-sentence kernel
         if (npg > max_pages) { work_defer(io, lane, s); continue; }
+        KGPU_TM(const uint64_t tm_p0 = __builtin_amdgcn_s_memtime();)
         uint32_t pg = pool_wait_alloc(bm, npg, lane);
+        KGPU_TM(const uint64_t tm_p1 = __builtin_amdgcn_s_memtime(); tmPool += tm_p1 - tm_p0;)
         if (pg == NONE) { work_defer(io, lane, s); continue; }
         for (uint32_t attempt = 0;; ++attempt) {  // at most one redo, with the exact size
         uint8_t *smem = pool + POOL_HDR + pg * page;
         const uint32_t lds_bytes = npg * page;
 
         uint64_t tick[9];
+#ifdef KGPU_STEP_TIMING
+        constexpr bool prof = true;
+#else
         constexpr bool prof = PROF;
+#endif
 #define KGPU_TICK(k) do { if (prof) tick[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #define KGPU_STOP(k) if (stop_after == (k)) { if (lane == 0) { a.status[s] = KGPU_SENT_TRUNCATED; a.tok_count[s] = 0; } break; }
         KGPU_TICK(0);
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         uint16_t *nStart = (uint16_t *)(smem + off); off += 2 * N;
         off = align_up(off, 4);
         const uint32_t off_emit_end = off;                          // everything above is written by emit
-        uint16_t *pre = (uint16_t *)(smem + off);   off += align_up(2 * N, 4);  // may overlay the match buffer
+        uint16_t *pre = (uint16_t *)(smem + off);   off += align_up(2 * N + 2, 4);  // [N]: sink; may overlay the match buffer
         int16_t *mpair = (int16_t *)(smem + off);
         if (N > 0xFFFF) { work_defer(io, lane, s); break; }
         // exact requirement: emit-written arrays stay below the match buffer; afterwards pre + the
@@ -425,130 +438,153 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
             qb = bcast32(qb);  // values read back from LDS are VGPRs to the compiler: keep the loop control scalar
             const uint32_t eb0 = bcast32(ebase[qa]);
             const uint64_t tg0 = prof ? __builtin_amdgcn_s_memtime() : 0;
-            // -- 3b: gather every connection cost of the block into LDS (connection.rs:12-14)
+            // -- 3b: gather every connection cost of the block into LDS (connection.rs:12-14).  Lane = target, four
+            // independent gathers in flight per lane, the last group of a row padded with a repeat of its final entry
+            // (ceil(P / 4) dependent rounds per target instead of P / 4 + P % 4).  Measured alternatives, all slower:
+            // eight lanes per target with eight loads in flight (more LDS bookkeeping per load than it saves in cache
+            // lines), 16 loads in flight per lane.
             const uint32_t ta = bcast32(nb[qa]), tb = bcast32(nb[qb]);
             for (uint32_t t = ta + lane; t < tb; t += 64) {
                 const uint32_t q = nStart[t];
                 const uint32_t p0 = boff[q], P = boff[q + 1] - p0;
                 const uint32_t ti = t - nb[q];
                 const uint32_t base = ebase[q] - eb0 + ti * P;  // pair (ti, j) lives at ti*P + j
-                const uint32_t stride = 1u;
                 const int16_t *col = d.conn + (size_t)d.conn_rows * nLeft[t];
-                uint32_t j = 0;
-                for (; j + 4 <= P; j += 4) {  // 4 independent gathers in flight per lane
-                    const uint32_t r0 = bk[p0 + j].y & 0xFFFFu, r1 = bk[p0 + j + 1].y & 0xFFFFu;
-                    const uint32_t r2 = bk[p0 + j + 2].y & 0xFFFFu, r3 = bk[p0 + j + 3].y & 0xFFFFu;
+                for (uint32_t j = 0; j < P; j += 4) {
+                    const uint32_t j1 = min(j + 1, P - 1), j2 = min(j + 2, P - 1), j3 = min(j + 3, P - 1);
+                    const uint32_t r0 = bk[p0 + j].y & 0xFFFFu, r1 = bk[p0 + j1].y & 0xFFFFu;
+                    const uint32_t r2 = bk[p0 + j2].y & 0xFFFFu, r3 = bk[p0 + j3].y & 0xFFFFu;
                     const int16_t c0 = col[r0], c1 = col[r1], c2 = col[r2], c3 = col[r3];
-                    mpair[base + j * stride] = c0; mpair[base + (j + 1) * stride] = c1;
-                    mpair[base + (j + 2) * stride] = c2; mpair[base + (j + 3) * stride] = c3;
+                    mpair[base + j] = c0; mpair[base + j1] = c1; mpair[base + j2] = c2; mpair[base + j3] = c3;
                 }
-                for (; j < P; ++j) mpair[base + j * stride] = col[bk[p0 + j].y & 0xFFFFu];
             }
             wave_sync();
             if (prof) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
             if (stop_after == 6) break;  // (the KGPU_STOP(6) below then ends the sentence)
 
             // -- 4: Viterbi sweep over the block (lattice.rs:116-142), LDS only.
-            // The sweep is one dependent chain per position, so what counts is the length of that
-            // chain, not arithmetic.  Position descriptors are therefore kept in VGPRs, one
-            // position per lane for 64 positions at a time, and broadcast with v_readlane (no LDS
-            // round trip, no wait); the common shape -- ceil_pow2(P) * T <= 64 lanes, P <= 16 --
-            // is straight-line code: pair (ti, j) on lane ti * Pp + j, one batch of LDS reads, a DPP
-            // butterfly min on the u64 key (total ^ signbit, predecessor node index), leaders write.
+            // One dependent chain per position: what a step costs is that chain and its taken branches, not its
+            // arithmetic (measured on one wavefront alone: LDS write -> read 86 cycles, three dependent DPP minima 43,
+            // a taken branch 32, an exec-masked block 64, descriptor read-out + scalar dispatch 52 -- tools/ubench).  So:
+            //  * per-position descriptors are ready-made LDS byte addresses, one position per lane for 64 positions at a
+            //    time, broadcast with v_readlane (no LDS round trip, no wait);
+            //  * ONE straight-line body serves 97.7 % of the positions (P <= 16; a second instantiation P <= 32): pair
+            //    (ti, j) sits on lane ti * G + j and again as (ti, j + G), G = 8 lanes per target, eight targets per pass
+            //    (one pass for nine positions in ten);
+            //  * every load is unconditional and unclamped (an index past the arrays reads someone else's LDS or zero,
+            //    and is deselected afterwards), an absent candidate is a total no real one reaches (real <= INF + 32767)
+            //    that still cannot overflow when the word cost is added -- so P = 0 ("nothing ends here") needs no case;
+            //  * there is no exec-masked region: after the butterfly every lane of a group holds the group's result, so all
+            //    of them store the same value to the same address; the groups beyond T store to a sink;
+            //  * two DPP group minima: the total, then the node index among the ties (strict '<' over ascending insertion
+            //    order, lattice.rs:125,136).
+            KGPU_TM(const uint64_t tm_s0 = __builtin_amdgcn_s_memtime();)
+            const uint32_t a_ncs = (uint32_t)((uint8_t *)nCS - pool), a_bk = (uint32_t)((uint8_t *)bk - pool);
+            const uint32_t a_mp = (uint32_t)((uint8_t *)mpair - pool), a_pre = (uint32_t)((uint8_t *)pre - pool);
+            const uint32_t a_sink_bk = a_bk + 8 * Nb, a_sink_pre = a_pre + 2 * N;
             for (uint32_t qc = qa; qc < qb; qc += 64) {
                 const uint32_t ql = qc + lane;
-                // two packed descriptor words per position: d0 = first target | first bucket slot << 16,
-                // d1 = pair offset (17 bits) | T (7) | P (5) | ceil(log2 P) (3; 7 = not the fast shape)
-                uint32_t dT = 0, dP = 0, d0 = 0, d1 = 7u << 29;
+                // three descriptor words per position: d0 = address of nCS[t0] (18 bits) | T (7) << 18 | P (6) << 25 | slow << 31,
+                // d1 = address of bk[p0], d2 = address of the position's pair costs
+                uint32_t dT = 0, dP = 0, dt0 = 0, d0 = 1u << 31, d1 = 0, d2 = 0;
                 if (ql < qb) {
-                    const uint32_t dt0 = nb[ql], dp0 = boff[ql], deb = ebase[ql] - eb0;  // deb <= mcap <= 80 Ki pairs
+                    dt0 = nb[ql];
+                    const uint32_t dp0 = boff[ql], deb = ebase[ql] - eb0;
                     dT = nb[ql + 1] - dt0;
                     dP = boff[ql + 1] - dp0;
-                    const uint32_t lgv = dP > 1 ? 32 - __clz(dP - 1) : 0;  // ceil(log2 P)
-                    const bool fastq = dP != 0 && lgv <= 4 && (dT << lgv) <= 64;
-                    d0 = dt0 | (dp0 << 16);
-                    d1 = deb | (fastq ? (dT << 17) | (dP << 24) | (lgv << 29) : 7u << 29);
+                    const bool fastq = dP <= 32 && dT - 1u < 127u;  // 1 <= T <= 127, P <= 32
+                    d0 = (a_ncs + 4 * dt0) | (fastq ? (dT << 18) | (dP << 25) : 1u << 31);
+                    d1 = a_bk + 8 * dp0;
+                    d2 = a_mp + 2 * deb;
                 }
-                const uint32_t nq = min(64u, qb - qc);
+                const uint32_t nq = bcast32(min(64u, qb - qc));
+                KGPU_TM(tmDesc += __builtin_amdgcn_s_memtime() - tm_s0;)
                 for (uint32_t r = 0; r < nq; ++r) {
                     const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)r);
                     const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)r);
-                    const uint32_t t0 = D0 & 0xFFFFu, p0 = D0 >> 16, eb = D1 & 0x1FFFFu;
-                    uint32_t lg = D1 >> 29;
-                    uint32_t T = (D1 >> 17) & 127u, P = (D1 >> 24) & 31u;
-                    if (lg != 7u) {
-                        // fast shape: one straight-line body per group size (compile-time shifts, exact
-                        // number of DPP steps, no inner branches)
-                        auto fast = [&](auto LGc) {
-                            constexpr uint32_t LG = decltype(LGc)::value;
-                            const uint32_t ti = lane >> LG, j = lane & ((1u << LG) - 1);
-                            const bool tv = ti < T;
-                            const uint32_t tt = t0 + (tv ? ti : 0);
-                            const uint32_t cs = nCS[tt];  // finalisation operands ride in the same round trip
-                            const int32_t cost = (int32_t)(int16_t)cs;
-                            const uint32_t sl = cs >> 16;
-                            // unconditional loads at clamped (always valid) indices: no exec-mask region in the chain
-                            const bool valid = tv && j < P;
-                            const uint2 e = bk[p0 + (valid ? j : 0u)];
-                            const int32_t pc = (int32_t)mpair[eb + (valid ? ti * P + j : 0u)];
-                            const int32_t v = valid ? (int32_t)e.x + pc : 0x7FFFFFFF;  // a real total is at most INF + 32767
-                            const uint32_t nd = e.y >> 16;
-                            const int32_t vmin = group_min_i32<LG>(v);
-                            const uint32_t nmin = group_min_u32<LG>(v == vmin ? nd : 0xFFFFFFFFu);
-                            if (tv && j == 0) {
-                                const int32_t tot = vmin + cost;
-                                const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
-                                pre[tt] = (uint16_t)(ok ? nmin : NONE16);
-                                bk[sl].x = (uint32_t)(ok ? tot : INF);
-                            }
+                    const uint32_t D2 = (uint32_t)__builtin_amdgcn_readlane((int)d2, (int)r);
+                    if (!(D0 >> 31)) {
+                        const uint32_t acs = D0 & 0x3FFFFu, T = (D0 >> 18) & 127u, P = D0 >> 25;
+                        const uint32_t apre = a_pre + ((acs - a_ncs) >> 1);  // pre[t0]
+                        auto pass = [&](auto LGc, uint32_t tb) {
+                            constexpr uint32_t LG = decltype(LGc)::value, G = 1u << LG;
+                            const uint32_t j = lane & (G - 1u), tl = lane >> LG;
+                            const uint32_t ti = tb + tl;
+                            const bool tv = ti < T, j0v = j < P, j1v = j + G < P;
+                            const uint32_t cs = *(const uint32_t *)(pool + acs + 4 * ti);
+                            const uint2 e0 = *(const uint2 *)(pool + D1 + 8 * j), e1 = *(const uint2 *)(pool + D1 + 8 * j + 8 * G);
+                            const uint32_t am = D2 + 2 * (__umul24(ti, P) + j);
+                            const int32_t pc0 = *(const int16_t *)(pool + am), pc1 = *(const int16_t *)(pool + am + 2 * G);
+                            __builtin_amdgcn_sched_barrier(0);  // the five reads stay one round trip
+                            constexpr int32_t ABSENT = 0x7FFEFFFF;
+                            const int32_t v0 = (tv && j0v) ? (int32_t)e0.x + pc0 : ABSENT;
+                            const int32_t v1 = (tv && j1v) ? (int32_t)e1.x + pc1 : ABSENT;
+                            const int32_t vmin = group_min_i32<LG>(min(v0, v1));
+                            const uint32_t n0 = v0 == vmin ? e0.y >> 16 : 0xFFFFFFFFu, n1 = v1 == vmin ? e1.y >> 16 : 0xFFFFFFFFu;
+                            const uint32_t nmin = group_min_u32<LG>(min(n0, n1));
+                            const int32_t tot = vmin + (int32_t)(int16_t)cs;
+                            const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
+                            *(uint16_t *)(pool + (tv ? apre + 2 * ti : a_sink_pre)) = (uint16_t)(ok ? nmin : NONE16);
+                            *(uint32_t *)(pool + (tv ? a_bk + 8 * (cs >> 16) : a_sink_bk)) = (uint32_t)(ok ? tot : INF);
                         };
-                        switch (lg) {
-                            case 0: fast(std::integral_constant<uint32_t, 0>{}); break;
-                            case 1: fast(std::integral_constant<uint32_t, 1>{}); break;
-                            case 2: fast(std::integral_constant<uint32_t, 2>{}); break;
-                            case 3: fast(std::integral_constant<uint32_t, 3>{}); break;
-                            default: fast(std::integral_constant<uint32_t, 4>{}); break;
+                        if (P <= 16) {
+                            pass(std::integral_constant<uint32_t, 3>{}, 0u);
+                            if (T > 8) for (uint32_t tb = 8; tb < T; tb += 8) pass(std::integral_constant<uint32_t, 3>{}, tb);
+                        } else {
+                            for (uint32_t tb = 0; tb < T; tb += 4) pass(std::integral_constant<uint32_t, 4>{}, tb);
                         }
-                    } else if ((T = (uint32_t)__builtin_amdgcn_readlane((int)dT, (int)r),
-                                P = (uint32_t)__builtin_amdgcn_readlane((int)dP, (int)r)) == 0) {
-                        // nothing ends here: every target stays at INF with no predecessor
-                        for (uint32_t t = t0 + lane; t < t0 + T; t += 64) {
-                            pre[t] = NONE16;
-                            bk[nCS[t] >> 16].x = (uint32_t)INF;
-                        }
-                    } else if (T) {  // any shape: loop over target groups and predecessor chunks
-                        lg = P > 1 ? 32 - __clz(P - 1) : 0;
-                        if (lg > 6) lg = 6;
-                        const uint32_t j = lane & ((1u << lg) - 1), tl = lane >> lg, TG = 64u >> lg;
-                        for (uint32_t tbase = 0; tbase < T; tbase += TG) {
-                            const uint32_t ti = tbase + tl;
-                            const bool tvalid = ti < T;
-                            const uint32_t cs = tvalid ? nCS[t0 + ti] : 0u;
-                            const int32_t cost = (int32_t)(int16_t)cs;
-                            const uint32_t sl = cs >> 16;
-                            uint64_t key = ~0ull;
-                            for (uint32_t jc = 0; jc < P; jc += 64) {
-                                const uint32_t jj = jc + j;
-                                uint64_t ck = ~0ull;
-                                if (tvalid && jj < P) {
-                                    const uint2 e = bk[p0 + jj];
-                                    const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + ti * P + jj];
-                                    ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (e.y >> 16);
+                    } else {
+                        KGPU_TM(tmSlowSteps += 1; const uint64_t tm_sl0 = __builtin_amdgcn_s_memtime();)
+                        const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)dT, (int)r);
+                        const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)dP, (int)r);
+                        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)dt0, (int)r);
+                        const uint32_t p0 = (D1 - a_bk) >> 3, eb = (D2 - a_mp) >> 1;
+                        if (P == 0) {
+                            // nothing ends here: every target stays at INF with no predecessor
+                            for (uint32_t t = t0 + lane; t < t0 + T; t += 64) {
+                                pre[t] = NONE16;
+                                bk[nCS[t] >> 16].x = (uint32_t)INF;
+                            }
+                        } else if (T) {  // any shape: loop over target groups and predecessor chunks
+                            uint32_t lg = P > 1 ? 32 - __clz(P - 1) : 0;
+                            if (lg > 6) lg = 6;
+                            const uint32_t jj0 = lane & ((1u << lg) - 1), tg = lane >> lg, TG = 64u >> lg;
+                            for (uint32_t tbase = 0; tbase < T; tbase += TG) {
+                                const uint32_t ti = tbase + tg;
+                                const bool tvalid = ti < T;
+                                const uint32_t cs = tvalid ? nCS[t0 + ti] : 0u;
+                                const int32_t cost = (int32_t)(int16_t)cs;
+                                const uint32_t sl = cs >> 16;
+                                uint64_t key = ~0ull;
+                                for (uint32_t jc = 0; jc < P; jc += 64) {
+                                    const uint32_t jj = jc + jj0;
+                                    uint64_t ck = ~0ull;
+                                    if (tvalid && jj < P) {
+                                        const uint2 e = bk[p0 + jj];
+                                        const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + ti * P + jj];
+                                        ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (e.y >> 16);
+                                    }
+                                    ck = group_min(ck, lg);
+                                    key = ck < key ? ck : key;
                                 }
-                                ck = group_min(ck, lg);
-                                key = ck < key ? ck : key;
-                            }
-                            if (tvalid && j == 0) {
-                                const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + cost;
-                                const bool ok = tot < INF;
-                                pre[t0 + ti] = (uint16_t)(ok ? ((uint32_t)key & 0xFFFFu) : NONE16);
-                                bk[sl].x = (uint32_t)(ok ? tot : INF);
+                                if (tvalid && jj0 == 0) {
+                                    const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + cost;
+                                    const bool ok = tot < INF;
+                                    pre[t0 + ti] = (uint16_t)(ok ? ((uint32_t)key & 0xFFFFu) : NONE16);
+                                    bk[sl].x = (uint32_t)(ok ? tot : INF);
+                                }
                             }
                         }
+                        wave_sync();
+                        KGPU_TM(tmSlow += __builtin_amdgcn_s_memtime() - tm_sl0;)
                     }
-                    wave_sync();
+                    // no fence per step: the LDS unit executes one wavefront's DS instructions in issue order, so the next
+                    // position's reads see these writes; a fence would make every step wait for the write acknowledgement
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
+            wave_sync();
+            KGPU_TM(tmS += __builtin_amdgcn_s_memtime() - tm_s0; tmSteps += qb - qa;)
             qa = qb;
         }
 
@@ -584,6 +620,9 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
             }
         }
         if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; }
+        KGPU_TM(const uint64_t tm_e = __builtin_amdgcn_s_memtime(); tmSent += tm_e - tm_p1; tmN += 1;
+                for (int k = 0; k < 6; ++k) tmPh[k] += tick[k + 1] - tick[k];
+                tmPh[6] += tm_e - tick[6];)
         if constexpr (PROF) {
             wT = wave_sum(wT);
             const uint64_t t7 = __builtin_amdgcn_s_memtime();
@@ -596,6 +635,13 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         }  // attempt
         if (pg != NONE) pool_free(bm, pg, 0, npg, lane);
     }
+#ifdef KGPU_STEP_TIMING
+    if (!PROF && lane == 0) {
+        const uint64_t tm[8] = {tmS, tmSteps, tmSlow, tmSlowSteps, tmSent, tmPool, tmN, tmDesc};
+        for (int k = 0; k < 8; ++k) atomicAdd(&a.ctl->phase[k], (unsigned long long)tm[k]);
+        for (int k = 0; k < 7; ++k) atomicAdd(&a.ctl->work[k], (unsigned long long)tmPh[k]);
+    }
+#endif
     if (PROF && lane == 0) {
         for (int k = 0; k < 7; ++k) atomicAdd(&a.ctl->work[k], (unsigned long long)accW[k]);
         for (int k = 0; k < 9; ++k) atomicAdd(&a.ctl->phase[k], (unsigned long long)accP[k]);
