@@ -10,7 +10,8 @@ Token ids are defined by the sort order of the records (derived `Ord` of
 `Record`, builder/record.rs:5-19), so that order is reproduced exactly; the
 double array comes from `kgpu_index_build`, byte-identical to the reference's
 packing.  The real mecab-ipadic sources are absent here, so this is exercised
-on small hand-written MeCab-format inputs only.
+on small hand-written MeCab-format inputs only: parity of a dictionary built here
+from mecab-ipadic with the reference's own build is UNVERIFIED.
 """
 from __future__ import annotations
 
@@ -106,8 +107,49 @@ def parse_char_def(text: str):
     return char_class, cat, np.array(invoke, dtype=np.uint8), np.array(group, dtype=np.uint8)
 
 
+def decode_euc_jp(data: bytes) -> str:
+    """EUC-JP as encoding_rs::EUC_JP decodes it (the WHATWG Encoding Standard's decoder, which the reference
+    uses: builder/record.rs:21-26): JIS X 0208 through the Windows-31J (CP932) table -- U+FF5E for 0xA1C1 where
+    Python's own 'euc_jp' codec gives U+301C, likewise 0xA1C2 / 0xA1DD / 0xA1F1 / 0xA1F2 / 0xA2CC and NEC row 13 --
+    half-width katakana behind 0x8E, JIS X 0212 behind 0x8F.  Surfaces decide the record sort order and with it
+    every token id, so the table has to be the reference's.  Raises BuilderError("EncodingError") where the
+    reference's `had_errors` is set."""
+    out = []
+    i, n = 0, len(data)
+    try:
+        while i < n:
+            b = data[i]
+            if b < 0x80:
+                j = i + 1
+                while j < n and data[j] < 0x80:
+                    j += 1
+                out.append(data[i:j].decode("ascii"))
+                i = j
+            elif b == 0x8E and i + 1 < n and 0xA1 <= data[i + 1] <= 0xDF:
+                out.append(chr(0xFF61 - 0xA1 + data[i + 1]))
+                i += 2
+            elif b == 0x8F and i + 2 < n and 0xA1 <= data[i + 1] <= 0xFE and 0xA1 <= data[i + 2] <= 0xFE:
+                out.append(data[i : i + 3].decode("euc_jp"))  # JIS X 0212
+                i += 3
+            elif 0xA1 <= b <= 0xFE and i + 1 < n and 0xA1 <= data[i + 1] <= 0xFE:
+                ku, ten = b - 0xA0, data[i + 1] - 0xA0
+                s1 = ((ku - 1) >> 1) + (0x81 if ku <= 62 else 0xC1)
+                s2 = ten + 0x3F + (1 if ten >= 64 else 0) if ku & 1 else ten + 0x9E
+                out.append(bytes((s1, s2)).decode("cp932"))
+                i += 2
+            else:
+                raise UnicodeDecodeError("euc-jp", data, i, i + 1, "invalid EUC-JP sequence")
+    except UnicodeDecodeError as e:
+        raise BuilderError("EncodingError") from e
+    return "".join(out)
+
+
 def _rows(text: str):
-    return [r for r in csv.reader(io.StringIO(text)) if r]
+    rows = [r for r in csv.reader(io.StringIO(text)) if r]
+    for r in rows:  # csv::ReaderBuilder (flexible = false): every record has the first record's field count
+        if len(r) != len(rows[0]):
+            raise BuilderError(f"CSV error: record with {len(r)} fields, expected {len(rows[0])}: {r!r}")
+    return rows
 
 
 def parse_csv(text: str):
@@ -162,10 +204,13 @@ def build_from_dir(root: str, encoding: str = "euc_jp") -> DictFile:
     """`ipa_dict_builder --dict <root>` (bin/ipa_dict_builder.rs:38-59, builder/config.rs:18-27)."""
     def read(name, enc):
         with open(os.path.join(root, name), "rb") as f:
-            try:
-                return f.read().decode(enc)
-            except UnicodeDecodeError as e:
-                raise BuilderError("EncodingError") from e
+            raw = f.read()
+        if enc.lower().replace("-", "_") == "euc_jp":
+            return decode_euc_jp(raw)
+        try:
+            return raw.decode(enc)
+        except UnicodeDecodeError as e:
+            raise BuilderError("EncodingError") from e
 
     records = []
     for name in os.listdir(root):

@@ -677,16 +677,19 @@ LaunchPlan default_launch_plan(int device) {
         t.long_lds_bytes = (uint32_t)kib * 1024;
         t.long_workgroups = kib ? cus * (160 / kib) : 0;
     }
-    // Default: two 80 KB pools per CU with 8 wavefronts each (16 sentences in flight per CU, any mix of
-    // sizes; smaller workgroups drain sooner at the tail of a 4096-sentence batch than one 160 KB /
-    // 16-wavefront workgroup).  A sentence expected to need more than 20 of a pool's 64 pages (25 KB,
-    // ~140 chars) goes to the long-sentence kernel instead: LDS x time grows with the square of the
-    // length, and a few long sentences would otherwise hold the pools while the short ones wait
-    // (cfg 3: 3.6 -> 7.3 M sentences/s).  KGPU_POOL="<KiB>:<wavefronts>[:<max pages>][,...]", "0" = none.
+    // Default: four 40 KB pools per CU with 4 wavefronts each (16 sentences in flight per CU, any mix of
+    // sizes).  A workgroup holds its LDS until its last wavefront is through, and the next launch's workgroups
+    // start only then: four-wavefront workgroups drain sooner at the tail of a 4096-sentence batch than eight-
+    // or sixteen-wavefront ones (80:8 66.3, 160:16 63.9, 40:4 68.6 M sentences/s; two-wavefront pools lose to
+    // fragmentation, and any shape that is not 16 wavefronts per CU loses to the batch size: 4096 = 256 x 16).
+    // A sentence expected to need more than 32 of a pool's 64 pages (20 KB, ~110 chars) goes to the
+    // long-sentence kernel instead: LDS x time grows with the square of the length, and a few long sentences
+    // would otherwise hold the pools while the short ones wait.
+    // KGPU_POOL="<KiB>:<wavefronts>[:<max pages>][,...]", "0" = none.
     t.n_pools = 0;
     {
         const char *e = getenv("KGPU_POOL");
-        const char *q = e ? e : "80:8:20";
+        const char *q = e ? e : "40:4:32";
         while (*q && t.n_pools < 2) {
             int kib = atoi(q), w = 8, mp = 64;
             const char *c = q;

@@ -13,6 +13,7 @@ The MorphFeatureTable (display strings) is not on the hot path and is not carrie
 from __future__ import annotations
 
 import ctypes as C
+import json
 import struct
 from dataclasses import dataclass, field
 from typing import Iterable, Mapping, Sequence
@@ -115,12 +116,12 @@ class Dict:
             morph_dict=np.frombuffer(self.morph_dict, dtype=np.uint8),
             unk_dict=np.frombuffer(self.unk_dict, dtype=np.uint8), char_category=self.char_category,
             invoke_list=self.invoke_list, group_list=self.group_list,
-            char_class=np.array(list(self.char_class), dtype=object),
+            char_class=np.frombuffer(json.dumps(list(self.char_class), ensure_ascii=False).encode("utf-8"), dtype=np.uint8),
         )
 
     @classmethod
     def load_npz(cls, path) -> "Dict":
-        z = np.load(path, allow_pickle=True)
+        z = np.load(path, allow_pickle=False)  # plain arrays only: a dictionary cache must not be able to run code
         return cls(z["index_dict"].tobytes(), z["connection_dict"].tobytes(), z["morph_dict"].tobytes(),
                    z["unk_dict"].tobytes(), z["char_category"], z["invoke_list"], z["group_list"],
-                   [str(x) for x in z["char_class"]])
+                   [str(x) for x in json.loads(z["char_class"].tobytes().decode("utf-8"))])

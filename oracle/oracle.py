@@ -50,7 +50,7 @@ def build(force: bool = False, asan: bool = False) -> str:
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        L = C.CDLL(build(asan=bool(os.environ.get("KORC_ASAN"))))  # KORC_ASAN=1: the ASan/UBSan build (tests/test_oracle_sanitize.py)
         u8p = C.c_void_p
         L.korc_last_error.restype = C.c_char_p
         L.korc_dict_from_blobs.restype = C.c_void_p

@@ -98,3 +98,43 @@ def test_end_to_end_build_and_ids(tmp_path):
 def test_cost_overflow_is_an_error():
     with pytest.raises(builder.BuilderError):
         builder.build([("あ", 1, 1, 40000, ["x"])], _matrix(), CHAR_DEF, [])
+
+
+def test_euc_jp_decoder_is_the_whatwg_one():
+    """encoding_rs::EUC_JP (builder/record.rs:21-26) is the WHATWG decoder: JIS X 0208 through the Windows-31J table.
+    Python's own 'euc_jp' codec differs in exactly these cells -- and surfaces decide the record order, hence every id."""
+    cells = {b"\xa1\xc1": "～", b"\xa1\xc2": "∥", b"\xa1\xdd": "－", b"\xa1\xf1": "￠", b"\xa1\xf2": "￡",
+             b"\xa2\xcc": "￢", b"\xa1\xc0": "＼", b"\xad\xa1": "①", b"\x8e\xb1": "ｱ"}
+    for raw, ch in cells.items():
+        assert builder.decode_euc_jp(raw) == ch
+    assert b"\xa1\xc1".decode("euc_jp") == "〜"  # the codec this module must NOT use
+    text = "東京都に住む、カタカナ123abc"
+    assert builder.decode_euc_jp(text.encode("euc_jp")) == text
+    for bad in (b"\xa1", b"\xff\xa1", b"\x8e\x41", b"\xa9\xa1"):  # truncated, invalid lead, bad kana trail, unassigned cell
+        with pytest.raises(builder.BuilderError):
+            builder.decode_euc_jp(bad)
+
+
+def test_build_from_euc_jp_directory(tmp_path):
+    """`ipa_dict_builder` reads EUC-JP sources (bin/ipa_dict_builder.rs:38-59): the same directory in EUC-JP and in UTF-8
+    gives the same dictionary, with a WAVE DASH cell (0xA1C1) landing on U+FF5E as in the reference."""
+    lex = LEX_A + "～,1,1,900,記号,一般,*,*,*,*,～,～,～\n"
+    euc, utf = tmp_path / "euc", tmp_path / "utf"
+    euc.mkdir(); utf.mkdir()
+    enc = lambda t: b"".join(b"\xa1\xc1" if ch == "～" else ch.encode("euc_jp") for ch in t)  # noqa: E731
+    for name, text in (("a.csv", lex), ("b.csv", LEX_B), ("char.def", CHAR_DEF), ("unk.def", UNK_DEF)):
+        (euc / name).write_bytes(enc(text))
+        (utf / name).write_bytes(text.encode("utf-8"))
+    for d in (euc, utf):
+        (d / "matrix.def").write_bytes(_matrix().encode())
+    a, b = builder.build_from_dir(str(euc)), builder.build_from_dir(str(utf), encoding="utf-8")
+    assert a.dict.index_dict == b.dict.index_dict and a.dict.morph_dict == b.dict.morph_dict and a.dict.unk_dict == b.dict.unk_dict
+    assert a.morph_feature_table == b.morph_feature_table
+    from oracle import oracle
+    toks, _ = oracle.OracleTokenizer.from_dict(a.dict).tokenize("東京～")
+    assert [int(t["cls"]) for t in toks] == [1, 1, 0]  # both known: the ～ record is found under U+FF5E
+
+
+def test_ragged_csv_is_rejected():
+    with pytest.raises(builder.BuilderError):  # csv::Reader with flexible = false (record.rs:27-31)
+        builder.parse_csv("あ,1,1,10,x,y\nい,1,1,10,x\n")
