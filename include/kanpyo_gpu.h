@@ -199,6 +199,33 @@ int kgpu_ctx_get_work(kgpu_ctx *c, kgpu_work *out, int reset);
  * sweep, backtrace+tokens, [8] = sentences counted, [9] spare. */
 int kgpu_ctx_get_phase_cycles(kgpu_ctx *c, uint64_t out[10], int reset);
 
+/* Lattice (reference src/lattice.rs:6-10: pub nodes, pub edges) of ONE sentence, read back from the device after
+ * Lattice::build + the forward pass of Lattice::viterbi -- the debugging aid behind the reference's `kanpyo graphviz`
+ * (src/graphviz.rs:30-163, src/bin/kanpyo.rs:127-148).  Nodes are in the reference's insertion order (BOS = 0, EOS last);
+ * edges[e] = the nodes ENDING at char position e, ascending, as offsets into edge_nodes (n_positions + 1 entries,
+ * n_positions = chars + 2).  Context ids are the dictionary's own (not the device's frequency-ranked ones).
+ * dp / pre are the Viterbi state of src/lattice.rs:118-141: dp = 1 << 30 where unreached, BOS has dp 0 ("None") and
+ * pre -1.  Runs the HBM-scratch kernel alone (any sentence length); not a fast path.  Free with kgpu_lattice_free. */
+typedef struct kgpu_lattice_node {
+    int32_t id;          /* Node::id(): KeywordID, 0 for BOS / EOS              (src/lattice/node.rs:27-32) */
+    uint32_t cls;        /* KGPU_CLASS_DUMMY / KNOWN / UNKNOWN                                              */
+    uint32_t byte_pos;   /* byte offset of the surface in the sentence                                      */
+    uint32_t char_pos;   /* char index where the node starts                                                */
+    uint32_t end_char;   /* char index where it ends (EOS: char_pos; BOS: 0)                                */
+    uint32_t byte_len;   /* surface length in bytes                                                         */
+    int16_t left_id, right_id, cost, reserved; /* Morph (kanpyo-dict/src/morph.rs:7-11)                     */
+    int32_t dp;          /* best total cost up to and including this node                                   */
+    int32_t pre;         /* best predecessor node index, -1 = None                                          */
+} kgpu_lattice_node;
+typedef struct kgpu_lattice {
+    uint64_t n_nodes, n_positions;
+    kgpu_lattice_node *nodes;
+    uint32_t *edge_offsets; /* n_positions + 1 */
+    uint32_t *edge_nodes;   /* n_nodes         */
+} kgpu_lattice;
+int kgpu_lattice_dump(kgpu_dict *d, const uint8_t *utf8, uint64_t len, kgpu_lattice *out);
+void kgpu_lattice_free(kgpu_lattice *l);
+
 /* IndexTable::build + write_dict (kanpyo-dict/src/index.rs:16-38,75-84 over
  * trie/da.rs:22-131,191-217): sorted keywords (duplicates adjacent) -> the
  * index.dict blob, byte-identical to the reference's first-fit packing.  Host

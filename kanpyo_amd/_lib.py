@@ -24,7 +24,7 @@ SYMBOLS = [
     "kgpu_last_error", "kgpu_device_count", "kgpu_dict_create", "kgpu_dict_destroy", "kgpu_dict_get_info",
     "kgpu_tokenize_batch", "kgpu_ctx_create", "kgpu_ctx_destroy", "kgpu_tokenize_device", "kgpu_ctx_sync",
     "kgpu_ctx_set_profiling", "kgpu_ctx_set_ablation", "kgpu_ctx_get_profile", "kgpu_ctx_get_work", "kgpu_ctx_get_phase_cycles", "kgpu_index_build", "kgpu_free",
-    "kgpu_host_alloc", "kgpu_host_free",
+    "kgpu_host_alloc", "kgpu_host_free", "kgpu_lattice_dump", "kgpu_lattice_free",
 ]
 
 
@@ -53,6 +53,17 @@ class Profile(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("tokenize_ms", C.c_double), ("aux_ms", C.c_double),
                 ("batches", C.c_uint64), ("sentences", C.c_uint64), ("deferred", C.c_uint64 * 4), ("redone", C.c_uint64 * 4),
                 ("long_launches", C.c_uint64), ("arena_regrows", C.c_uint64)]
+
+
+class LatticeNode(C.Structure):
+    _fields_ = [("id", C.c_int32), ("cls", C.c_uint32), ("byte_pos", C.c_uint32), ("char_pos", C.c_uint32), ("end_char", C.c_uint32),
+                ("byte_len", C.c_uint32), ("left_id", C.c_int16), ("right_id", C.c_int16), ("cost", C.c_int16), ("reserved", C.c_int16),
+                ("dp", C.c_int32), ("pre", C.c_int32)]
+
+
+class LatticeOut(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("n_positions", C.c_uint64), ("nodes", C.POINTER(LatticeNode)),
+                ("edge_offsets", C.POINTER(C.c_uint32)), ("edge_nodes", C.POINTER(C.c_uint32))]
 
 
 class Work(C.Structure):
@@ -98,6 +109,9 @@ def lib():
         L.kgpu_host_alloc.restype = vp
         L.kgpu_host_free.argtypes = [vp]
         L.kgpu_host_free.restype = None
+        L.kgpu_lattice_dump.argtypes = [vp, vp, C.c_uint64, C.POINTER(LatticeOut)]
+        L.kgpu_lattice_free.argtypes = [C.POINTER(LatticeOut)]
+        L.kgpu_lattice_free.restype = None
         _lib = L
     return _lib
 

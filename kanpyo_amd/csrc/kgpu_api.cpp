@@ -96,6 +96,7 @@ struct kgpu_dict {
     // number of contexts shares three streams; each context waits on its own completion event.
     std::vector<hipStream_t> streams;
     unsigned next_stream = 0;
+    std::vector<uint32_t> left_of_rank, right_of_rank;  // device (ranked) context id -> the dictionary's own; empty = identity
     // One reference for the handle the caller holds plus one per live context: the tables and the shared
     // streams go when the last one does (a context outliving kgpu_dict_destroy keeps working).
     std::atomic<int> refs{1};
@@ -297,6 +298,7 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
     // cache line, and the frequent rows' first lines stay L1-resident.  The sweep's dominant L2
     // consumer is exactly this gather (connection.rs:12-14 once per relaxation).
     uint32_t bos_right = 0, eos_left = 0;
+    std::vector<uint32_t> rank_r, rank_l;  // id -> rank, kept (inverted) for kgpu_lattice_dump
     {
         bool in_range = true;  // remap only when every id is a plain (row, col) index
         for (auto *v : {&morphs, &unk_morphs})
@@ -320,6 +322,7 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
             for (auto *v : {&morphs, &unk_morphs})
                 for (auto &m : *v) { m.right = (int16_t)rmap[m.right]; m.left = (int16_t)lmap[m.left]; }
             bos_right = rmap[0]; eos_left = lmap[0];
+            rank_r = rmap; rank_l = lmap;
         }
     }
 
@@ -333,6 +336,9 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
     HIPCHECK(hipSetDevice(device));
     kgpu_dict *d = new kgpu_dict();
     d->device = device;
+    d->right_of_rank.resize(rank_r.size()); d->left_of_rank.resize(rank_l.size());
+    for (uint32_t i = 0; i < rank_r.size(); ++i) d->right_of_rank[rank_r[i]] = i;
+    for (uint32_t i = 0; i < rank_l.size(); ++i) d->left_of_rank[rank_l[i]] = i;
     std::vector<uint8_t> cat(b->char_category, b->char_category + b->char_category_len);
     int rc;
     // First-character jump table: the walk from every start position begins with a whole
@@ -757,6 +763,93 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
         return KGPU_ERR_CAPACITY;
     }
     return rc;
+}
+
+// ----------------------------------------------------------------- lattice dump
+extern "C" int kgpu_lattice_dump(kgpu_dict *d, const uint8_t *utf8, uint64_t len, kgpu_lattice *out) {
+    if (!d || !out || (len && !utf8)) { set_error("kgpu_lattice_dump: null argument"); return KGPU_ERR_INVALID_ARG; }
+    if (len >= (1ull << 31)) { set_error("kgpu_lattice_dump: sentence too long"); return KGPU_ERR_INVALID_ARG; }
+    *out = kgpu_lattice{};
+    HIPCHECK(hipSetDevice(d->device));
+    kgpu_ctx *c = nullptr;
+    {
+        std::lock_guard<std::mutex> g(d->pool_mu);
+        if (!d->pool.empty()) { c = d->pool.back(); d->pool.pop_back(); }
+    }
+    int rc = KGPU_OK;
+    if (!c && (rc = kgpu_ctx_create(d, nullptr, &c))) return rc;
+    auto give_back = [&]() { std::lock_guard<std::mutex> g(d->pool_mu); d->pool.push_back(c); };
+    const uint64_t offs[2] = {0, len};
+    Control hc{};
+    if ((c->pending && (rc = kgpu_ctx_sync(c, nullptr)) != KGPU_OK && rc != KGPU_ERR_CAPACITY) ||
+        (rc = c->arena.ensure(ARENA_INITIAL)) || (rc = c->stage.ensure((size_t)(len + 2) * sizeof(kgpu_token) + 64)) ||
+        (rc = c->tok_count.ensure(8)) || (rc = c->in_utf8.ensure((size_t)len + 16)) || (rc = c->in_off.ensure(16)) ||
+        (rc = c->out_status.ensure(16))) { give_back(); return rc; }
+    auto fail = [&](hipError_t e, const char *what) { set_error("kgpu_lattice_dump: %s: %s", what, hipGetErrorString(e)); c->ctl_dirty = true; give_back(); return KGPU_ERR_HIP; };
+    hipError_t e;
+    if (len && (e = hipMemcpyAsync(c->in_utf8.p, utf8, (size_t)len, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return fail(e, "H2D");
+    if ((e = hipMemcpyAsync(c->in_off.p, offs, 16, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return fail(e, "H2D");
+    for (;;) {
+        BatchArgs a{};
+        a.utf8 = (const uint8_t *)c->in_utf8.p; a.offsets = (const uint64_t *)c->in_off.p; a.n = 1; a.ctl = c->d_ctl;
+        a.arena = (uint8_t *)c->arena.p; a.arena_bytes = c->arena.bytes;
+        a.stage = (kgpu_token *)c->stage.p; a.tok_count = (uint32_t *)c->tok_count.p; a.status = (uint8_t *)c->out_status.p;
+        a.dump_lattice = 1;
+        c->ctl_dirty = true;  // no scan kernel behind this launch: the next batch zeroes the block itself
+        if ((e = hipMemsetAsync(c->d_ctl, 0, sizeof(Control), c->stream)) != hipSuccess) return fail(e, "memset");
+        if ((e = (hipError_t)launch_general_only(d->view, a, c->stream)) != hipSuccess) return fail(e, "launch");
+        if ((e = hipMemcpyAsync(&hc, c->d_ctl, sizeof(Control), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return fail(e, "D2H");
+        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail(e, "sync");
+        if (!hc.arena_overflow) break;
+        size_t want = c->arena.bytes * 2;
+        if (want > ARENA_MAX) { set_error("scratch arena exceeded %zu bytes", ARENA_MAX); give_back(); return KGPU_ERR_INTERNAL; }
+        if ((rc = c->arena.ensure(want))) { give_back(); return rc; }
+    }
+    if (!hc.dump[5]) { set_error("kgpu_lattice_dump: the sentence is not valid UTF-8"); give_back(); return KGPU_ERR_INVALID_ARG; }
+    const uint64_t B = hc.dump[2], C = hc.dump[3], N = hc.dump[4], na = B + 4;
+    std::vector<uint32_t> cbyte(C + 1), boff(C + 2), pre(N);
+    std::vector<uint32_t> nodeA(4 * N), bucket(4 * N), nodeB(2 * N);
+    const uint8_t *sa = (const uint8_t *)c->arena.p + hc.dump[0], *sn = (const uint8_t *)c->arena.p + hc.dump[1];
+    // slab layouts: k_tokenize_general (kgpu_kernels.hip): cbyte | uspan | nb | boff | ... (u32[na] each); nodeA | bucket | nodeB | pre
+    if ((e = hipMemcpy(cbyte.data(), sa, (C + 1) * 4, hipMemcpyDeviceToHost)) != hipSuccess ||
+        (e = hipMemcpy(boff.data(), sa + 3 * na * 4, (C + 2) * 4, hipMemcpyDeviceToHost)) != hipSuccess ||
+        (e = hipMemcpy(nodeA.data(), sn, N * 16, hipMemcpyDeviceToHost)) != hipSuccess ||
+        (e = hipMemcpy(bucket.data(), sn + N * 16, N * 16, hipMemcpyDeviceToHost)) != hipSuccess ||
+        (e = hipMemcpy(nodeB.data(), sn + N * 32, N * 8, hipMemcpyDeviceToHost)) != hipSuccess ||
+        (e = hipMemcpy(pre.data(), sn + N * 40, N * 4, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "slab read-back");
+    give_back();
+    out->n_nodes = N; out->n_positions = C + 2;
+    out->nodes = (kgpu_lattice_node *)calloc((size_t)N, sizeof(kgpu_lattice_node));
+    out->edge_offsets = (uint32_t *)calloc((size_t)C + 3, 4);
+    out->edge_nodes = (uint32_t *)calloc((size_t)N, 4);
+    if (!out->nodes || !out->edge_offsets || !out->edge_nodes) { kgpu_lattice_free(out); set_error("kgpu_lattice_dump: out of memory"); return KGPU_ERR_INTERNAL; }
+    auto orig = [](const std::vector<uint32_t> &inv, uint32_t r) { return (int16_t)(inv.empty() || r >= inv.size() ? r : inv[r]); };
+    for (uint64_t t = 0; t < N; ++t) {
+        kgpu_lattice_node &nd = out->nodes[t];
+        if (t == 0) { nd.pre = -1; continue; }  // BOS: Dummy at 0 with Morph(0, 0, 0); dp None
+        const uint32_t *A = &nodeA[4 * t];
+        const int32_t sid = (int32_t)A[3];
+        const uint32_t st = nodeB[2 * t], en = nodeB[2 * t + 1];
+        nd.id = sid < 0 ? -sid : sid;
+        nd.cls = sid > 0 ? KGPU_CLASS_KNOWN : sid < 0 ? KGPU_CLASS_UNKNOWN : KGPU_CLASS_DUMMY;
+        nd.char_pos = st; nd.end_char = en; nd.byte_pos = cbyte[st]; nd.byte_len = cbyte[en] - cbyte[st];
+        if (sid != 0) { nd.left_id = orig(d->left_of_rank, A[0] & 0xFFFFu); nd.right_id = orig(d->right_of_rank, A[0] >> 16); nd.cost = (int16_t)(int32_t)A[1]; }
+        nd.dp = A[2] == 0xFFFFFFFFu ? (int32_t)hc.dump[6] : (int32_t)bucket[4 * A[2]];
+        nd.pre = pre[t] == 0xFFFFFFFFu ? -1 : (int32_t)pre[t];
+    }
+    // edges[e] = nodes ending at e, ascending node index (the kernel fills a bucket in arrival order)
+    for (uint64_t e2 = 0; e2 <= C + 1; ++e2) out->edge_offsets[e2] = e2 <= C + 1 && e2 < boff.size() ? boff[e2] : 0;
+    out->edge_offsets[C + 1] = (uint32_t)(N - 1); out->edge_offsets[C + 2] = (uint32_t)N;
+    for (uint64_t sl = 0; sl + 1 < N; ++sl) out->edge_nodes[sl] = bucket[4 * sl + 2];
+    out->edge_nodes[N - 1] = (uint32_t)(N - 1);
+    for (uint64_t e2 = 0; e2 <= C; ++e2) std::sort(out->edge_nodes + out->edge_offsets[e2], out->edge_nodes + out->edge_offsets[e2 + 1]);
+    return KGPU_OK;
+}
+
+extern "C" void kgpu_lattice_free(kgpu_lattice *l) {
+    if (!l) return;
+    free(l->nodes); free(l->edge_offsets); free(l->edge_nodes);
+    *l = kgpu_lattice{};
 }
 
 // Pinned, device-visible host memory for the buffers of kgpu_tokenize_batch: the copies then run as DMA

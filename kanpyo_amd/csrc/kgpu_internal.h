@@ -51,6 +51,7 @@ struct Control {
     unsigned long long n_tokens;      // dense token count (written by the scan kernel)
     unsigned long long work[7];       // kgpu_work, only when BatchArgs::count_work
     unsigned long long phase[10];     // shader-clock cycles per phase of the LDS kernel (count_work only)
+    unsigned long long dump[8];       // kgpu_lattice_dump: arena offsets of the sentence's two slabs, B, C, N, 1 = valid, dp of EOS
 };
 
 struct BatchArgs {
@@ -67,6 +68,7 @@ struct BatchArgs {
     uint32_t count_work;          // accumulate kgpu_work into ctl->work (slow; off in timed runs)
     uint32_t *ovf[4];             // n entries each: work lists of launches 1.. (filled by the launch before)
     uint32_t est_q8;              // expected LDS bytes per input byte (x256): reservation size and length routing
+    uint32_t dump_lattice;        // general kernel: leave the slab offsets of the (single) sentence in ctl->dump
 };
 
 // Launch plan of one batch: the LDS page-pool kernel (kgpu_pool.hip) once or twice -- W independent
@@ -89,6 +91,7 @@ struct LaunchPlan {
 // stays complete without the later ones: their work falls through to the next launch).
 int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now,
                     uint32_t stop_after /* kgpu_ctx_set_ablation; 0 = run everything */, void *stream);
+int launch_general_only(const DictView &d, const BatchArgs &a, void *stream);  // kgpu_lattice_dump: HBM-scratch kernel alone
 int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream);  // host_ctl: device pointer of the pinned result block
 LaunchPlan default_launch_plan(int device);
 

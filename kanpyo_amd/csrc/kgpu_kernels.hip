@@ -299,6 +299,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                         const bool ok = tot < INF;
                         pre[t] = ok ? nmin : NONE;
                         if (na_.z != NONE) bucket[na_.z].x = (uint32_t)(ok ? tot : INF);
+                        else if (a.dump_lattice) a.ctl->dump[6] = (unsigned long long)(uint32_t)(ok ? tot : INF);  // EOS has no bucket entry
                     }
                 }
                 __syncthreads();
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                 }
                 pre[t] = prv;
                 if (na_.z != NONE) bucket[na_.z].x = (uint32_t)dpv;
+                else if (a.dump_lattice) a.ctl->dump[6] = (unsigned long long)(uint32_t)dpv;  // EOS has no bucket entry
             }
             __syncthreads();
         };
@@ -548,6 +550,10 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             }
         }
         if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; }
+        if (a.dump_lattice && lane == 0) {  // kgpu_lattice_dump: the host reads the lattice straight out of the two slabs
+            a.ctl->dump[0] = (unsigned long long)(sa.ptr - a.arena); a.ctl->dump[1] = (unsigned long long)(sn.ptr - a.arena);
+            a.ctl->dump[2] = B; a.ctl->dump[3] = C; a.ctl->dump[4] = N; a.ctl->dump[5] = 1;
+        }
         if (a.count_work) {
             wT = wave_sum(wT);
             accW[0] += 1; accW[1] += B; accW[2] += C; accW[3] += wT; accW[4] += N - 1; accW[5] += bcast32(wE); accW[6] += K;
@@ -651,6 +657,12 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
     uint64_t wg = plan.general_workgroups;
     if (!in_list && a.n < wg) wg = a.n;
     hipLaunchKernelGGL(k_tokenize_general<false>, dim3((unsigned)(wg ? wg : 1)), dim3(64), 0, (hipStream_t)stream, d, a, io, 0u, stop_after);
+    return (int)hipGetLastError();
+}
+
+int launch_general_only(const DictView &d, const BatchArgs &a, void *stream) {
+    WorkIO io{nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(k_tokenize_general<false>, dim3(1), dim3(64), 0, (hipStream_t)stream, d, a, io, 0u, 0u);
     return (int)hipGetLastError();
 }
 

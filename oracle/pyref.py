@@ -86,8 +86,9 @@ class PyDict:
         return res
 
 
-def tokenize(d: PyDict, text: str):
-    """-> list of (id, cls, position, start, end, byte_len)."""
+def lattice(d: PyDict, text: str):
+    """Lattice::build + the forward pass of Lattice::viterbi (src/lattice.rs:101-142) -> (nodes, edges, dp, pre) with
+    nodes[i] = (cls, id, byte_pos, char_pos, morph, surface_bytes, surface_chars)."""
     inp = text.encode("utf-8")
     chars = list(text)
     C = len(chars)
@@ -147,6 +148,12 @@ def tokenize(d: PyDict, text: str):
                 if total < dp[i]:
                     dp[i] = total
                     pre[i] = j
+    return nodes, edges, dp, pre
+
+
+def tokenize(d: PyDict, text: str):
+    """-> list of (id, cls, position, start, end, byte_len)."""
+    nodes, edges, dp, pre = lattice(d, text)
     pos = len(nodes) - 1
     path = []
     while pre[pos] is not None:

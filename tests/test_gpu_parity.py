@@ -394,3 +394,35 @@ def test_concurrent_callers_share_one_dictionary(small):
     [t.join() for t in th]
     for k in range(len(jobs)):
         assert np.array_equal(got[k][1], want[k].offsets) and np.array_equal(got[k][0], want[k].tokens)
+
+
+def test_lattice_dump_and_graphviz(libs, full):
+    """kgpu_lattice_dump reads Lattice{nodes, edges} and the Viterbi state of one sentence back from
+    the device; it must equal the naive Python restatement's lattice node for node (insertion order, morphs in the
+    dictionary's own context ids, dp, pre, edges ascending), and render to the same DOT (reference src/graphviz.rs)."""
+    from kanpyo_amd import Dict, Tokenizer, synth
+    from kanpyo_amd.lattice import dump_lattice, graphviz
+    from oracle import pyref
+    from test_lattice_cpu import lattice_from_pyref
+
+    g = load_golden("fixture_graphviz.json")
+    d = Dict.from_parts(**fixture_dict_parts())
+    pd = pyref.PyDict(d.index_dict, d.connection_dict, d.morph_dict, d.unk_dict, d.char_category, d.invoke_list, d.group_list)
+    tok = Tokenizer(d)
+    conn = lambda r, l: pd.conn[pd.row * l + r]  # noqa: E731
+    known, unk = (lambda i: g["features"]["known"].get(str(i), ["x"])), (lambda i: g["features"]["unknown"].get(str(i), ["y"]))
+    for text in [g["input"], "", "テスト", "テ", "テあ", "あいうえお", "辞書あ辞書"]:
+        got, exp = dump_lattice(tok, text), lattice_from_pyref(pd, text)
+        assert got.edges == exp.edges, text
+        assert got.nodes == exp.nodes, text
+        for full_state in (False, True):
+            assert graphviz(got, conn, known, unk, 48, full_state) == graphviz(exp, conn, known, unk, 48, full_state)
+    assert graphviz(dump_lattice(tok, g["input"]), conn, known, unk, 48, False) == g["dot"]
+    # the IPADIC-shaped dictionary (frequency-ranked context ids on the device, duplicates, unknown groups, non-BMP)
+    sd, tok2, _ = full
+    d2 = sd.dict
+    pd2 = pyref.PyDict(d2.index_dict, d2.connection_dict, d2.morph_dict, d2.unk_dict, d2.char_category, d2.invoke_list, d2.group_list)
+    for text in synth.make_corpus(sd, 6, 77, "cfg2") + synth.make_corpus(sd, 2, 78, "cfg3")[:1] + ["すもももももももものうち", "ア" * 70 + "\U00020000x"]:
+        got, exp = dump_lattice(tok2, text), lattice_from_pyref(pd2, text)
+        assert got.edges == exp.edges and got.nodes == exp.nodes, text
+        assert [n.key() for n in got.viterbi()] == [n.key() for n in exp.viterbi()]
