@@ -52,4 +52,5 @@ def test_graphviz_degenerate_inputs():
     lat = lattice_from_pyref(pd, "テ")  # category 0 has no unk entry: EOS has no predecessor
     assert lat.viterbi() == []
     dot = graphviz(lat, conn, f, f)
-    assert '[label="EOS"' in dot and "style=bold" not in dot
+    # only EOS is reachable from EOS, and the reference labels visible id 0 "BOS" whatever it is (src/graphviz.rs:96-102)
+    assert dot.count("[label=") == 1 and '0 [label="BOS"' in dot and "style=bold" not in dot
