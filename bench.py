@@ -276,7 +276,9 @@ def measure_config(tok, dev, wl, n_chars, passes, queue, streams, label):
             work[k] += v
         c.set_profiling(PROFILE_OFF)
         c.profile(reset=True)
-    run_job(eng, 1)  # warm (routing estimate settled)
+    run_job(eng, max(2, -(-eng.Q // max(wl.nb(0), 1))))  # warm: every context has grown its scratch arena, the routing estimate has settled
+    for c in eng.ctxs:
+        c.profile(reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_job(eng, passes)

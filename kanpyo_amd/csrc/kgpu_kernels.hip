@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             // predecessor) pairs fit the LDS budget.  Per block: one round of coalesced loads, one
             // parallel gather of the connection costs, then the serial chain at LDS latency.
             uint32_t *posT0 = (uint32_t *)lds, *posP0 = posT0 + 64, *posP = posP0 + 64, *posEb = posP + 64;
-            const uint32_t cap = lds_bytes - 1024;
+            const uint32_t cap = lds_bytes - 1040;  // 1024 B of position tables + 16 B of store sinks
             for (uint32_t qa = 0; qa <= C;) {
                 const uint32_t ql = qa + lane;
                 const bool in = ql <= C;
@@ -355,7 +355,8 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                 const uint32_t nt = (uint32_t)__shfl((int)cT, (int)nq - 1, 64), nbk = (uint32_t)__shfl((int)cP, (int)nq - 1, 64);
                 const uint32_t np = (uint32_t)__shfl((int)cE, (int)nq - 1, 64);
                 wE += (lane < nq) ? pairs : 0;  // summed over lanes at the end
-                uint32_t off = 1024;
+                uint32_t off = 1040;
+                uint32_t *sink = (uint32_t *)(lds + 1024);                  // [0] dp, [1] pre, [2] target dp: stores of absent lanes
                 uint32_t *dpL = (uint32_t *)(lds + off);  off += 4 * nbk;   // dp of the bucket entries ending in the block
                 uint32_t *ndL = (uint32_t *)(lds + off);  off += 4 * nbk;   // their node index (tie-break, pre)
                 uint32_t *csL = (uint32_t *)(lds + off);  off += 4 * nt;    // targets: word cost | local bucket slot << 16 (0xFFFF: outside)
@@ -370,7 +371,8 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                     dpL[i] = e.x; ndL[i] = e.z; rtL[i] = (uint16_t)e.y;
                 }
                 wave_fence();
-                // targets + gather (lane = target, 4 gathers in flight)
+                // targets + gather (lane = target, 4 gathers in flight; issuing the node records and sixteen gathers of four
+                // targets at once was measured and is slower: cfg 3 11.6 -> 10.1 M sentences/s)
                 for (uint32_t t = lane; t < nt; t += 64) {
                     const uint4 na_ = nodeA[tA + t];
                     const uint32_t z = na_.z;
@@ -379,60 +381,57 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                     const uint32_t q = nodeB[tA + t].x - qa;
                     const uint32_t Pq = posP[q], p0 = posP0[q], base = posEb[q] + (t - posT0[q]) * Pq;
                     const int16_t *col = d.conn + (size_t)d.conn_rows * (na_.x & 0xFFFFu);
-                    uint32_t j = 0;
-                    for (; j + 4 <= Pq; j += 4) {
-                        const int16_t c0 = col[rtL[p0 + j]], c1 = col[rtL[p0 + j + 1]], c2 = col[rtL[p0 + j + 2]], c3 = col[rtL[p0 + j + 3]];
-                        prL[base + j] = c0; prL[base + j + 1] = c1; prL[base + j + 2] = c2; prL[base + j + 3] = c3;
+                    for (uint32_t j = 0; j < Pq; j += 4) {  // the last group of a row repeats its final entry: ceil(P / 4) dependent rounds
+                        const uint32_t j1 = min(j + 1, Pq - 1), j2 = min(j + 2, Pq - 1), j3 = min(j + 3, Pq - 1);
+                        const int16_t c0 = col[rtL[p0 + j]], c1 = col[rtL[p0 + j1]], c2 = col[rtL[p0 + j2]], c3 = col[rtL[p0 + j3]];
+                        prL[base + j] = c0; prL[base + j1] = c1; prL[base + j2] = c2; prL[base + j3] = c3;
                     }
-                    for (; j < Pq; ++j) prL[base + j] = col[rtL[p0 + j]];
                 }
                 wave_fence();
-                // the chain: position r of the block, pair (ti, j) on lane ti * 2^lg + j when it fits 64 lanes
-                // two packed descriptor words per position (broadcast by v_readlane + scalar bit-field extracts):
-                // d0 = first target | first bucket slot << 16, d1 = pair offset (17 bits) | T (7) | P (5) |
-                // ceil(log2 P) (3; 7 = not the straight-line shape 2^lg * T <= 64, P <= 16)
-                const uint32_t lgv = P > 1 ? 32 - __clz(P - 1) : 0;
-                const bool fastq = lane < nq && P != 0 && T != 0 && lgv <= 4 && (T << lgv) <= 64;
+                // The chain (same step as kgpu_pool.hip's, see there for the measurements behind it): descriptors in lanes,
+                // d0 = first target | first bucket slot << 16, d1 = pair offset (17 bits) | T (7) << 17 | P (6) << 24, bit 31 =
+                // not the straight-line shape.  ONE straight-line body for P <= 16 (eight lanes per target, lane j takes
+                // predecessors j and j + 8, eight targets per pass), a second instantiation for P <= 32; loads unconditional
+                // and unclamped (past the arrays: other LDS of this workgroup or zero), absent candidates deselected by a
+                // total no real one reaches; no exec-masked region: every lane of a group stores the group's result, absent
+                // groups and nodes that end beyond the block store to a sink.
+                const bool fastq = lane < nq && P <= 32 && T - 1u < 127u;
                 const uint32_t d0 = (t0g - tA) | ((p0g - pA) << 16);
-                const uint32_t d1 = (cE - pairs) | (fastq ? (T << 17) | (P << 24) | (lgv << 29) : 7u << 29);
+                const uint32_t d1 = (cE - pairs) | (fastq ? (T << 17) | (P << 24) : 1u << 31);
                 for (uint32_t r = 0; r < nq; ++r) {
                     const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)r);
                     const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)r);
                     const uint32_t t0 = D0 & 0xFFFFu, p0 = D0 >> 16, eb = D1 & 0x1FFFFu;
-                    if ((D1 >> 29) != 7u) {
-                        const uint32_t Tq = (D1 >> 17) & 127u, Pq = (D1 >> 24) & 31u;
-                        auto fast = [&](auto LGc) {
-                            constexpr uint32_t LG = decltype(LGc)::value;
-                            const uint32_t ti = lane >> LG, j = lane & ((1u << LG) - 1);
-                            const bool tv = ti < Tq;
-                            const uint32_t tt = t0 + (tv ? ti : 0);
-                            const uint32_t cs = csL[tt];
-                            int32_t v = 0x7FFFFFFF;
-                            uint32_t nd = 0xFFFFFFFFu;
-                            if (tv && j < Pq) {
-                                v = (int32_t)dpL[p0 + j] + (int32_t)prL[eb + ti * Pq + j];
-                                nd = ndL[p0 + j];
-                            }
-                            const int32_t vmin = gmin_i32(v, LG);   // LG is a constant here: the steps fold
-                            const uint32_t nmin = gmin_u32(v == vmin ? nd : 0xFFFFFFFFu, LG);
-                            if (tv && j == 0) {
-                                const int32_t tot = vmin + (int32_t)(int16_t)cs;
-                                const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
-                                const uint32_t dpn = (uint32_t)(ok ? tot : INF);
-                                preL[tt] = ok ? nmin : NONE;
-                                dpT[tt] = dpn;
-                                const uint32_t sl = cs >> 16;
-                                if (sl != 0xFFFFu) dpL[sl] = dpn;
-                            }
+                    if (!(D1 >> 31)) {
+                        const uint32_t Tq = (D1 >> 17) & 127u, Pq = (D1 >> 24) & 63u;
+                        auto pass = [&](auto LGc, uint32_t tb) {
+                            constexpr uint32_t LG = decltype(LGc)::value, G = 1u << LG;
+                            const uint32_t j = lane & (G - 1u), ti = tb + (lane >> LG);
+                            const bool tv = ti < Tq, j0v = j < Pq, j1v = j + G < Pq;
+                            const uint32_t cs = csL[t0 + ti];
+                            const uint32_t dp0 = dpL[p0 + j], dp1 = dpL[p0 + j + G], nd0 = ndL[p0 + j], nd1 = ndL[p0 + j + G];
+                            const int16_t *mrow = prL + eb + __umul24(ti, Pq) + j;
+                            const int32_t pc0 = mrow[0], pc1 = mrow[G];
+                            __builtin_amdgcn_sched_barrier(0);  // the seven reads stay one round trip
+                            constexpr int32_t ABSENT = 0x7FFEFFFF;  // above every real total (<= INF + 32767), no overflow with a word cost added
+                            const int32_t v0 = (tv && j0v) ? (int32_t)dp0 + pc0 : ABSENT;
+                            const int32_t v1 = (tv && j1v) ? (int32_t)dp1 + pc1 : ABSENT;
+                            const int32_t vmin = gmin_i32(min(v0, v1), LG);   // LG is a constant here: the steps fold
+                            const uint32_t nmin = gmin_u32(min(v0 == vmin ? nd0 : 0xFFFFFFFFu, v1 == vmin ? nd1 : 0xFFFFFFFFu), LG);
+                            const int32_t tot = vmin + (int32_t)(int16_t)cs;
+                            const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
+                            const uint32_t dpn = (uint32_t)(ok ? tot : INF), sl = cs >> 16;
+                            *(tv ? &preL[t0 + ti] : &sink[1]) = ok ? nmin : NONE;
+                            *(tv ? &dpT[t0 + ti] : &sink[2]) = dpn;
+                            *((tv && sl != 0xFFFFu) ? &dpL[sl] : &sink[0]) = dpn;
                         };
-                        switch (D1 >> 29) {
-                            case 0: fast(std::integral_constant<uint32_t, 0>{}); break;
-                            case 1: fast(std::integral_constant<uint32_t, 1>{}); break;
-                            case 2: fast(std::integral_constant<uint32_t, 2>{}); break;
-                            case 3: fast(std::integral_constant<uint32_t, 3>{}); break;
-                            default: fast(std::integral_constant<uint32_t, 4>{}); break;
+                        if (Pq <= 16) {
+                            pass(std::integral_constant<uint32_t, 3>{}, 0u);
+                            if (Tq > 8) for (uint32_t tb = 8; tb < Tq; tb += 8) pass(std::integral_constant<uint32_t, 3>{}, tb);
+                        } else {
+                            for (uint32_t tb = 0; tb < Tq; tb += 4) pass(std::integral_constant<uint32_t, 4>{}, tb);
                         }
-                        wave_fence();
+                        __builtin_amdgcn_wave_barrier();  // no fence: one wavefront's DS instructions execute in issue order
                         continue;
                     }
                     const uint32_t Tq = (uint32_t)__builtin_amdgcn_readlane((int)T, (int)r);
@@ -481,6 +480,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                     }
                     wave_fence();
                 }
+                wave_fence();
                 // dp of the nodes that end beyond the block goes back to their HBM bucket entries
                 for (uint32_t t = lane; t < nt; t += 64) {
                     pre[tA + t] = preL[t];
