@@ -633,7 +633,9 @@ def main():
                                  "sentences_per_s_at_median": n_call / ts[len(ts) // 2]}
         result["pcie_inclusive"]["call_latency"] = lat
         result["pcie_inclusive"]["call_latency_what"] = ("kgpu_tokenize_batch through the ctypes mirror (Tokenizer.tokenize_packed, caller-owned "
-                                                         "result arrays), host buffers in and out, wall time per call")
+                                                         "result arrays), host buffers in and out, wall time per call; n <= 128 takes the single-launch "
+                                                         "path (pinned in/out, the kernel compacts and publishes itself), of which ~40 us are the one "
+                                                         "sentence's own dependent chain on one wavefront")
         if not args.no_extras:
             nbf = len(full_batches)
             utf8_all, offs_all = pack_sentences(corpora[0][: nbf * BATCH])

@@ -125,6 +125,9 @@ struct kgpu_ctx {
     DevBuf arena, stage, tok_count;
     // host-buffer path staging
     DevBuf in_utf8, in_off, out_tok, out_off, out_status;
+    // single-launch small calls: one pinned, device-mapped block (input | offsets | tokens | token offsets | status)
+    uint8_t *sm_host = nullptr, *sm_dev = nullptr;
+    uint32_t sm_seq = 0;
     // last enqueued batch (for the arena-overflow retry and for sync)
     BatchArgs last{};
     bool pending = false;
@@ -455,6 +458,7 @@ extern "C" void kgpu_ctx_destroy(kgpu_ctx *c) {
     c->in_utf8.release(); c->in_off.release(); c->out_tok.release(); c->out_off.release(); c->out_status.release();
     if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    if (c->sm_host) (void)hipHostFree(c->sm_host);
     kgpu_dict *d = c->dict;
     delete c;
     dict_release(d);
@@ -699,6 +703,84 @@ static int host_job_finish(HostJob &j, kgpu_token *tokens, uint64_t token_capaci
     return KGPU_OK;
 }
 
+// ---- small calls: ONE launch, no copies ------------------------------------------------------------------
+// The reference's call shape is one sentence per call (src/bin/kanpyo.rs:106-126); the general path costs such a call
+// five dependent launches, two host-to-device and three device-to-host copies (~120 us).  Here the sentences and the
+// results live in one pinned, device-mapped block: the pool kernel reads its input over PCIe, tokenizes one sentence
+// per wavefront, compacts and publishes by itself (kgpu_pool.hip, `fused_host`), and the host polls a sequence number.
+static constexpr uint64_t SMALL_MAX_N = 128, SMALL_MAX_BYTES = 16 * 1024;
+static constexpr size_t SM_OFF_OFFS = SMALL_MAX_BYTES + 64, SM_OFF_TOK = SM_OFF_OFFS + (SMALL_MAX_N + 1) * 8 + 56,
+                        SM_OFF_TOFF = SM_OFF_TOK + (SMALL_MAX_BYTES + SMALL_MAX_N) * sizeof(kgpu_token),
+                        SM_OFF_STATUS = SM_OFF_TOFF + (SMALL_MAX_N + 1) * 8 + 56, SM_BYTES = SM_OFF_STATUS + SMALL_MAX_N + 64;
+
+// KGPU_OK: done; KGPU_ERR_CAPACITY: done, caller's buffer too small; -1: not served here (a sentence needs the long way)
+static int small_call(kgpu_dict *d, kgpu_ctx *c, const uint8_t *utf8, const uint64_t *offsets, uint64_t n, kgpu_token *tokens,
+                      uint64_t token_capacity, uint64_t *tok_offsets, uint8_t *status, uint64_t *n_tokens) {
+    const uint64_t base = offsets[0], total = offsets[n] - base;
+    int rc;
+    if (!c->sm_host) {
+        if (hipHostMalloc((void **)&c->sm_host, SM_BYTES, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&c->sm_dev, c->sm_host, 0) != hipSuccess) {
+            if (c->sm_host) { (void)hipHostFree(c->sm_host); c->sm_host = nullptr; }
+            return -1;
+        }
+    }
+    if (c->pending && (rc = kgpu_ctx_sync(c, nullptr)) != KGPU_OK && rc != KGPU_ERR_CAPACITY) return rc;
+    if ((rc = c->arena.ensure(ARENA_INITIAL)) || (rc = c->stage.ensure((size_t)(total + n + 1) * sizeof(kgpu_token) + 64)) ||
+        (rc = c->tok_count.ensure((size_t)(n + 1) * 4)) || (rc = c->ovf.ensure((size_t)(n + 1) * 4 * 4)))
+        return rc;
+    std::memcpy(c->sm_host, utf8 + base, (size_t)total);
+    uint64_t *h_off = (uint64_t *)(c->sm_host + SM_OFF_OFFS);
+    for (uint64_t i = 0; i <= n; ++i) h_off[i] = offsets[i] - base;
+    const uint32_t seq = ++c->sm_seq ? c->sm_seq : ++c->sm_seq;  // never 0
+    __atomic_store_n(&c->h_ctl->small_flag, 0u, __ATOMIC_RELEASE);
+    BatchArgs a{};
+    a.utf8 = c->sm_dev; a.offsets = (const uint64_t *)(c->sm_dev + SM_OFF_OFFS); a.n = n; a.ctl = c->d_ctl;
+    a.arena = (uint8_t *)c->arena.p; a.arena_bytes = c->arena.bytes;
+    a.stage = (kgpu_token *)c->stage.p; a.tok_count = (uint32_t *)c->tok_count.p;
+    a.status = c->sm_dev + SM_OFF_STATUS; a.out = (kgpu_token *)(c->sm_dev + SM_OFF_TOK); a.out_cap = total + n;
+    a.tok_offsets = (uint64_t *)(c->sm_dev + SM_OFF_TOFF);
+    a.est_q8 = d->est_q8.load(std::memory_order_relaxed);
+    for (int k = 0; k < 4; ++k) a.ovf[k] = (uint32_t *)c->ovf.p + (size_t)k * (n + 1);
+    a.fused_host = c->h_ctl_dev; a.fused_seq = seq;
+    if (c->ctl_dirty) HIPCHECK(hipMemsetAsync(c->d_ctl, 0, sizeof(Control), c->stream));
+    c->ctl_dirty = true;
+    {
+        hipError_t e = (hipError_t)launch_small_call(d->view, a, c->plan, c->stream);
+        if (e != hipSuccess) { set_error("small-call launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    }
+    // poll the sequence number (the kernel's last store); a stream query now and then catches a failed launch
+    for (uint64_t spin = 0;; ++spin) {
+        if (__atomic_load_n(&c->h_ctl->small_flag, __ATOMIC_ACQUIRE) == seq) break;
+        if ((spin & 0xFFFF) == 0xFFFF) {
+            hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(&c->h_ctl->small_flag, __ATOMIC_ACQUIRE) == seq) break;
+                set_error("small call: the kernel finished without publishing"); return KGPU_ERR_INTERNAL;
+            }
+            if (q != hipErrorNotReady) { set_error("small call: %s", hipGetErrorString(q)); return KGPU_ERR_HIP; }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    c->ctl_dirty = false;  // the publishing wavefront zeroed the device block
+    c->prof.batches++; c->prof.sentences += n;
+    c->prof.deferred[0] += c->h_ctl->ovf_count[0]; c->prof.redone[0] += c->h_ctl->late_count[0];
+    if (c->h_ctl->ovf_count[0] != 0 || c->h_ctl->arena_overflow) return -1;  // a sentence left for the long / HBM-scratch kernels
+    const uint64_t got = c->h_ctl->n_tokens;
+    if (n_tokens) *n_tokens = got;
+    const uint64_t *h_toff = (const uint64_t *)(c->sm_host + SM_OFF_TOFF);
+    if (got > token_capacity) {
+        set_error("token buffer too small: need %llu, capacity %llu", (unsigned long long)got, (unsigned long long)token_capacity);
+        return KGPU_ERR_CAPACITY;
+    }
+    std::memcpy(tokens, c->sm_host + SM_OFF_TOK, (size_t)got * sizeof(kgpu_token));
+    std::memcpy(tok_offsets, h_toff, (size_t)(n + 1) * 8);
+    if (status) std::memcpy(status, c->sm_host + SM_OFF_STATUS, (size_t)n);
+    return KGPU_OK;
+}
+
 extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
                                    kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets,
                                    uint8_t *status, uint64_t *n_tokens) {
@@ -710,6 +792,22 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
         if (offsets[i + 1] < offsets[i]) { set_error("kgpu_tokenize_batch: offsets not monotone at %llu", (unsigned long long)i); return KGPU_ERR_INVALID_ARG; }
     if (offsets[n] - offsets[0] && !utf8) { set_error("kgpu_tokenize_batch: null utf8"); return KGPU_ERR_INVALID_ARG; }
     HIPCHECK(hipSetDevice(d->device));
+
+    if (n >= 1 && n <= SMALL_MAX_N && offsets[n] - offsets[0] <= SMALL_MAX_BYTES && !getenv("KGPU_NO_SMALL_CALLS")) {
+        kgpu_ctx *c = nullptr;
+        {
+            std::lock_guard<std::mutex> g(d->pool_mu);
+            if (!d->pool.empty()) { c = d->pool.back(); d->pool.pop_back(); }
+        }
+        int rc = c ? KGPU_OK : kgpu_ctx_create(d, nullptr, &c);
+        if (rc) return rc;
+        rc = c->plan.n_pools ? small_call(d, c, utf8, offsets, n, tokens, token_capacity, tok_offsets, status, n_tokens) : -1;
+        {
+            std::lock_guard<std::mutex> g(d->pool_mu);
+            d->pool.push_back(c);
+        }
+        if (rc != -1) return rc;  // -1: a sentence needs a kernel this path does not launch: take the general path below
+    }
 
     // A large call goes through in chunks (bounded device staging: 24 B per input byte), three of them in
     // flight on pooled contexts: while chunk k's results travel to the host, chunk k+1's kernels run and

@@ -51,6 +51,10 @@ struct Control {
     unsigned long long n_tokens;      // dense token count (written by the scan kernel)
     unsigned long long work[7];       // kgpu_work, only when BatchArgs::count_work
     unsigned long long phase[10];     // shader-clock cycles per phase of the LDS kernel (count_work only)
+    unsigned int waves_done;          // single-launch small calls: wavefronts through with their sentence ...
+    unsigned int waves_copied;        // ... and through with moving its tokens to the caller's (pinned) buffers
+    unsigned int small_flag;          // the call's sequence number, stored LAST into the host copy: the host polls it
+    unsigned int pad1;
     unsigned long long dump[8];       // kgpu_lattice_dump: arena offsets of the sentence's two slabs, B, C, N, 1 = valid, dp of EOS
 };
 
@@ -69,6 +73,8 @@ struct BatchArgs {
     uint32_t *ovf[4];             // n entries each: work lists of launches 1.. (filled by the launch before)
     uint32_t est_q8;              // expected LDS bytes per input byte (x256): reservation size and length routing
     uint32_t dump_lattice;        // general kernel: leave the slab offsets of the (single) sentence in ctl->dump
+    Control *fused_host;          // non-null: single-launch small call -- the pool kernel also scans, compacts into the (pinned,
+    uint32_t fused_seq;           // device-mapped) output and publishes the control block with this sequence number
 };
 
 // Launch plan of one batch: the LDS page-pool kernel (kgpu_pool.hip) once or twice -- W independent
@@ -91,7 +97,8 @@ struct LaunchPlan {
 // stays complete without the later ones: their work falls through to the next launch).
 int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now,
                     uint32_t stop_after /* kgpu_ctx_set_ablation; 0 = run everything */, void *stream);
-int launch_general_only(const DictView &d, const BatchArgs &a, void *stream);  // kgpu_lattice_dump: HBM-scratch kernel alone
+int launch_general_only(const DictView &d, const BatchArgs &a, void *stream);
+int launch_small_call(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, void *stream);  // pool kernel alone, one sentence per wavefront  // kgpu_lattice_dump: HBM-scratch kernel alone
 int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream);  // host_ctl: device pointer of the pinned result block
 LaunchPlan default_launch_plan(int device);
 

@@ -660,6 +660,13 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
     return (int)hipGetLastError();
 }
 
+int launch_small_call(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, void *stream) {
+    Control *ctl = a.ctl;
+    WorkIO io{nullptr, nullptr, a.ovf[0], &ctl->ovf_count[0], &ctl->late_count[0]};
+    const uint64_t wg = (a.n + plan.pool_waves[0] - 1) / plan.pool_waves[0];  // every wavefront gets at most one sentence
+    return launch_tokenize_pool(d, a, io, plan.pool_bytes[0], plan.pool_waves[0], plan.pool_max_pages[0], (int)(wg ? wg : 1), 0u, stream);
+}
+
 int launch_general_only(const DictView &d, const BatchArgs &a, void *stream) {
     WorkIO io{nullptr, nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(k_tokenize_general<false>, dim3(1), dim3(64), 0, (hipStream_t)stream, d, a, io, 0u, 0u);

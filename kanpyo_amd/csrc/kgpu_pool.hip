@@ -30,6 +30,7 @@
 // and redoes the sentence; a sentence that cannot fit an empty pool, or has more than MAXM
 // dictionary prefixes at one position, goes to the next launch's work list.  The wavefronts of
 // a workgroup never meet at a barrier after the pool is set up.
+#include <cstddef>
 #include <cstdlib>
 #include <type_traits>
 
@@ -645,6 +646,60 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
     if (PROF && lane == 0) {
         for (int k = 0; k < 7; ++k) atomicAdd(&a.ctl->work[k], (unsigned long long)accW[k]);
         for (int k = 0; k < 9; ++k) atomicAdd(&a.ctl->phase[k], (unsigned long long)accP[k]);
+    }
+    // ---- single-launch small call (kgpu_tokenize_batch with a handful of sentences: the reference's own call shape is
+    // ONE sentence per call, src/bin/kanpyo.rs:106-126).  The grid gives every wavefront at most one sentence; input and
+    // output live in pinned, device-mapped host memory; instead of three more dependent launches and four copies the
+    // wavefronts meet at a counter, every one moves its own tokens to their dense place, and the last one publishes the
+    // control block and the sequence number the host is polling.
+    if (a.fused_host) {
+        const uint32_t total_waves = gridDim.x * W;
+        const uint64_t my = (uint64_t)blockIdx.x + (uint64_t)gridDim.x * wave;
+        __threadfence();  // release: status, token count, staged tokens of my sentence
+        if (lane == 0) atomicAdd(&a.ctl->waves_done, 1u);
+        for (uint32_t spin = 0; spin < (1u << 22); ++spin) {  // bounded: every wavefront of this small grid is resident
+            if (bcast32(__hip_atomic_load(&a.ctl->waves_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= total_waves) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __threadfence();  // acquire
+        const bool clean = bcast32(ld_l2(&a.ctl->ovf_count[0])) == 0;  // every sentence was served here (else the host takes the long way)
+        uint32_t before = 0, total = 0;
+        if (clean) {
+            for (uint64_t i0 = 0; i0 < a.n; i0 += 64) {
+                const uint64_t i = i0 + lane;
+                const uint32_t c = i < a.n ? ld_l2(&a.tok_count[i]) : 0u;
+                before += i < my ? c : 0u;
+                total += c;
+            }
+            before = bcast32(wave_sum(before)); total = bcast32(wave_sum(total));
+            if (my < a.n) {
+                const uint32_t cnt = bcast32(ld_l2(&a.tok_count[my]));
+                if ((uint64_t)before + cnt <= a.out_cap) {
+                    const uint32_t *src = (const uint32_t *)(a.stage + (a.offsets[my] - a.offsets[0] + my));
+                    uint32_t *dst = (uint32_t *)(a.out + before);
+                    for (uint32_t w = lane; w < cnt * 6; w += 64) dst[w] = ld_l2(src + w);
+                }
+                if (lane == 0) a.tok_offsets[my] = before;
+            }
+            if (my == 0 && lane == 0) a.tok_offsets[a.n] = total;
+        }
+        __threadfence_system();  // my part of the result is in host memory
+        uint32_t copied = 0;
+        if (lane == 0) copied = atomicAdd(&a.ctl->waves_copied, 1u) + 1u;
+        if (bcast32(copied) == total_waves) {  // last one: publish, leave the device block zeroed for the next batch
+            __threadfence();
+            uint32_t *dc = (uint32_t *)a.ctl, *hc = (uint32_t *)a.fused_host;
+            const uint32_t nt = (uint32_t)(offsetof(Control, n_tokens) / 4), fl = (uint32_t)(offsetof(Control, small_flag) / 4);
+            for (uint32_t k = lane; k < sizeof(Control) / 4; k += 64) {
+                uint32_t v = ld_l2(&dc[k]);
+                if (k == nt) v = total;
+                if (k == nt + 1) v = 0;
+                if (k != fl) __hip_atomic_store(&hc[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                dc[k] = 0;
+            }
+            __threadfence_system();
+            if (lane == 0) __hip_atomic_store(&hc[fl], a.fused_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

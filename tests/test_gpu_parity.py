@@ -426,3 +426,33 @@ def test_lattice_dump_and_graphviz(libs, full):
         got, exp = dump_lattice(tok2, text), lattice_from_pyref(pd2, text)
         assert got.edges == exp.edges and got.nodes == exp.nodes, text
         assert [n.key() for n in got.viterbi()] == [n.key() for n in exp.viterbi()]
+
+
+def test_small_calls_single_launch_path(small, monkeypatch):
+    """kgpu_tokenize_batch with a handful of sentences (the reference's own call shape is ONE sentence per call,
+    src/bin/kanpyo.rs:106-126) takes the single-launch path: pinned input / output, the pool kernel compacts and
+    publishes by itself.  Same records as the oracle for every n up to the path's limit, mixed with what the path must
+    hand over to the general one (a sentence too long for LDS) and what it must flag (invalid UTF-8); the capacity error
+    reports the exact need."""
+    from kanpyo_amd import _lib, synth
+    from kanpyo_amd.tokenizer import TOKEN_DTYPE, pack_sentences
+
+    sd, tok, orc = small
+    corpus = synth.make_corpus(sd, 400, 21, "cfg2")
+    for n in (1, 2, 3, 7, 64, 65, 127, 128, 129):
+        assert_same(tok, orc, corpus[:n])
+    assert_same(tok, orc, [""])
+    assert_same(tok, orc, ["", "すもももももももものうち", ""])
+    assert_same(tok, orc, corpus[:5] + ["ア" * 3000] + corpus[5:9])          # one sentence for the long-sentence kernel: whole call falls back
+    assert_same(tok, orc, [corpus[0]] * 128)
+    utf8, offs = pack_sentences([corpus[0].encode(), b"\xe3\x81", corpus[1].encode()])
+    t, toff, status = tok.tokenize_packed(utf8, offs)
+    assert status.tolist() == [0, _lib.KGPU_SENT_INVALID_UTF8, 0] and toff[2] == toff[1]
+    exp = orc.tokenize_batch(*pack_sentences([corpus[0], corpus[1]]), 1)
+    assert np.array_equal(t, exp.tokens)
+    with pytest.raises(_lib.KgpuError) as ei:  # capacity: exact need reported, nothing written past the buffer
+        tok.tokenize_packed(*pack_sentences(corpus[:3]), out=(np.empty(2, dtype=TOKEN_DTYPE), np.empty(4, dtype=np.uint64), np.empty(3, dtype=np.uint8)))
+    assert ei.value.code == _lib.KGPU_ERR_CAPACITY
+    monkeypatch.setenv("KGPU_NO_SMALL_CALLS", "1")  # and the general path gives the same for the same calls
+    for n in (1, 7, 128):
+        assert_same(tok, orc, corpus[:n])
