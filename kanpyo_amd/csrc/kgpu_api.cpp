@@ -329,6 +329,23 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
         }
     }
 
+    // ---- the device copy of the double array carries the duplicate counts in its leaves ----
+    // A leaf (reached through the terminator byte, trie/da.rs:118-123) stores base = -id.  The walk has to load that node
+    // anyway, and the record count of the surface (index.rs:46-51) is the next thing it needs: with ids below 2^21 the spare
+    // bits hold it (1023 = larger, look it up), and one dependent load per match disappears from the walk.
+    uint32_t leaf_dup = 0;
+    if (morphs.size() < (1u << 21)) {
+        leaf_dup = 1;
+        for (size_t a2 = 0; a2 < da.size(); ++a2) {
+            DaNode &nd = da[a2];
+            if (nd.base < 0 && nd.check > 0 && (size_t)nd.check < da.size() && da[(size_t)nd.check].base == (int32_t)a2) {
+                const uint32_t id = (uint32_t)(-(int64_t)nd.base);
+                const uint32_t dupc = std::min<uint32_t>(morphs[id - 1].dup, 1023u);
+                nd.base = -(int32_t)(id | (dupc << 21));
+            }
+        }
+    }
+
     // ---- upload once to HBM ----
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -371,6 +388,7 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
         return rc;
     }
     d->view.da_len = (uint32_t)da.size();
+    d->view.leaf_dup = leaf_dup;
     d->view.n_morph = (uint32_t)morphs.size();
     d->view.n_unk_morph = (uint32_t)unk_morphs.size();
     d->view.conn_rows = (uint32_t)rows;

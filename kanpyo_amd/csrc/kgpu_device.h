@@ -57,8 +57,15 @@ __device__ __forceinline__ bool slab_ensure(Slab &s, uint64_t need, const BatchA
     return true;
 }
 
+// A leaf's payload: (trie id, duplicate count or NONE = "read Morph8::dup of the first record").
+__device__ __forceinline__ void leaf_decode(const DictView &d, int32_t base, uint32_t &id, uint32_t &dup) {
+    const uint32_t enc = (uint32_t)(-base);
+    if (d.leaf_dup) { id = enc & 0x1FFFFFu; dup = enc >> 21; if (dup == 1023u) dup = NONE; }
+    else { id = enc; dup = NONE; }
+}
+
 // One double-array walk from byte k0 of the sentence (trie/da.rs:155-182).
-// F(id, byte_len_so_far_chars, morph_of_first) is invoked per match in
+// F(id, length in chars, duplicate count or NONE) is invoked per match in
 // ascending byte length.  Returns nothing; `matched` is set by the callback.
 template <class F>
 __device__ __forceinline__ uint32_t da_walk(const DictView &d, const uint8_t *text, uint32_t k, uint32_t B,
@@ -79,7 +86,7 @@ __device__ __forceinline__ uint32_t da_walk(const DictView &d, const uint8_t *te
         int32_t ah = bp;  // + TERMINATOR (da.rs:166)
         if ((uint32_t)ah < d.da_len) {
             DaNode t = d.da[ah];
-            if (t.check == p && t.base < 0) on_match((uint32_t)(-t.base), nch);
+            if (t.check == p && t.base < 0) { uint32_t id, dup; leaf_decode(d, t.base, id, dup); on_match(id, nch, dup); }
         }
     }
     return steps;
@@ -110,7 +117,7 @@ __device__ __forceinline__ uint32_t da_walk_first(const DictView &d, const uint8
         DaNode t{0, 0}, nx{0, 0};
         if (doprobe) t = d.da[bp];  // + TERMINATOR (da.rs:166)
         if (donext) nx = d.da[q];
-        if (doprobe && t.check == p && t.base < 0) on_match((uint32_t)(-t.base), nstart);
+        if (doprobe && t.check == p && t.base < 0) { uint32_t id, dup; leaf_decode(d, t.base, id, dup); on_match(id, nstart, dup); }
         if (!more) break;
         ++steps;
         if (!donext || nx.check != p) break;  // da.rs:162-165

@@ -31,6 +31,9 @@ enum : uint32_t { CAT_INVOKE = 1u, CAT_GROUP = 2u, CAT_HAS_UNK = 4u };
 
 struct DictView {
     const DaNode *da;        uint32_t da_len;
+    uint32_t leaf_dup;       // 1: a leaf's base is -(id | dup << 21), dup = IndexTable.dup[id] (1023: look it up in the morph record):
+                             // the device copy of the double array is re-encoded at create time so that the walk learns a surface's
+                             // record count (index.rs:46-51) from the terminator node it has to load anyway
     const DaNode *first;     // [65536] per BMP code point: {node, base[node]} after walking its UTF-8 bytes from
                              // the root, or {0, byte steps attempted before the walk failed}
     const Morph8 *morph;     uint32_t n_morph;

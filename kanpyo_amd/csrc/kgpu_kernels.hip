@@ -170,11 +170,11 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             carry_end = bcast32(run_end);
             if (active) {
                 uint32_t cnt = 0, m = 0;
-                wT += da_walk_first(d, text, cp16[i], cbyte[i], cbyte[i + 1], B, base_root, [&](uint32_t id, uint32_t nch) {
+                wT += da_walk_first(d, text, cp16[i], cbyte[i], cbyte[i + 1], B, base_root, [&](uint32_t id, uint32_t nch, uint32_t dup) {
                     if (m < GMAXM && nch < 256) { mid[(size_t)i * GMAXM + m] = id; mnch[(size_t)i * GMAXM + m] = (uint8_t)nch; }
                     else m = 0x100;  // does not fit the parking area: the emit phase walks again
                     ++m;
-                    uint32_t nrec = 1u + d.morph[id - 1].dup;  // index.rs:46-51
+                    uint32_t nrec = 1u + (dup != NONE ? dup : (uint32_t)d.morph[id - 1].dup);  // index.rs:46-51
                     cnt += nrec;
                     atomicAdd(&cnt_e[i + nch], nrec);
                 });
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         // ---- phase 3: emit -----------------------------------------------------------
         for (uint32_t i = lane; i < C; i += 64) {
             uint32_t t = nb[i];
-            auto emit_match = [&](uint32_t id, uint32_t nch) {
+            auto emit_match = [&](uint32_t id, uint32_t nch, uint32_t /*dup*/ = 0) {
                 const uint32_t end = i + nch;
                 const Morph8 m0 = d.morph[id - 1];  // first record: carries the duplicate count (index.rs:46-51)
                 const uint32_t nrec = 1u + m0.dup;

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
     const int32_t base_root = d.da[1].base;
     uint64_t *bm = (uint64_t *)pool;
     const uint32_t page = ((pool_bytes - POOL_HDR) / POOL_PAGES) & ~15u;
+    auto pages_for = [&](uint32_t bytes) { return (bytes + page - 1) / page; };  // (a reciprocal multiply instead: measured, no difference)
     if (threadIdx.x == 0) *bm = 0;
     __syncthreads();  // the only workgroup barrier: from here on the wavefronts are independent
     // profiling accumulators of this workgroup (flushed once at exit: per-sentence
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         // pool is routed on without paying for a trie walk that would be thrown away.
         const uint32_t need1 = align_up(B + 4, 4) + 24 * (C + 2) + 2 * align_up(C + 2, 4) + align_up(C * MAXM * 5, 16) + 32;
         const uint32_t est = max(need1, (uint32_t)(((uint64_t)B * a.est_q8) >> 8) + 768);
-        uint32_t npg = (est + page - 1) / page;
+        uint32_t npg = pages_for(est);
         // routing: a sentence expected to need more than max_pages would hold a large part of the pool for a long
         // time (LDS x time grows with the square of the length); it is better served by the long-sentence kernel
         if (npg > max_pages) { work_defer(io, lane, s); continue; }
@@ -290,11 +291,11 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
                 carry_end = bcast32(run_end);
                 if (active) {
                     uint32_t cnt = 0, m = 0;
-                    auto on_match = [&](uint32_t id, uint32_t nch) {
+                    auto on_match = [&](uint32_t id, uint32_t nch, uint32_t dup) {
                         if (m < MAXM && nch < 256) { mid[i * MAXM + m] = id; mnch[i * MAXM + m] = (uint8_t)nch; }
                         else ovf = 1;
                         ++m;
-                        const uint32_t nrec = 1u + d.morph[id - 1].dup;  // index.rs:46-51
+                        const uint32_t nrec = 1u + (dup != NONE ? dup : (uint32_t)d.morph[id - 1].dup);  // index.rs:46-51
                         cnt += nrec;
                         atomicAdd(&boff[i + nch], nrec);
                     };
@@ -366,8 +367,8 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
             pool_free(bm, pg, 0, npg, lane);
             if (lane == 0) atomicAdd(io.late_count, 1u);
             pg = NONE;
-            if ((max(need_emit, off + 2 * maxpairs) + page - 1) / page > max_pages || attempt != 0) { work_defer(io, lane, s); break; }
-            npg = min(max_pages, (max(need_emit, need_full) + page - 1) / page);
+            if (pages_for(max(need_emit, off + 2 * maxpairs)) > max_pages || attempt != 0) { work_defer(io, lane, s); break; }
+            npg = min(max_pages, pages_for(max(need_emit, need_full)));
             pg = pool_wait_alloc(bm, npg, lane);
             if (pg == NONE) { work_defer(io, lane, s); break; }
             continue;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         wave_sync();
         if (lane == 0) pre[0] = NONE16;
         {   // the match buffer is dead now: give back the pages beyond pre + the whole pair table
-            const uint32_t keep = (need_full + page - 1) / page;
+            const uint32_t keep = pages_for(need_full);
             if (keep < npg) { pool_free(bm, pg, keep, npg, lane); npg = keep; }
         }
         const uint32_t mcap = (npg * page - off) / 2;
@@ -528,7 +529,25 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
                             *(uint16_t *)(pool + (tv ? apre + 2 * ti : a_sink_pre)) = (uint16_t)(ok ? nmin : NONE16);
                             *(uint32_t *)(pool + (tv ? a_bk + 8 * (cs >> 16) : a_sink_bk)) = (uint32_t)(ok ? tot : INF);
                         };
-                        if (P <= 16) {
+                        auto pass1 = [&](uint32_t tb) {  // P <= 8 (87 % of the positions): one candidate per lane
+                            const uint32_t j = lane & 7u, ti = tb + (lane >> 3);
+                            const bool tv = ti < T, j0v = j < P;
+                            const uint32_t cs = *(const uint32_t *)(pool + acs + 4 * ti);
+                            const uint2 e0 = *(const uint2 *)(pool + D1 + 8 * j);
+                            const int32_t pc0 = *(const int16_t *)(pool + D2 + 2 * (__umul24(ti, P) + j));
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int32_t v0 = (tv && j0v) ? (int32_t)e0.x + pc0 : 0x7FFEFFFF;  // absent: see below
+                            const int32_t vmin = group_min_i32<3>(v0);
+                            const uint32_t nmin = group_min_u32<3>(v0 == vmin ? e0.y >> 16 : 0xFFFFFFFFu);
+                            const int32_t tot = vmin + (int32_t)(int16_t)cs;
+                            const bool ok = tot < INF;
+                            *(uint16_t *)(pool + (tv ? apre + 2 * ti : a_sink_pre)) = (uint16_t)(ok ? nmin : NONE16);
+                            *(uint32_t *)(pool + (tv ? a_bk + 8 * (cs >> 16) : a_sink_bk)) = (uint32_t)(ok ? tot : INF);
+                        };
+                        if (P <= 8) {
+                            pass1(0u);
+                            if (T > 8) for (uint32_t tb = 8; tb < T; tb += 8) pass1(tb);
+                        } else if (P <= 16) {
                             pass(std::integral_constant<uint32_t, 3>{}, 0u);
                             if (T > 8) for (uint32_t tb = 8; tb < T; tb += 8) pass(std::integral_constant<uint32_t, 3>{}, tb);
                         } else {

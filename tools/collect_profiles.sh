@@ -1,16 +1,26 @@
 #!/bin/bash
-# GPU box: rocprofv3 kernel-trace stats + separate PMC passes of the bench command.
-# usage: bash tools/collect_profiles.sh <outdir>
+# GPU box: everything profiles/ holds for a round -- the bench line, rocprofv3 kernel-trace stats of the same command, the PMC
+# passes (pool kernel: cfg 2; long-sentence kernel: cfg 5 and cfg 3), per-phase counters.
+# usage: bash tools/collect_profiles.sh <outdir> <round tag, e.g. r02>
 set -u
-OUT=$(realpath -m "$1")
+OUT=$(realpath -m "$1"); TAG=$2
 REPO=$(cd "$(dirname "$0")/.." && pwd)
+export GPU_MAX_HW_QUEUES=8
 mkdir -p "$OUT"
-python "$REPO/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
+python "$REPO/bench.py" > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python "$REPO/bench.py" --steps 96 --warmup 8 --no-cpu > "$OUT/trace.json" 2> "$OUT/trace.err"
-cp $(find "$OUT/trace" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv"
-bash "$REPO/tools/pmc_passes.sh" "$OUT/pmc" > "$OUT/pmc.log" 2>&1
-python "$REPO/tools/pmc_summary.py" "$OUT/pmc" --json "$OUT/pmc_summary.json" > "$OUT/pmc_summary.txt"
-python "$REPO/tools/make_traffic_json.py" "$OUT/pmc_summary.json" "$OUT/pmc_traffic.json" > /dev/null
-rm -rf "$OUT/trace" "$OUT/pmc"/pass*/
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python "$REPO/bench.py" --steps 8 --warmup 2 --no-cpu --no-extras > "$OUT/trace.json" 2> "$OUT/trace.err"
+cp "$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)" "$OUT/${TAG}_kernel_stats.csv"
+for cfg in "cfg5 1000" "cfg3 100000"; do
+  set -- $cfg
+  BENCH_Q=8 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$1" -- python "$REPO/tools/bench_cfg.py" $1 $2 > "$OUT/trace_$1.log" 2>&1
+  cp "$(find "$OUT/trace_$1" -name "*kernel_stats.csv" | head -1)" "$OUT/${TAG}_$1_kernel_stats.csv"
+done
+bash "$REPO/tools/pmc_passes.sh" "$OUT/pmc" python "$REPO/bench.py" --steps 2 --warmup 1 --queue 1 --no-cpu --no-extras > "$OUT/pmc.log" 2>&1
+python "$REPO/tools/pmc_summary.py" "$OUT/pmc" --json "$OUT/${TAG}_pmc_summary.json" > "$OUT/${TAG}_pmc_summary.txt"
+python "$REPO/tools/make_traffic_json.py" "$OUT/${TAG}_pmc_summary.json" "$OUT/pmc_traffic.json" "$TAG" > /dev/null
+BENCH_Q=1 bash "$REPO/tools/pmc_passes.sh" "$OUT/pmc_cfg5" python "$REPO/tools/bench_cfg.py" cfg5 1000 > "$OUT/pmc_cfg5.log" 2>&1
+python "$REPO/tools/pmc_summary.py" "$OUT/pmc_cfg5" --json "$OUT/${TAG}_cfg5_pmc_summary.json" > "$OUT/${TAG}_cfg5_pmc_summary.txt"
+bash "$REPO/tools/pmc_phases.sh" "$OUT/phases" 1 2 3 4 5 6 7 0 > "$OUT/${TAG}_phase_counters.txt" 2>&1
+rm -rf "$OUT"/trace "$OUT"/trace_cfg5 "$OUT"/trace_cfg3 "$OUT"/pmc/pass*/ "$OUT"/pmc_cfg5/pass*/ "$OUT"/phases
 echo done

@@ -1,11 +1,13 @@
 #!/usr/bin/env python
 """profiles/pmc_traffic.json from a pmc_summary.json (tools/pmc_summary.py --json): HBM bytes per
 batch of the tokenize kernels, FETCH_SIZE corrected as MI355X_MICROARCH.md's HBM section prescribes.
-usage: python tools/make_traffic_json.py <pmc_summary.json> <out.json>"""
+Also writes pmc_instructions.json next to it (wave-instructions per sentence of the pool kernel: bench.py's instruction roofline).
+usage: python tools/make_traffic_json.py <pmc_summary.json> <out.json> [round tag]"""
 import json
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
 d = json.load(open(src))
 # the plain instantiation only: the <true> one (device-side work counters) runs outside the timed region
 kernels = [k for k in d if "k_tokenize" in k and "<true>" not in k]
@@ -18,8 +20,8 @@ for k in kernels:
     write += d[k]["WRITE_SIZE"]["sum"] * scale
 fetch_kb, write_kb = fetch / batches, write / batches
 out = {
-    "source": f"profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-              "`python bench.py --steps 24 --warmup 2 --queue 1 --no-cpu`, tools/pmc_passes.sh)",
+    "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+              "`python bench.py --steps 2 --warmup 1 --queue 1 --no-cpu --no-extras`, tools/pmc_passes.sh)",
     "per": "one batch of 4096 sentences = the k_tokenize_pool launch(es) + the k_tokenize_general launch: " + ", ".join(kernels),
     "batches": batches,
     "fetch_size_kb": fetch_kb,
@@ -32,3 +34,14 @@ out = {
 }
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
+
+import os
+m = d[main]
+waves = m["SQ_WAVES"]["sum"]  # one wavefront per sentence in this kernel's first pass (4096-sentence batches, 4096 wave slots)
+ins = {
+    "source": f"profiles/{tag}_pmc_summary.json, kernel {main}: SQ_INSTS_* / SQ_WAVES (every wavefront of a full batch tokenizes one sentence)",
+    "valu_per_sentence": m["SQ_INSTS_VALU"]["sum"] / waves, "salu_per_sentence": m["SQ_INSTS_SALU"]["sum"] / waves,
+    "lds_per_sentence": m["SQ_INSTS_LDS"]["sum"] / waves, "vmem_rd_per_sentence": m["SQ_INSTS_VMEM_RD"]["sum"] / waves,
+    "wave_cycles_per_sentence": 4 * m["SQ_WAVE_CYCLES"]["sum"] / waves,
+}
+json.dump(ins, open(os.path.join(os.path.dirname(os.path.abspath(dst)), "pmc_instructions.json"), "w"), indent=1)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Separate rocprofv3 --pmc passes (never combined with tracing) over a short single-stream bench run.
-# usage (GPU box): bash tools/pmc_passes.sh <outdir> [bench args]
+# Separate rocprofv3 --pmc passes (never combined with tracing; only the counter groups that have run clean on this pool --
+# other groups have hung the profiler) over a short run of a command.
+# usage (GPU box): bash tools/pmc_passes.sh <outdir> <command...>      e.g.  ... python bench.py --steps 2 --warmup 1 --queue 1 --no-cpu --no-extras
 set -u
 OUT=$(realpath -m "$1"); shift
-REPO=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -15,6 +15,6 @@ for grp in \
   "WRITE_SIZE" \
   "TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pass$i" -- python "$REPO/bench.py" --steps 24 --warmup 2 --queue 1 --no-cpu "$@" > "$OUT/pass$i.log" 2>&1
+  timeout 240 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pass$i" -- "$@" > "$OUT/pass$i.log" 2>&1
   echo "pass $i rc=$? : $grp"
 done
