@@ -232,10 +232,14 @@ def chunk_steps_for(nb_per_step):
 # ------------------------------------------------------------------ extras (N = 1)
 
 def _extras_child(sd, outdir, cfg3_n):
-    """Forked before any GPU state exists: generates the other single-GPU configs' corpora while the parent
-    runs the headline legs (the generator is a pure-Python loop: ~1 minute per million cfg 3 sentences)."""
+    """Forked before any GPU state exists (a fork is not safe afterwards), but asleep until the parent's timed region is
+    over: then it generates the other single-GPU configs' corpora while the parent runs its remaining legs (the
+    generator is a pure-Python loop: ~1 minute per million cfg 3 sentences)."""
     from kanpyo_amd import synth
     from kanpyo_amd.tokenizer import pack_sentences
+
+    while not os.path.exists(os.path.join(outdir, "go")):
+        time.sleep(0.05)
 
     for kind, n, seed in (("cfg5", 1000, 5), ("cfg3", cfg3_n, 2)):
         sents = synth.make_corpus(sd, n, seed, kind)
@@ -312,6 +316,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="HIP streams the contexts share round-robin (one hardware queue each with "
                     "GPU_MAX_HW_QUEUES=8; a stream that has to share a queue unbalances them)")
     ap.add_argument("--corpora", type=int, default=4, help="N>1: distinct cfg 4 corpora (seeds 100..) generated and cycled; 100 = all of cfg 4")
+    ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="untimed: the same steps for this long before the W warmup steps "
+                    "(the first process on a freshly started box measures ~4 %% low for its first second: clocks / page tables still settling)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="lower bound of CPU-baseline work")
     ap.add_argument("--cfg3-sentences", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true")
@@ -435,6 +441,16 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warmup (also brings up the RCCL channels of the gather)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm_seconds:  # untimed, every rank the same number of rounds
+        if not multi:
+            job(20)
+        else:
+            job(4)
+            flag = torch.tensor([1.0 if time.perf_counter() - t_pre < args.prewarm_seconds else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) == 0.0:
+                break
     if W > 0:
         job(W)
     for c in eng.ctxs:
@@ -459,6 +475,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if extras_dir:
+        open(os.path.join(extras_dir, "go"), "w").close()  # the corpus generator may have its core now
     prof = {"launches": 0, "tokenize_ms": 0.0, "aux_ms": 0.0, "batches": 0, "sentences": 0, "deferred": [0] * 4, "redone": [0] * 4,
             "long_launches": 0, "arena_regrows": 0}
     for c in eng.ctxs:
