@@ -99,7 +99,8 @@ typedef struct kgpu_dict_info {
  * ctx stream (bench.py roofline leg). */
 typedef struct kgpu_profile {
     uint64_t launches;     /* tokenize kernel launches timed                  */
-    double tokenize_ms;    /* sum of the fused lattice+Viterbi kernel durations */
+    double tokenize_ms;    /* sum over the timed batches of the whole tokenize launch chain (dominant kernel, long-sentence and
+                              last-resort kernels, and whatever time those small launches wait for a slot on a busy chip) */
     double aux_ms;         /* sum of scan + compaction kernel durations         */
     /* Routing counters, always on (they cost nothing: read from the batch's control block at
      * kgpu_ctx_sync).  A dictionary or text whose lattices outgrow the LDS-resident kernel shows up
@@ -113,6 +114,8 @@ typedef struct kgpu_profile {
                                  (LDS reservation too small: the sentence was redone)         */
     uint64_t long_launches;   /* batches for which the long-sentence kernel was launched      */
     uint64_t arena_regrows;   /* batches rerun because the HBM scratch arena was too small    */
+    double first_ms;          /* sum over the timed batches of the FIRST launch alone: the dominant kernel
+                                 (k_tokenize_pool), the number rocprofv3's kernel stats report for it        */
 } kgpu_profile;
 
 /* Work counters of one or more batches, counted on the device when

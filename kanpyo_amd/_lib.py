@@ -52,7 +52,7 @@ class DictInfo(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("tokenize_ms", C.c_double), ("aux_ms", C.c_double),
                 ("batches", C.c_uint64), ("sentences", C.c_uint64), ("deferred", C.c_uint64 * 4), ("redone", C.c_uint64 * 4),
-                ("long_launches", C.c_uint64), ("arena_regrows", C.c_uint64)]
+                ("long_launches", C.c_uint64), ("arena_regrows", C.c_uint64), ("first_ms", C.c_double)]
 
 
 class LatticeNode(C.Structure):

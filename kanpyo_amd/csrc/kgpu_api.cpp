@@ -496,20 +496,20 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
     // The Control block is zero here: the previous launch's scan kernel left it so.
     if (c->ctl_dirty) HIPCHECK(hipMemsetAsync(c->d_ctl, 0, sizeof(Control), c->stream));
     c->ctl_dirty = true;  // until this enqueue is through
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    hipEvent_t e0 = nullptr, ef = nullptr, e1 = nullptr, e2 = nullptr;
     int rc;
     const bool timed = c->profiling && (c->launch_seq++ % c->event_every) == 0;
     if (timed) {
-        if ((rc = next_event(c, &e0)) || (rc = next_event(c, &e1)) || (rc = next_event(c, &e2))) return rc;
+        if ((rc = next_event(c, &e0)) || (rc = next_event(c, &ef)) || (rc = next_event(c, &e1)) || (rc = next_event(c, &e2))) return rc;
         HIPCHECK(hipEventRecord(e0, c->stream));
     }
     if (a.n) {
         const int pools_now = c->dict->big_pool_batches.load(std::memory_order_relaxed) > 0 ? c->plan.n_pools : std::min(c->plan.n_pools, 1);
         c->last_pools = pools_now;
         c->last_long = c->plan.long_lds_bytes && (c->plan.n_pools == 0 || c->dict->long_batches.load(std::memory_order_relaxed) > 0);
-        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->last_long, c->stop_after, c->stream);
+        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->last_long, c->stop_after, c->stream, ef);
         if (e != hipSuccess) { set_error("k_tokenize launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
-    }
+    } else if (timed) HIPCHECK(hipEventRecord(ef, c->stream));
     if (timed) HIPCHECK(hipEventRecord(e1, c->stream));
     {
         hipError_t e = (hipError_t)launch_scan_compact(a, c->h_ctl_dev, c->stream);
@@ -598,11 +598,12 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
         if (est != c->last.est_q8) c->dict->est_q8.store(est, std::memory_order_relaxed);
     }
     if (c->profiling) {
-        for (size_t i = 0; i + 3 <= c->ev_used; i += 3) {
-            float t01 = 0, t12 = 0;
-            if (hipEventElapsedTime(&t01, c->ev_pool[i], c->ev_pool[i + 1]) == hipSuccess &&
-                hipEventElapsedTime(&t12, c->ev_pool[i + 1], c->ev_pool[i + 2]) == hipSuccess) {
-                c->prof.launches++; c->prof.tokenize_ms += t01; c->prof.aux_ms += t12;
+        for (size_t i = 0; i + 4 <= c->ev_used; i += 4) {
+            float t0f = 0, t01 = 0, t12 = 0;
+            if (hipEventElapsedTime(&t0f, c->ev_pool[i], c->ev_pool[i + 1]) == hipSuccess &&
+                hipEventElapsedTime(&t01, c->ev_pool[i], c->ev_pool[i + 2]) == hipSuccess &&
+                hipEventElapsedTime(&t12, c->ev_pool[i + 2], c->ev_pool[i + 3]) == hipSuccess) {
+                c->prof.launches++; c->prof.first_ms += t0f; c->prof.tokenize_ms += t01; c->prof.aux_ms += t12;
             }
         }
         c->ev_used = 0;

@@ -99,7 +99,8 @@ struct LaunchPlan {
 // n_pools_now <= plan.n_pools: how many of the pool launches to issue for this batch (the chain
 // stays complete without the later ones: their work falls through to the next launch).
 int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now,
-                    uint32_t stop_after /* kgpu_ctx_set_ablation; 0 = run everything */, void *stream);
+                    uint32_t stop_after /* kgpu_ctx_set_ablation; 0 = run everything */, void *stream,
+                    void *event_after_first /* hipEvent_t recorded behind the first (dominant) launch, or null */);
 int launch_general_only(const DictView &d, const BatchArgs &a, void *stream);
 int launch_small_call(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, void *stream);  // pool kernel alone, one sentence per wavefront  // kgpu_lattice_dump: HBM-scratch kernel alone
 int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream);  // host_ctl: device pointer of the pinned result block

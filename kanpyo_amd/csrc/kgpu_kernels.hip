@@ -624,7 +624,8 @@ int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
 
 // Launch chain: pool kernel(s), then the general (HBM scratch) kernel.  Every launch is a
 // persistent grid over its work list (the first one: the identity over [0, n)).
-int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now, uint32_t stop_after, void *stream) {
+int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now, uint32_t stop_after, void *stream,
+                    void *event_after_first) {
     Control *ctl = a.ctl;
     const uint32_t *in_list = nullptr;
     const unsigned int *in_count = nullptr;
@@ -636,9 +637,11 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
         if (!in_list && want < wg) wg = want;
         int e = launch_tokenize_pool(d, a, io, plan.pool_bytes[k], plan.pool_waves[k], plan.pool_max_pages[k], (int)(wg ? wg : 1), stop_after, stream);
         if (e) return e;
+        if (k == 0 && event_after_first && hipEventRecord((hipEvent_t)event_after_first, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
         in_list = a.ovf[li];
         in_count = &ctl->ovf_count[li];
     }
+    if (event_after_first && (plan.n_pools == 0 || n_pools_now == 0) && hipEventRecord((hipEvent_t)event_after_first, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
     if (long_now && plan.long_lds_bytes) {  // HBM lattice + LDS-blocked sweep; takes its whole list, leaves none
         WorkIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], nullptr};
         uint64_t wg = plan.long_workgroups;

@@ -56,7 +56,7 @@ class DeviceContext:
         return {"launches": int(p.launches), "tokenize_ms": float(p.tokenize_ms), "aux_ms": float(p.aux_ms),
                 "batches": int(p.batches), "sentences": int(p.sentences), "deferred": [int(x) for x in p.deferred],
                 "redone": [int(x) for x in p.redone], "long_launches": int(p.long_launches),
-                "arena_regrows": int(p.arena_regrows)}
+                "arena_regrows": int(p.arena_regrows), "first_ms": float(p.first_ms)}
 
     def set_ablation(self, stop_after_stage: int):
         """Measurement only: following batches stop after the given stage (STAGE_*), zero tokens; 0 = off."""
