@@ -133,6 +133,8 @@ struct kgpu_ctx {
     bool pending = false;
     LaunchPlan plan{};
     DevBuf ovf;
+    DevBuf stat_slots;                             // profiling runs: per-wavefront counters of the pool kernel (BatchArgs::stat_slots)
+    std::vector<unsigned long long> stat_host;
     // profiling
     bool profiling = false;   // KGPU_PROFILE_EVENTS
     bool count_work = false;  // KGPU_PROFILE_WORK
@@ -334,7 +336,7 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
     // anyway, and the record count of the surface (index.rs:46-51) is the next thing it needs: with ids below 2^21 the spare
     // bits hold it (1023 = larger, look it up), and one dependent load per match disappears from the walk.
     uint32_t leaf_dup = 0;
-    if (morphs.size() < (1u << 21)) {
+    if (morphs.size() < (1u << 21) && !getenv("KGPU_PLAIN_LEAVES") /* tests: the layout of a dictionary with 2^21 morphs or more */) {
         leaf_dup = 1;
         for (size_t a2 = 0; a2 < da.size(); ++a2) {
             DaNode &nd = da[a2];
@@ -472,7 +474,7 @@ extern "C" void kgpu_ctx_destroy(kgpu_ctx *c) {
     if (c->pending && c->done_ev) (void)hipEventSynchronize(c->done_ev);
     if (c->done_ev) (void)hipEventDestroy(c->done_ev);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    c->arena.release(); c->ovf.release(); c->stage.release(); c->tok_count.release();
+    c->arena.release(); c->ovf.release(); c->stat_slots.release(); c->stage.release(); c->tok_count.release();
     c->in_utf8.release(); c->in_off.release(); c->out_tok.release(); c->out_off.release(); c->out_status.release();
     if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
@@ -547,6 +549,18 @@ extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const ui
     a.tok_count = (uint32_t *)c->tok_count.p;
     a.status = d_status; a.out = d_tokens; a.out_cap = token_capacity; a.tok_offsets = d_tok_offsets;
     a.count_work = c->count_work ? 1u : 0u;
+#ifdef KGPU_STEP_TIMING
+    const bool want_stats = true;
+#else
+    const bool want_stats = c->count_work;
+#endif
+    if (want_stats) {
+        if (!c->stat_slots.p) {
+            if ((rc = c->stat_slots.ensure((size_t)STAT_SLOTS * STAT_WORDS * 8))) return rc;
+            HIPCHECK(hipMemsetAsync(c->stat_slots.p, 0, (size_t)STAT_SLOTS * STAT_WORDS * 8, c->stream));
+        }
+        a.stat_slots = (unsigned long long *)c->stat_slots.p;
+    }
     a.est_q8 = c->dict->est_q8.load(std::memory_order_relaxed);
     for (int k = 0; k < 4; ++k) a.ovf[k] = (uint32_t *)c->ovf.p + (size_t)k * (n + 1);
     return enqueue(c, a);
@@ -608,18 +622,23 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
         }
         c->ev_used = 0;
     }
-#ifdef KGPU_STEP_TIMING
-    if (!c->last.count_work) {
-        for (int k = 0; k < 10; ++k) c->phase[k] += c->h_ctl->phase[k];
-        const unsigned long long *w = c->h_ctl->work;  // measurement build: per-phase ticks ride in the work counters
-        c->work.sentences += w[0]; c->work.B += w[1]; c->work.C += w[2]; c->work.T += w[3]; c->work.N += w[4]; c->work.E += w[5]; c->work.K += w[6];
-    }
-#endif
-    if (c->last.count_work) {
+    if (c->last.count_work) {  // what the general kernels counted (atomics on the control block)
         const unsigned long long *w = c->h_ctl->work;
         c->work.sentences += w[0]; c->work.B += w[1]; c->work.C += w[2]; c->work.T += w[3];
         c->work.N += w[4]; c->work.E += w[5]; c->work.K += w[6];
         for (int k = 0; k < 10; ++k) c->phase[k] += c->h_ctl->phase[k];
+    }
+    if (c->last.stat_slots) {  // ... and the pool kernel's wavefronts, each in its own slot
+        const size_t words = (size_t)STAT_SLOTS * STAT_WORDS;
+        c->stat_host.resize(words);
+        HIPCHECK(hipMemcpyAsync(c->stat_host.data(), c->last.stat_slots, words * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipMemsetAsync(c->last.stat_slots, 0, words * 8, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        unsigned long long sum[STAT_WORDS] = {0};
+        for (size_t i = 0; i < words; ++i) sum[i % STAT_WORDS] += c->stat_host[i];
+        c->work.sentences += sum[0]; c->work.B += sum[1]; c->work.C += sum[2]; c->work.T += sum[3];
+        c->work.N += sum[4]; c->work.E += sum[5]; c->work.K += sum[6];
+        for (int k = 0; k < 10; ++k) c->phase[k] += sum[16 + k];
     }
     uint64_t need = c->h_ctl->n_tokens;
     if (n_tokens) *n_tokens = need;

@@ -78,7 +78,9 @@ struct BatchArgs {
     uint32_t dump_lattice;        // general kernel: leave the slab offsets of the (single) sentence in ctl->dump
     Control *fused_host;          // non-null: single-launch small call -- the pool kernel also scans, compacts into the (pinned,
     uint32_t fused_seq;           // device-mapped) output and publishes the control block with this sequence number
-};
+    unsigned long long *stat_slots;  // profiling runs: STAT_SLOTS x STAT_WORDS counters, one slot per wavefront of the pool launch
+};                                   // (added to by its owner, summed on the host: hot atomics on a few words would distort the run)
+constexpr uint32_t STAT_SLOTS = 16384, STAT_WORDS = 32;  // words 0..6: Control::work, 16..25: Control::phase
 
 // Launch plan of one batch: the LDS page-pool kernel (kgpu_pool.hip) once or twice -- W independent
 // wavefronts per workgroup share pool_bytes of LDS, each sentence takes what it needs -- then the

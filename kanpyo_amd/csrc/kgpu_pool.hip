@@ -141,8 +141,11 @@ __device__ __forceinline__ uint32_t pool_wait_alloc(uint64_t *bm, uint32_t k, ui
 // PROF: device-side work counters + per-phase shader clocks (KGPU_PROFILE_WORK).  A separate
 // instantiation, because the 16 wave-uniform u64 accumulators + 9 ticks cost ~50 of the 102 SGPRs
 // and push the plain kernel into SGPR spilling (v_readlane / v_writelane traffic on the VALU).
+#ifndef KGPU_POOL_WPE
+#define KGPU_POOL_WPE 4
+#endif
 template <bool PROF>
-__global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a, WorkIO io, uint32_t pool_bytes, uint32_t max_pages,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_WPE))) void k_tokenize_pool(DictView d, BatchArgs a, WorkIO io, uint32_t pool_bytes, uint32_t max_pages,
                                                         uint32_t stop_after /* ablation timing only; 0 = run everything */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t pool[];
     const uint32_t lane = threadIdx.x & 63u, wave = bcast32(threadIdx.x >> 6) /* SGPR: everything per-sentence is wave-uniform */, W = blockDim.x >> 6;
@@ -183,7 +186,10 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         // reservation: what the per-position arrays + match buffer need for sure, or the host-adapted
         // estimate of the whole lattice, whichever is larger.  A sentence expected not to fit an empty
         // pool is routed on without paying for a trie walk that would be thrown away.
-        const uint32_t need1 = align_up(B + 4, 4) + 24 * (C + 2) + 2 * align_up(C + 2, 4) + align_up(C * MAXM * 5, 16) + 32;
+        // a parked match: {trie id, chars | records << 8}; one word id (21 bits) | chars (8) | records (3; 0 = look the count up)
+        // when the ids fit (DictView::leaf_dup: fewer than 2^21 morphs)
+        const uint32_t MS = d.leaf_dup ? 4u : 8u;
+        const uint32_t need1 = align_up(B + 4, 4) + 24 * (C + 2) + 2 * align_up(C + 2, 4) + align_up(C * MAXM * MS, 16) + 32;
         const uint32_t est = max(need1, (uint32_t)(((uint64_t)B * a.est_q8) >> 8) + 768);
         uint32_t npg = pages_for(est);
         // routing: a sentence expected to need more than max_pages would hold a large part of the pool for a long
@@ -225,11 +231,10 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         uint16_t *cp16 = (uint16_t *)(smem + off);  off += 2 * (C + 2);  // BMP code point (0xFFFF: not BMP)
         uint8_t *ccat = smem + off;                 off += align_up(C + 2, 4);
         uint8_t *mcnt = smem + off;                 off += align_up(C + 2, 4);
-        const uint32_t mbytes = align_up(C * MAXM * 5, 16);
+        const uint32_t mbytes = align_up(C * MAXM * MS, 16);
         // off + mbytes <= need1 <= lds_bytes by construction of the reservation
         const uint32_t moff = (lds_bytes - mbytes) & ~15u;
-        uint32_t *mid = (uint32_t *)(smem + moff);           // [C][MAXM] trie ids
-        uint8_t *mnch = smem + moff + 4 * C * MAXM;          // [C][MAXM] match length in chars
+        uint32_t *mbuf = (uint32_t *)(smem + moff);          // [C][MAXM] parked matches
         wave_sync();
         KGPU_TICK(1);
         KGPU_STOP(1)
@@ -292,10 +297,12 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
                 if (active) {
                     uint32_t cnt = 0, m = 0;
                     auto on_match = [&](uint32_t id, uint32_t nch, uint32_t dup) {
-                        if (m < MAXM && nch < 256) { mid[i * MAXM + m] = id; mnch[i * MAXM + m] = (uint8_t)nch; }
-                        else ovf = 1;
-                        ++m;
                         const uint32_t nrec = 1u + (dup != NONE ? dup : (uint32_t)d.morph[id - 1].dup);  // index.rs:46-51
+                        if (m < MAXM && nch < 256) {
+                            if (MS == 4) mbuf[i * MAXM + m] = id | (nch << 21) | ((nrec < 8 ? nrec : 0u) << 29);
+                            else *(uint2 *)(mbuf + 2 * (i * MAXM + m)) = make_uint2(id, nch | (nrec << 8));
+                        } else ovf = 1;
+                        ++m;
                         cnt += nrec;
                         atomicAdd(&boff[i + nch], nrec);
                     };
@@ -378,35 +385,48 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         KGPU_TICK(4);
         KGPU_STOP(4)
         // ---- phase 3: emit nodes from the parked matches --------------------------------
+        // 3a, lane = start position, LDS only: the node list in insertion order (lattice.rs:177-201) -- per node its
+        // morph id, start and (parked in nLeft) end position
         for (uint32_t i = lane; i < C; i += 64) {
             uint32_t t = nb[i];
-            const uint32_t nm = mcnt[i];
+            const uint32_t nm = mcnt[i], span = uspan[i];
+            CatInfo ci{};
+            if (span) ci = d.cinfo[ccat[i]];  // in flight while the matches are written out
             for (uint32_t m = 0; m < nm; ++m) {
-                const uint32_t id = mid[i * MAXM + m];
-                const uint32_t end = i + mnch[i * MAXM + m];
-                const Morph8 m0 = d.morph[id - 1];  // first record: carries the duplicate count (index.rs:46-51)
-                const uint32_t nrec = 1u + m0.dup;
-                for (uint32_t r = 0; r < nrec; ++r) {  // lattice.rs:177-188
-                    const Morph8 mm = r ? d.morph[id - 1 + r] : m0;
-                    const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
-                    nLeft[t] = (uint16_t)mm.left; nCS[t] = (uint32_t)(uint16_t)mm.cost | (slot << 16); nStart[t] = (uint16_t)i;
-                    nSid[t] = (int32_t)(id + r);
-                    bk[slot].y = (uint32_t)(uint16_t)mm.right | (t << 16);
-                    ++t;
+                uint32_t id, end, nrec;
+                if (MS == 4) {
+                    const uint32_t w = mbuf[i * MAXM + m];
+                    id = w & 0x1FFFFFu; end = i + ((w >> 21) & 255u); nrec = w >> 29;
+                    if (nrec == 0) nrec = 1u + d.morph[id - 1].dup;  // eight or more records on one surface
+                } else {
+                    const uint2 w = *(const uint2 *)(mbuf + 2 * (i * MAXM + m));
+                    id = w.x; end = i + (w.y & 255u); nrec = w.y >> 8;
                 }
+                for (uint32_t r = 0; r < nrec; ++r, ++t) { nSid[t] = (int32_t)(id + r); nStart[t] = (uint16_t)i; nLeft[t] = (uint16_t)end; }
             }
-            const uint32_t span = uspan[i];
-            if (span) {  // lattice.rs:87-97,190-201
-                const CatInfo ci = d.cinfo[ccat[i]];
-                const uint32_t end = i + span;
-                for (uint32_t r = 0; r < ci.unk_count; ++r) {
-                    const Morph8 mm = d.unk_morph[ci.unk_first - 1 + (int32_t)r];
-                    const uint32_t slot = boff[end] + atomicAdd(&bfill[end], 1u);
-                    nLeft[t] = (uint16_t)mm.left; nCS[t] = (uint32_t)(uint16_t)mm.cost | (slot << 16); nStart[t] = (uint16_t)i;
-                    nSid[t] = -(ci.unk_first + (int32_t)r);
-                    bk[slot].y = (uint32_t)(uint16_t)mm.right | (t << 16);
-                    ++t;
-                }
+            if (span)   // lattice.rs:87-97,190-201
+                for (uint32_t r = 0; r < ci.unk_count; ++r, ++t) { nSid[t] = -(ci.unk_first + (int32_t)r); nStart[t] = (uint16_t)i; nLeft[t] = (uint16_t)(i + span); }
+        }
+        wave_sync();
+        // 3b, lane = node: its morph record (one gather per 64 nodes instead of one dependent load per record of the
+        // busiest position), its slot in the bucket of the position it ends at.  The order inside a bucket is free:
+        // the sweep breaks ties on the node index it carries.
+        for (uint32_t t0 = 1; t0 < N - 1; t0 += 128) {
+            const uint32_t ta = t0 + lane, tb = ta + 64;
+            const bool va = ta < N - 1, vb = tb < N - 1;
+            const int32_t sa = va ? nSid[ta] : 1, sb = vb ? nSid[tb] : 1;
+            const uint32_t ea = va ? nLeft[ta] : 0u, eb = vb ? nLeft[tb] : 0u;
+            const Morph8 ma = *(sa > 0 ? d.morph + (sa - 1) : d.unk_morph + (-sa - 1));
+            const Morph8 mb = *(sb > 0 ? d.morph + (sb - 1) : d.unk_morph + (-sb - 1));
+            if (va) {
+                const uint32_t slot = boff[ea] + atomicAdd(&bfill[ea], 1u);
+                nLeft[ta] = (uint16_t)ma.left; nCS[ta] = (uint32_t)(uint16_t)ma.cost | (slot << 16);
+                bk[slot].y = (uint32_t)(uint16_t)ma.right | (ta << 16);
+            }
+            if (vb) {
+                const uint32_t slot = boff[eb] + atomicAdd(&bfill[eb], 1u);
+                nLeft[tb] = (uint16_t)mb.left; nCS[tb] = (uint32_t)(uint16_t)mb.cost | (slot << 16);
+                bk[slot].y = (uint32_t)(uint16_t)mb.right | (tb << 16);
             }
         }
         if (lane == 0) {
@@ -655,16 +675,32 @@ __global__ __launch_bounds__(1024) void k_tokenize_pool(DictView d, BatchArgs a,
         }  // attempt
         if (pg != NONE) pool_free(bm, pg, 0, npg, lane);
     }
+    {   // flush the profiling accumulators: the wavefront's own slot (plain adds, summed on the host)
 #ifdef KGPU_STEP_TIMING
-    if (!PROF && lane == 0) {
+        constexpr bool flush = true;
         const uint64_t tm[8] = {tmS, tmSteps, tmSlow, tmSlowSteps, tmSent, tmPool, tmN, tmDesc};
-        for (int k = 0; k < 8; ++k) atomicAdd(&a.ctl->phase[k], (unsigned long long)tm[k]);
-        for (int k = 0; k < 7; ++k) atomicAdd(&a.ctl->work[k], (unsigned long long)tmPh[k]);
-    }
+#else
+        constexpr bool flush = PROF;
 #endif
-    if (PROF && lane == 0) {
-        for (int k = 0; k < 7; ++k) atomicAdd(&a.ctl->work[k], (unsigned long long)accW[k]);
-        for (int k = 0; k < 9; ++k) atomicAdd(&a.ctl->phase[k], (unsigned long long)accP[k]);
+        if (flush) {
+            uint64_t v = 0;
+#ifdef KGPU_STEP_TIMING
+            if (!PROF) {
+                for (int k = 0; k < 7; ++k) if (lane == (uint32_t)k) v = tmPh[k];
+                for (int k = 0; k < 8; ++k) if (lane == 16u + k) v = tm[k];
+            }
+#endif
+            if (PROF) {
+                for (int k = 0; k < 7; ++k) if (lane == (uint32_t)k) v = accW[k];
+                for (int k = 0; k < 9; ++k) if (lane == 16u + k) v = accP[k];
+            }
+            if (a.stat_slots) {
+                if (lane < STAT_WORDS) a.stat_slots[(((uint64_t)blockIdx.x * W + wave) & (STAT_SLOTS - 1)) * STAT_WORDS + lane] += v;
+            } else {
+                if (lane < 7) atomicAdd(&a.ctl->work[lane], (unsigned long long)v);
+                if (lane >= 16 && lane < 26) atomicAdd(&a.ctl->phase[lane - 16], (unsigned long long)v);
+            }
+        }
     }
     // ---- single-launch small call (kgpu_tokenize_batch with a handful of sentences: the reference's own call shape is
     // ONE sentence per call, src/bin/kanpyo.rs:106-126).  The grid gives every wavefront at most one sentence; input and

@@ -456,3 +456,18 @@ def test_small_calls_single_launch_path(small, monkeypatch):
     monkeypatch.setenv("KGPU_NO_SMALL_CALLS", "1")  # and the general path gives the same for the same calls
     for n in (1, 7, 128):
         assert_same(tok, orc, corpus[:n])
+
+
+def test_plain_leaves_layout(small, monkeypatch):
+    """A dictionary with 2^21 morphs or more keeps plain leaves (base = -id) and the pool kernel parks its matches in
+    two words instead of one; KGPU_PLAIN_LEAVES selects that layout for a small dictionary.  Same records either way
+    (index.rs:46-51: the duplicate count then comes from the first morph record)."""
+    from kanpyo_amd import Tokenizer, synth
+
+    sd, _, orc = small
+    monkeypatch.setenv("KGPU_PLAIN_LEAVES", "1")
+    tok = Tokenizer(sd.dict)
+    monkeypatch.delenv("KGPU_PLAIN_LEAVES")
+    assert_same(tok, orc, synth.make_corpus(sd, 3000, 31, "cfg2"))
+    assert_same(tok, orc, synth.make_corpus(sd, 300, 32, "cfg3"))
+    assert_same(tok, orc, synth.make_corpus(sd, 5, 33, "cfg2"))  # small-call path
