@@ -94,6 +94,13 @@ __device__ __forceinline__ uint64_t group_min(uint64_t k, uint32_t lg) {  // lg 
 
 __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }
 
+// LDS access by absolute 32-bit LDS address (the sweep keeps ready-made addresses in its descriptors; going through
+// `pool + offset` makes the compiler add the array's link-time base -- zero -- to every address, on the VALU)
+#define KGPU_LDS(T) __attribute__((address_space(3))) T
+template <class T> __device__ __forceinline__ T lds_ld(uint32_t addr) { return *(const KGPU_LDS(T) *)(uintptr_t)addr; }
+template <class T> __device__ __forceinline__ void lds_st(uint32_t addr, T v) { *(KGPU_LDS(T) *)(uintptr_t)addr = v; }
+__device__ __forceinline__ uint2 lds_ld2(uint32_t addr) { const uint64_t v = lds_ld<uint64_t>(addr); return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); }
+
 // Wavefront-level ordering point.  LDS executes one wavefront's instructions in issue order, so
 // data written by one lane is visible to the others at the next instruction; this only stops the
 // compiler from moving LDS accesses across it (no s_barrier: the workgroup's wavefronts are
@@ -501,8 +508,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             //  * two DPP group minima: the total, then the node index among the ties (strict '<' over ascending insertion
             //    order, lattice.rs:125,136).
             KGPU_TM(const uint64_t tm_s0 = __builtin_amdgcn_s_memtime();)
-            const uint32_t a_ncs = (uint32_t)((uint8_t *)nCS - pool), a_bk = (uint32_t)((uint8_t *)bk - pool);
-            const uint32_t a_mp = (uint32_t)((uint8_t *)mpair - pool), a_pre = (uint32_t)((uint8_t *)pre - pool);
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(KGPU_LDS(uint8_t) *)pool;  // absolute LDS addresses, wave-uniform: SGPRs
+            const uint32_t a_ncs = bcast32(lds0 + (uint32_t)((uint8_t *)nCS - pool)), a_bk = bcast32(lds0 + (uint32_t)((uint8_t *)bk - pool));
+            const uint32_t a_mp = bcast32(lds0 + (uint32_t)((uint8_t *)mpair - pool)), a_pre = bcast32(lds0 + (uint32_t)((uint8_t *)pre - pool));
             const uint32_t a_sink_bk = a_bk + 8 * Nb, a_sink_pre = a_pre + 2 * N;
             for (uint32_t qc = qa; qc < qb; qc += 64) {
                 const uint32_t ql = qc + lane;
@@ -533,10 +541,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                             const uint32_t j = lane & (G - 1u), tl = lane >> LG;
                             const uint32_t ti = tb + tl;
                             const bool tv = ti < T, j0v = j < P, j1v = j + G < P;
-                            const uint32_t cs = *(const uint32_t *)(pool + acs + 4 * ti);
-                            const uint2 e0 = *(const uint2 *)(pool + D1 + 8 * j), e1 = *(const uint2 *)(pool + D1 + 8 * j + 8 * G);
+                            const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
+                            const uint2 e0 = lds_ld2(D1 + 8 * j), e1 = lds_ld2(D1 + 8 * j + 8 * G);
                             const uint32_t am = D2 + 2 * (__umul24(ti, P) + j);
-                            const int32_t pc0 = *(const int16_t *)(pool + am), pc1 = *(const int16_t *)(pool + am + 2 * G);
+                            const int32_t pc0 = lds_ld<int16_t>(am), pc1 = lds_ld<int16_t>(am + 2 * G);
                             __builtin_amdgcn_sched_barrier(0);  // the five reads stay one round trip
                             constexpr int32_t ABSENT = 0x7FFEFFFF;
                             const int32_t v0 = (tv && j0v) ? (int32_t)e0.x + pc0 : ABSENT;
@@ -546,23 +554,23 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                             const uint32_t nmin = group_min_u32<LG>(min(n0, n1));
                             const int32_t tot = vmin + (int32_t)(int16_t)cs;
                             const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
-                            *(uint16_t *)(pool + (tv ? apre + 2 * ti : a_sink_pre)) = (uint16_t)(ok ? nmin : NONE16);
-                            *(uint32_t *)(pool + (tv ? a_bk + 8 * (cs >> 16) : a_sink_bk)) = (uint32_t)(ok ? tot : INF);
+                            lds_st<uint16_t>(tv ? apre + 2 * ti : a_sink_pre, (uint16_t)(ok ? nmin : NONE16));
+                            lds_st<uint32_t>(tv ? a_bk + 8 * (cs >> 16) : a_sink_bk, (uint32_t)(ok ? tot : INF));
                         };
                         auto pass1 = [&](uint32_t tb) {  // P <= 8 (87 % of the positions): one candidate per lane
                             const uint32_t j = lane & 7u, ti = tb + (lane >> 3);
                             const bool tv = ti < T, j0v = j < P;
-                            const uint32_t cs = *(const uint32_t *)(pool + acs + 4 * ti);
-                            const uint2 e0 = *(const uint2 *)(pool + D1 + 8 * j);
-                            const int32_t pc0 = *(const int16_t *)(pool + D2 + 2 * (__umul24(ti, P) + j));
+                            const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
+                            const uint2 e0 = lds_ld2(D1 + 8 * j);
+                            const int32_t pc0 = lds_ld<int16_t>(D2 + 2 * (__umul24(ti, P) + j));
                             __builtin_amdgcn_sched_barrier(0);
                             const int32_t v0 = (tv && j0v) ? (int32_t)e0.x + pc0 : 0x7FFEFFFF;  // absent: see below
                             const int32_t vmin = group_min_i32<3>(v0);
                             const uint32_t nmin = group_min_u32<3>(v0 == vmin ? e0.y >> 16 : 0xFFFFFFFFu);
                             const int32_t tot = vmin + (int32_t)(int16_t)cs;
                             const bool ok = tot < INF;
-                            *(uint16_t *)(pool + (tv ? apre + 2 * ti : a_sink_pre)) = (uint16_t)(ok ? nmin : NONE16);
-                            *(uint32_t *)(pool + (tv ? a_bk + 8 * (cs >> 16) : a_sink_bk)) = (uint32_t)(ok ? tot : INF);
+                            lds_st<uint16_t>(tv ? apre + 2 * ti : a_sink_pre, (uint16_t)(ok ? nmin : NONE16));
+                            lds_st<uint32_t>(tv ? a_bk + 8 * (cs >> 16) : a_sink_bk, (uint32_t)(ok ? tot : INF));
                         };
                         if (P <= 8) {
                             pass1(0u);
