@@ -511,7 +511,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             const uint32_t lds0 = (uint32_t)(uintptr_t)(KGPU_LDS(uint8_t) *)pool;  // absolute LDS addresses, wave-uniform: SGPRs
             const uint32_t a_ncs = bcast32(lds0 + (uint32_t)((uint8_t *)nCS - pool)), a_bk = bcast32(lds0 + (uint32_t)((uint8_t *)bk - pool));
             const uint32_t a_mp = bcast32(lds0 + (uint32_t)((uint8_t *)mpair - pool)), a_pre = bcast32(lds0 + (uint32_t)((uint8_t *)pre - pool));
-            const uint32_t a_sink_bk = a_bk + 8 * Nb, a_sink_pre = a_pre + 2 * N;
             for (uint32_t qc = qa; qc < qb; qc += 64) {
                 const uint32_t ql = qc + lane;
                 // three descriptor words per position: d0 = address of nCS[t0] (18 bits) | T (7) << 18 | P (6) << 25 | slow << 31,
@@ -536,41 +535,42 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                     if (!(D0 >> 31)) {
                         const uint32_t acs = D0 & 0x3FFFFu, T = (D0 >> 18) & 127u, P = D0 >> 25;
                         const uint32_t apre = a_pre + ((acs - a_ncs) >> 1);  // pre[t0]
+                        // (target groups past T redo target T - 1: same loads, same result, same stores -- no sink, no select)
                         auto pass = [&](auto LGc, uint32_t tb) {
                             constexpr uint32_t LG = decltype(LGc)::value, G = 1u << LG;
-                            const uint32_t j = lane & (G - 1u), tl = lane >> LG;
-                            const uint32_t ti = tb + tl;
-                            const bool tv = ti < T, j0v = j < P, j1v = j + G < P;
+                            const uint32_t j = lane & (G - 1u), ti = min(tb + (lane >> LG), T - 1u);
+                            const bool j0v = j < P, j1v = j + G < P;
                             const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
                             const uint2 e0 = lds_ld2(D1 + 8 * j), e1 = lds_ld2(D1 + 8 * j + 8 * G);
                             const uint32_t am = D2 + 2 * (__umul24(ti, P) + j);
                             const int32_t pc0 = lds_ld<int16_t>(am), pc1 = lds_ld<int16_t>(am + 2 * G);
                             __builtin_amdgcn_sched_barrier(0);  // the five reads stay one round trip
                             constexpr int32_t ABSENT = 0x7FFEFFFF;
-                            const int32_t v0 = (tv && j0v) ? (int32_t)e0.x + pc0 : ABSENT;
-                            const int32_t v1 = (tv && j1v) ? (int32_t)e1.x + pc1 : ABSENT;
+                            const int32_t v0 = j0v ? (int32_t)e0.x + pc0 : ABSENT;
+                            const int32_t v1 = j1v ? (int32_t)e1.x + pc1 : ABSENT;
                             const int32_t vmin = group_min_i32<LG>(min(v0, v1));
-                            const uint32_t n0 = v0 == vmin ? e0.y >> 16 : 0xFFFFFFFFu, n1 = v1 == vmin ? e1.y >> 16 : 0xFFFFFFFFu;
+                            // ties: the smallest node index wins; it sits in the upper half of the word (the right id below it is along for the ride)
+                            const uint32_t n0 = v0 == vmin ? e0.y : 0xFFFFFFFFu, n1 = v1 == vmin ? e1.y : 0xFFFFFFFFu;
                             const uint32_t nmin = group_min_u32<LG>(min(n0, n1));
                             const int32_t tot = vmin + (int32_t)(int16_t)cs;
                             const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
-                            lds_st<uint16_t>(tv ? apre + 2 * ti : a_sink_pre, (uint16_t)(ok ? nmin : NONE16));
-                            lds_st<uint32_t>(tv ? a_bk + 8 * (cs >> 16) : a_sink_bk, (uint32_t)(ok ? tot : INF));
+                            lds_st<uint16_t>(apre + 2 * ti, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
+                            lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
                         };
                         auto pass1 = [&](uint32_t tb) {  // P <= 8 (87 % of the positions): one candidate per lane
-                            const uint32_t j = lane & 7u, ti = tb + (lane >> 3);
-                            const bool tv = ti < T, j0v = j < P;
+                            const uint32_t j = lane & 7u, ti = min(tb + (lane >> 3), T - 1u);
+                            const bool j0v = j < P;
                             const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
                             const uint2 e0 = lds_ld2(D1 + 8 * j);
                             const int32_t pc0 = lds_ld<int16_t>(D2 + 2 * (__umul24(ti, P) + j));
                             __builtin_amdgcn_sched_barrier(0);
-                            const int32_t v0 = (tv && j0v) ? (int32_t)e0.x + pc0 : 0x7FFEFFFF;  // absent: see below
+                            const int32_t v0 = j0v ? (int32_t)e0.x + pc0 : 0x7FFEFFFF;  // absent: see below
                             const int32_t vmin = group_min_i32<3>(v0);
-                            const uint32_t nmin = group_min_u32<3>(v0 == vmin ? e0.y >> 16 : 0xFFFFFFFFu);
+                            const uint32_t nmin = group_min_u32<3>(v0 == vmin ? e0.y : 0xFFFFFFFFu);
                             const int32_t tot = vmin + (int32_t)(int16_t)cs;
                             const bool ok = tot < INF;
-                            lds_st<uint16_t>(tv ? apre + 2 * ti : a_sink_pre, (uint16_t)(ok ? nmin : NONE16));
-                            lds_st<uint32_t>(tv ? a_bk + 8 * (cs >> 16) : a_sink_bk, (uint32_t)(ok ? tot : INF));
+                            lds_st<uint16_t>(apre + 2 * ti, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
+                            lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
                         };
                         if (P <= 8) {
                             pass1(0u);
