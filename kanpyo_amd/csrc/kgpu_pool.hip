@@ -151,10 +151,28 @@ __device__ __forceinline__ uint32_t pool_wait_alloc(uint64_t *bm, uint32_t k, ui
 #ifndef KGPU_POOL_WPE
 #define KGPU_POOL_WPE 4
 #endif
+// The arguments stay in the kernarg segment and every phase reads the fields it needs from there (scalar loads,
+// KGPU_ARGS() at the phase boundaries): as ordinary by-value parameters the ~85 dwords are loaded at entry, live to
+// the end, and -- 102 SGPRs per wavefront -- spilled to VGPR lanes and read back with v_readlane all over the kernel,
+// on the VALU, once per sentence.
+struct PoolArgs {
+    DictView d; BatchArgs a; WorkIO io;
+    uint32_t pool_bytes, max_pages, stop_after /* ablation timing only; 0 = run everything */;
+};
 template <bool PROF>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_WPE))) void k_tokenize_pool(DictView d, BatchArgs a, WorkIO io, uint32_t pool_bytes, uint32_t max_pages,
-                                                        uint32_t stop_after /* ablation timing only; 0 = run everything */) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_WPE))) void k_tokenize_pool(PoolArgs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t pool[];
+    typedef const __attribute__((address_space(4))) PoolArgs *KArgs;
+    const KArgs kargs = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    DictView d; BatchArgs a; WorkIO io;
+    uint32_t stop_after;
+    // (the empty asm makes the pointer opaque: what was read before it is dead, what is not used before the next one is never loaded)
+#define KGPU_ARGS() do { KArgs kq_ = kargs; asm volatile("" : "+s"(kq_)); \
+        d.da = kq_->d.da; d.da_len = kq_->d.da_len; d.leaf_dup = kq_->d.leaf_dup; d.first = kq_->d.first; d.morph = kq_->d.morph; d.n_morph = kq_->d.n_morph; d.unk_morph = kq_->d.unk_morph; d.n_unk_morph = kq_->d.n_unk_morph; d.conn = kq_->d.conn; d.conn_rows = kq_->d.conn_rows; d.bos_right = kq_->d.bos_right; d.eos_left = kq_->d.eos_left; d.cat = kq_->d.cat; d.cat_len = kq_->d.cat_len; d.cinfo = kq_->d.cinfo; \
+        a.utf8 = kq_->a.utf8; a.offsets = kq_->a.offsets; a.n = kq_->a.n; a.ctl = kq_->a.ctl; a.arena = kq_->a.arena; a.arena_bytes = kq_->a.arena_bytes; a.stage = kq_->a.stage; a.tok_count = kq_->a.tok_count; a.status = kq_->a.status; a.out = kq_->a.out; a.out_cap = kq_->a.out_cap; a.tok_offsets = kq_->a.tok_offsets; a.count_work = kq_->a.count_work; a.ovf[0] = kq_->a.ovf[0]; a.ovf[1] = kq_->a.ovf[1]; a.ovf[2] = kq_->a.ovf[2]; a.ovf[3] = kq_->a.ovf[3]; a.est_q8 = kq_->a.est_q8; a.dump_lattice = kq_->a.dump_lattice; a.fused_host = kq_->a.fused_host; a.fused_seq = kq_->a.fused_seq; a.stat_slots = kq_->a.stat_slots; \
+        io.in_list = kq_->io.in_list; io.in_count = kq_->io.in_count; io.out_list = kq_->io.out_list; io.out_count = kq_->io.out_count; io.late_count = kq_->io.late_count; stop_after = kq_->stop_after; } while (0)
+    KGPU_ARGS();
+    const uint32_t pool_bytes = kargs->pool_bytes, max_pages = kargs->max_pages;
     const uint32_t lane = threadIdx.x & 63u, wave = bcast32(threadIdx.x >> 6) /* SGPR: everything per-sentence is wave-uniform */, W = blockDim.x >> 6;
     const int32_t base_root = d.da[1].base;
     uint64_t *bm = (uint64_t *)pool;
@@ -174,6 +192,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
 #endif
 
     for (uint32_t iter = 0;; ++iter) {
+        KGPU_ARGS();
         uint64_t s = 0;
         // sentence i of the work list -> workgroup i mod G, wavefront (i / G) mod W
         if (!work_next_at(io, a, (uint64_t)blockIdx.x + (uint64_t)gridDim.x * (wave + (uint64_t)W * iter), s)) break;
@@ -218,6 +237,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
 #endif
 #define KGPU_TICK(k) do { if (prof) tick[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #define KGPU_STOP(k) if (stop_after == (k)) { if (lane == 0) { a.status[s] = KGPU_SENT_TRUNCATED; a.tok_count[s] = 0; } break; }
+        KGPU_ARGS();
         KGPU_TICK(0);
         // ---- phase 0a: stage the sentence in LDS, count chars -----------------
         uint8_t *text = smem;
@@ -245,6 +265,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         wave_sync();
         KGPU_TICK(1);
         KGPU_STOP(1)
+        KGPU_ARGS();
 
         // ---- phase 0b: decode + validate + category --------------------------------
         uint32_t cb = 0, bad = 0, lensum = 0;
@@ -287,6 +308,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
 
         KGPU_TICK(2);
         KGPU_STOP(2)
+        KGPU_ARGS();
         // ---- phase 1: one trie walk per start position; count + park matches ------
         uint32_t wT = 0, ovf = 0;
         {
@@ -341,6 +363,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
 
         KGPU_TICK(3);
         KGPU_STOP(3)
+        KGPU_ARGS();
         // ---- phase 2: prefix sums: node numbering, bucket offsets, pair offsets ------
         uint32_t ncarry = 1, bcarry = 0, ecarry = 0, maxpairs = 0;
         for (uint32_t i0 = 0; i0 < C + 2; i0 += 64) {
@@ -391,6 +414,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
 
         KGPU_TICK(4);
         KGPU_STOP(4)
+        KGPU_ARGS();
         // ---- phase 3: emit nodes from the parked matches --------------------------------
         // 3a, lane = start position, LDS only: the node list in insertion order (lattice.rs:177-201) -- per node its
         // morph id, start and (parked in nLeft) end position
@@ -450,10 +474,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         const uint32_t mcap = (npg * page - off) / 2;
         KGPU_TICK(5);
         KGPU_STOP(5)
+        KGPU_ARGS();
         uint64_t cyc_gather = 0;
         // ---- phases 3b + 4, per block of positions whose pairs fit the pair table ----
         uint32_t qa = 0;
         while (qa <= C) {
+            KGPU_ARGS();
             uint32_t qb;
             if (E - ebase[qa] <= mcap) qb = C + 1;
             else {  // largest qb with ebase[qb] - ebase[qa] <= mcap (ebase is non-decreasing)
@@ -639,6 +665,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         KGPU_TICK(6);
         KGPU_STOP(6)
         KGPU_STOP(7)
+        KGPU_ARGS();
         // ---- phase 5: backtrace (lattice.rs:144-153) + Node -> Token (tokenizer.rs:22-43)
         uint32_t K = 0;
         if (lane == 0) {
@@ -683,6 +710,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         }  // attempt
         if (pg != NONE) pool_free(bm, pg, 0, npg, lane);
     }
+    KGPU_ARGS();
     {   // flush the profiling accumulators: the wavefront's own slot (plain adds, summed on the host)
 #ifdef KGPU_STEP_TIMING
         constexpr bool flush = true;
@@ -787,9 +815,9 @@ int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const WorkIO &io
             hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
             if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL(k_tokenize_pool<true>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, d, a, io, pool_bytes, max_pages, stop_after);
+        hipLaunchKernelGGL(k_tokenize_pool<true>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, PoolArgs{d, a, io, pool_bytes, max_pages, stop_after});
     } else {
-        hipLaunchKernelGGL(k_tokenize_pool<false>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, d, a, io, pool_bytes, max_pages, stop_after);
+        hipLaunchKernelGGL(k_tokenize_pool<false>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, PoolArgs{d, a, io, pool_bytes, max_pages, stop_after});
     }
     return (int)hipGetLastError();
 }
