@@ -18,18 +18,24 @@ __device__ __forceinline__ uint64_t bcast64(uint64_t v) {
     uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= (uint32_t)d) v += t;
-    }
+// Inclusive prefix sum over the 64 lanes, on the DPP network: four shifted adds inside each row of 16 lanes, then the row
+// totals are passed on with row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3) -- six VALU ops and no LDS
+// crossbar round trips (the ds_bpermute form is six dependent ~100-cycle trips).  Exec must be full.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {  // lanes whose source is out of range (or whose row is masked) add 0
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t /*lane*/) {
+    v = dpp_add<0x111, 0xF>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);  // row_shr:8
+    v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1, 3
+    v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2, 3
     return v;
 }
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {  // every lane gets the total
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0), 63);
 }
 __device__ __forceinline__ uint32_t ld_l2(const uint32_t *p) {  // bypass the CU's L1
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
