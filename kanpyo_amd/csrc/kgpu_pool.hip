@@ -44,7 +44,11 @@ namespace {
 
 constexpr uint32_t MAXM = 8;         // trie matches buffered per start position
 constexpr uint32_t NONE16 = 0xFFFFu;
-constexpr uint32_t PAIR_CAP = 16 * 1024;  // bytes of pair table a sentence may hold beyond its largest position
+#ifndef KGPU_PAIR_CAP
+#define KGPU_PAIR_CAP 1024
+#endif
+constexpr uint32_t PAIR_CAP = KGPU_PAIR_CAP;  // bytes of pair table a sentence reserves beyond its largest position: the sweep goes block by block
+                                     // (<= 64 targets each, one gather round), a block's pairs rarely need more
 
 // ---- DPP butterfly: min over aligned groups of 2^lg lanes, every lane gets it.
 // The key is one u64 (total ^ signbit) << 32 | predecessor node index, so one
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
     uint32_t stop_after;
     // (the empty asm makes the pointer opaque: what was read before it is dead, what is not used before the next one is never loaded)
 #define KGPU_ARGS() do { KArgs kq_ = kargs; asm volatile("" : "+s"(kq_)); \
-        d.da = kq_->d.da; d.da_len = kq_->d.da_len; d.leaf_dup = kq_->d.leaf_dup; d.first = kq_->d.first; d.morph = kq_->d.morph; d.n_morph = kq_->d.n_morph; d.unk_morph = kq_->d.unk_morph; d.n_unk_morph = kq_->d.n_unk_morph; d.conn = kq_->d.conn; d.conn_rows = kq_->d.conn_rows; d.bos_right = kq_->d.bos_right; d.eos_left = kq_->d.eos_left; d.cat = kq_->d.cat; d.cat_len = kq_->d.cat_len; d.cinfo = kq_->d.cinfo; \
+        d.da = kq_->d.da; d.da_len = kq_->d.da_len; d.leaf_dup = kq_->d.leaf_dup; d.first = kq_->d.first; d.morph = kq_->d.morph; d.n_morph = kq_->d.n_morph; d.unk_morph = kq_->d.unk_morph; d.n_unk_morph = kq_->d.n_unk_morph; d.conn = kq_->d.conn; d.conn_rows = kq_->d.conn_rows; d.bos_right = kq_->d.bos_right; d.eos_left = kq_->d.eos_left; d.cat = kq_->d.cat; d.cat_len = kq_->d.cat_len; d.cinfo = kq_->d.cinfo; d.conn_tiled = kq_->d.conn_tiled; d.conn_rt64 = kq_->d.conn_rt64; \
         a.utf8 = kq_->a.utf8; a.offsets = kq_->a.offsets; a.n = kq_->a.n; a.ctl = kq_->a.ctl; a.arena = kq_->a.arena; a.arena_bytes = kq_->a.arena_bytes; a.stage = kq_->a.stage; a.tok_count = kq_->a.tok_count; a.status = kq_->a.status; a.out = kq_->a.out; a.out_cap = kq_->a.out_cap; a.tok_offsets = kq_->a.tok_offsets; a.count_work = kq_->a.count_work; a.ovf[0] = kq_->a.ovf[0]; a.ovf[1] = kq_->a.ovf[1]; a.ovf[2] = kq_->a.ovf[2]; a.ovf[3] = kq_->a.ovf[3]; a.est_q8 = kq_->a.est_q8; a.dump_lattice = kq_->a.dump_lattice; a.fused_host = kq_->a.fused_host; a.fused_seq = kq_->a.fused_seq; a.stat_slots = kq_->a.stat_slots; \
         io.in_list = kq_->io.in_list; io.in_count = kq_->io.in_count; io.out_list = kq_->io.out_list; io.out_count = kq_->io.out_count; io.late_count = kq_->io.late_count; stop_after = kq_->stop_after; } while (0)
     KGPU_ARGS();
@@ -388,16 +392,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         off = align_up(off, 8);
         uint2 *bk = (uint2 *)(smem + off);          off += 8 * (Nb + 1);  // bucket (= edges[e]): {dp, right | node << 16}; [Nb]: sink for EOS
         int32_t *nSid = (int32_t *)(smem + off);    off += 4 * N;   // +id known, -id unknown, 0 dummy
-        uint16_t *nLeft = (uint16_t *)(smem + off); off += 2 * N;
+        uint16_t *nLeft = (uint16_t *)(smem + off); off += 2 * N;   // left id until the node's block is gathered, then its best predecessor
         uint32_t *nCS = (uint32_t *)(smem + off);   off += 4 * N;   // word cost (i16) | bucket slot of the node << 16
         uint16_t *nStart = (uint16_t *)(smem + off); off += 2 * N;
         off = align_up(off, 4);
         const uint32_t off_emit_end = off;                          // everything above is written by emit
-        uint16_t *pre = (uint16_t *)(smem + off);   off += align_up(2 * N + 2, 4);  // [N]: sink; may overlay the match buffer
-        int16_t *mpair = (int16_t *)(smem + off);
+        uint16_t *pre = nLeft;                                      // (a block's sweep writes pre[t] after its gather has read nLeft[t])
+        int16_t *mpair = (int16_t *)(smem + off);                   // pair table of one block; overlays the match buffer
         if (N > 0xFFFF) { work_defer(io, lane, s); break; }
-        // exact requirement: emit-written arrays stay below the match buffer; afterwards pre + the
-        // pair table (whole, so that the sweep is one block) overlay it
+        // exact requirement: emit-written arrays stay below the match buffer; afterwards the pair table overlays it
         const uint32_t need_emit = off_emit_end + mbytes + 16, need_full = off + min(2 * E, max(2 * maxpairs, PAIR_CAP));
         if (need_emit > lds_bytes || off + 2 * maxpairs > lds_bytes) {
             // reservation too small: release, wait (holding nothing) for the exact size, redo
@@ -442,6 +445,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         // 3b, lane = node: its morph record (one gather per 64 nodes instead of one dependent load per record of the
         // busiest position), its slot in the bucket of the position it ends at.  The order inside a bucket is free:
         // the sweep breaks ties on the node index it carries.
+        // (with the tiled matrix the bucket carries the right id as its tile offset, (r >> 3) * 64 + (r & 7): the gather adds it as is)
+        const bool tiled = d.conn_tiled != nullptr;
+        auto rword = [&](uint32_t r) { return tiled ? ((r >> 3) << 6) | (r & 7u) : r; };
         for (uint32_t t0 = 1; t0 < N - 1; t0 += 128) {
             const uint32_t ta = t0 + lane, tb = ta + 64;
             const bool va = ta < N - 1, vb = tb < N - 1;
@@ -452,18 +458,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             if (va) {
                 const uint32_t slot = boff[ea] + atomicAdd(&bfill[ea], 1u);
                 nLeft[ta] = (uint16_t)ma.left; nCS[ta] = (uint32_t)(uint16_t)ma.cost | (slot << 16);
-                bk[slot].y = (uint32_t)(uint16_t)ma.right | (ta << 16);
+                bk[slot].y = rword((uint32_t)(uint16_t)ma.right) | (ta << 16);
             }
             if (vb) {
                 const uint32_t slot = boff[eb] + atomicAdd(&bfill[eb], 1u);
                 nLeft[tb] = (uint16_t)mb.left; nCS[tb] = (uint32_t)(uint16_t)mb.cost | (slot << 16);
-                bk[slot].y = (uint32_t)(uint16_t)mb.right | (tb << 16);
+                bk[slot].y = rword((uint32_t)(uint16_t)mb.right) | (tb << 16);
             }
         }
         if (lane == 0) {
             nLeft[N - 1] = (uint16_t)d.eos_left; nCS[N - 1] = Nb << 16;  // EOS: Morph(0,0,0), ranked id; its dp goes to the sink slot
             nStart[N - 1] = (uint16_t)C; nSid[N - 1] = 0;
-            bk[0] = make_uint2(0u, d.bos_right);  // BOS: dp None -> 0 (lattice.rs:127), right_id 0 (ranked), node 0
+            bk[0] = make_uint2(0u, rword(d.bos_right));  // BOS: dp None -> 0 (lattice.rs:127), right_id 0 (ranked), node 0
         }
         wave_sync();
         if (lane == 0) pre[0] = NONE16;
@@ -479,32 +485,29 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         // ---- phases 3b + 4, per block of positions whose pairs fit the pair table ----
         uint32_t qa = 0;
         while (qa <= C) {
-            KGPU_ARGS();
-            uint32_t qb;
-            if (E - ebase[qa] <= mcap) qb = C + 1;
-            else {  // largest qb with ebase[qb] - ebase[qa] <= mcap (ebase is non-decreasing)
-                uint32_t lo = qa + 1, hi = C + 1;  // invariant: ebase[lo] - ebase[qa] <= mcap (a single position fits)
-                while (lo < hi) {
-                    const uint32_t mid_ = (lo + hi + 1) / 2;
-                    if (ebase[mid_] - ebase[qa] <= mcap) lo = mid_; else hi = mid_ - 1;
-                }
-                qb = lo;
-            }
-            qb = bcast32(qb);  // values read back from LDS are VGPRs to the compiler: keep the loop control scalar
-            const uint32_t eb0 = bcast32(ebase[qa]);
+            // a block: as many positions (at most 64: one per lane) as keep the targets within one gather round (64) and
+            // the pairs within the table; the first position is taken whatever its size (the reservation covers the largest)
+            const uint32_t ql = qa + lane;
+            const bool inq = ql <= C;
+            const uint32_t nb0 = nb[inq ? ql : C], nb1 = nb[inq ? ql + 1 : C], eb_l = ebase[inq ? ql : C], eb1 = ebase[inq ? ql + 1 : C];
+            const uint32_t tA = bcast32(nb0), eb0 = bcast32(eb_l);
+            const uint64_t fits = __ballot(inq && (lane == 0 || (nb1 - tA <= 64u && eb1 - eb0 <= mcap)));
+            const uint32_t nq = ~fits ? (uint32_t)__ffsll((unsigned long long)~fits) - 1u : 64u;  // a prefix of the lanes: both sums are monotone (1..64)
+            const uint32_t qb = qa + nq;
             const uint64_t tg0 = prof ? __builtin_amdgcn_s_memtime() : 0;
             // -- 3b: gather every connection cost of the block into LDS (connection.rs:12-14).  Lane = target, four
             // independent gathers in flight per lane, the last group of a row padded with a repeat of its final entry
             // (ceil(P / 4) dependent rounds per target instead of P / 4 + P % 4).  Measured alternatives, all slower:
             // eight lanes per target with eight loads in flight (more LDS bookkeeping per load than it saves in cache
             // lines), 16 loads in flight per lane.
-            const uint32_t ta = bcast32(nb[qa]), tb = bcast32(nb[qb]);
+            const uint32_t ta = tA, tb = bcast32(nb[qb]);
             for (uint32_t t = ta + lane; t < tb; t += 64) {
                 const uint32_t q = nStart[t];
                 const uint32_t p0 = boff[q], P = boff[q + 1] - p0;
                 const uint32_t ti = t - nb[q];
                 const uint32_t base = ebase[q] - eb0 + ti * P;  // pair (ti, j) lives at ti*P + j
-                const int16_t *col = d.conn + (size_t)d.conn_rows * nLeft[t];
+                const uint32_t L = nLeft[t];
+                const int16_t *col = d.conn_tiled ? d.conn_tiled + ((size_t)(L >> 3) * d.conn_rt64 + (L & 7u) * 8u) : d.conn + (size_t)d.conn_rows * L;
                 for (uint32_t j = 0; j < P; j += 4) {
                     const uint32_t j1 = min(j + 1, P - 1), j2 = min(j + 2, P - 1), j3 = min(j + 3, P - 1);
                     const uint32_t r0 = bk[p0 + j].y & 0xFFFFu, r1 = bk[p0 + j1].y & 0xFFFFu;
@@ -537,22 +540,20 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             const uint32_t lds0 = (uint32_t)(uintptr_t)(KGPU_LDS(uint8_t) *)pool;  // absolute LDS addresses, wave-uniform: SGPRs
             const uint32_t a_ncs = bcast32(lds0 + (uint32_t)((uint8_t *)nCS - pool)), a_bk = bcast32(lds0 + (uint32_t)((uint8_t *)bk - pool));
             const uint32_t a_mp = bcast32(lds0 + (uint32_t)((uint8_t *)mpair - pool)), a_pre = bcast32(lds0 + (uint32_t)((uint8_t *)pre - pool));
-            for (uint32_t qc = qa; qc < qb; qc += 64) {
-                const uint32_t ql = qc + lane;
+            {
                 // three descriptor words per position: d0 = address of nCS[t0] (18 bits) | T (7) << 18 | P (6) << 25 | slow << 31,
                 // d1 = address of bk[p0], d2 = address of the position's pair costs
                 uint32_t dT = 0, dP = 0, dt0 = 0, d0 = 1u << 31, d1 = 0, d2 = 0;
-                if (ql < qb) {
-                    dt0 = nb[ql];
-                    const uint32_t dp0 = boff[ql], deb = ebase[ql] - eb0;
-                    dT = nb[ql + 1] - dt0;
+                if (lane < nq) {
+                    dt0 = nb0;
+                    const uint32_t dp0 = boff[ql], deb = eb_l - eb0;
+                    dT = nb1 - dt0;
                     dP = boff[ql + 1] - dp0;
                     const bool fastq = dP <= 32 && dT - 1u < 127u;  // 1 <= T <= 127, P <= 32
                     d0 = (a_ncs + 4 * dt0) | (fastq ? (dT << 18) | (dP << 25) : 1u << 31);
                     d1 = a_bk + 8 * dp0;
                     d2 = a_mp + 2 * deb;
                 }
-                const uint32_t nq = bcast32(min(64u, qb - qc));
                 KGPU_TM(tmDesc += __builtin_amdgcn_s_memtime() - tm_s0;)
                 for (uint32_t r = 0; r < nq; ++r) {
                     const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)r);
