@@ -115,7 +115,11 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // ---- LDS page pool: 64 pages, bit i of *bm set = page i taken ---------------------------------
+#ifdef KGPU_STEP_TIMING
+constexpr uint32_t POOL_HDR = 32;  // + sum of the wavefronts' exit times, exit counter (idle time of finished wavefronts inside a live workgroup)
+#else
 constexpr uint32_t POOL_HDR = 16;
+#endif
 constexpr uint32_t POOL_PAGES = 64;
 __device__ __forceinline__ uint64_t run_mask(uint32_t k, uint32_t pos) { return (k >= 64 ? ~0ull : ((1ull << k) - 1)) << pos; }
 
@@ -183,6 +187,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
     const uint32_t page = ((pool_bytes - POOL_HDR) / POOL_PAGES) & ~15u;
     auto pages_for = [&](uint32_t bytes) { return (bytes + page - 1) / page; };  // (a reciprocal multiply instead: measured, no difference)
     if (threadIdx.x == 0) *bm = 0;
+#ifdef KGPU_STEP_TIMING
+    if (threadIdx.x == 0) { *(uint64_t *)(pool + 16) = 0; *(uint32_t *)(pool + 24) = 0; }
+    const uint64_t tm_w0 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();  // the only workgroup barrier: from here on the wavefronts are independent
     // profiling accumulators of this workgroup (flushed once at exit: per-sentence
     // atomics on a handful of hot words distort what they measure)
@@ -716,6 +724,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
 #ifdef KGPU_STEP_TIMING
         constexpr bool flush = true;
         const uint64_t tm[8] = {tmS, tmSteps, tmSlow, tmSlowSteps, tmSent, tmPool, tmN, tmDesc};
+        uint64_t tm_idle = 0, tm_life = 0;
+        {
+            const uint64_t te = __builtin_amdgcn_s_memtime();
+            tm_life = te - tm_w0;
+            uint32_t old = 0;
+            if (lane == 0) { atomicAdd((unsigned long long *)(pool + 16), (unsigned long long)te); __threadfence_block(); old = atomicAdd((uint32_t *)(pool + 24), 1u); }
+            old = bcast32(old);
+            if (old == W - 1) tm_idle = (uint64_t)W * te - *(volatile uint64_t *)(pool + 16);  // the last one out: what the others waited
+        }
 #else
         constexpr bool flush = PROF;
 #endif
@@ -725,6 +742,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             if (!PROF) {
                 for (int k = 0; k < 7; ++k) if (lane == (uint32_t)k) v = tmPh[k];
                 for (int k = 0; k < 8; ++k) if (lane == 16u + k) v = tm[k];
+                if (lane == 24u) v = tm_idle;
+                if (lane == 25u) v = tm_life;
             }
 #endif
             if (PROF) {
