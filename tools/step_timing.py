@@ -10,7 +10,13 @@ from kanpyo_amd.tokenizer import pack_sentences
 kind = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 Q = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-sd = synth.build_dict(); sents = synth.make_corpus(sd, n, 1, kind); tok = Tokenizer(sd.dict); dev = torch.device("cuda", 0)
+sd = synth.build_dict(); sents = synth.make_corpus(sd, n, 1, kind)
+if os.environ.get("STEP_LEN"):  # only sentences of lo..hi characters (how much of the time is the spread of lengths inside a workgroup?)
+    lo, hi = map(int, os.environ["STEP_LEN"].split(","))
+    sents = [x for x in synth.make_corpus(sd, 40 * n, 1, kind) if lo <= len(x) <= hi][:n]
+    assert len(sents) == n, len(sents)
+    print("sentences of", lo, "..", hi, "characters, mean", sum(map(len, sents)) / n)
+tok = Tokenizer(sd.dict); dev = torch.device("cuda", 0)
 utf8, offs = pack_sentences(sents); cap = int(offs[-1]) + n
 du, do = torch.from_numpy(utf8.copy()).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev)
 ctxs = [DeviceContext(tok) for _ in range(Q)]
