@@ -526,7 +526,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             }
             wave_sync();
             if (prof) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
-            if (stop_after == 6) break;  // (the KGPU_STOP(6) below then ends the sentence)
+            if (stop_after == 6) { qa = qb; continue; }  // ablation timing: every block's gather, no sweep (the KGPU_STOP(6) below then ends the sentence)
 
             // -- 4: Viterbi sweep over the block (lattice.rs:116-142), LDS only.
             // One dependent chain per position: what a step costs is that chain and its taken branches, not its

@@ -10,19 +10,16 @@ src, dst = sys.argv[1], sys.argv[2]
 tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
 d = json.load(open(src))
 # the plain instantiation only: the <true> one (device-side work counters) runs outside the timed region
-kernels = [k for k in d if "k_tokenize" in k and "<true>" not in k]
-main = [k for k in kernels if "k_tokenize_pool" in k][0]
-batches = d[main]["FETCH_SIZE"]["dispatches"]  # the first pool launch of every plain batch
-fetch = write = 0.0
-for k in kernels:
-    scale = 1.0 if k == main else batches / max(d[k]["FETCH_SIZE"]["dispatches"], 1)  # general kernel: per-dispatch average
-    fetch += d[k]["FETCH_SIZE"]["sum"] * scale
-    write += d[k]["WRITE_SIZE"]["sum"] * scale
-fetch_kb, write_kb = fetch / batches, write / batches
+FULL = " [full 4096-sentence launches]"
+kernels = [k for k in d if "k_tokenize_pool" in k and "<true>" not in k and k.endswith(FULL)]
+main = kernels[0]
+batches = d[main]["FETCH_SIZE"]["dispatches"]
+fetch_kb = d[main]["FETCH_SIZE"]["per_dispatch"]  # per launch of the dominant kernel over a full batch (the general kernel
+write_kb = d[main]["WRITE_SIZE"]["per_dispatch"]  # behind it finds an empty list on cfg 2)
 out = {
     "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
               "`python bench.py --steps 2 --warmup 1 --queue 1 --no-cpu --no-extras`, tools/pmc_passes.sh)",
-    "per": "one batch of 4096 sentences = the k_tokenize_pool launch(es) + the k_tokenize_general launch: " + ", ".join(kernels),
+    "per": "one k_tokenize_pool launch over a full batch of 4096 sentences (grid 1024 x 256): " + main,
     "batches": batches,
     "fetch_size_kb": fetch_kb,
     "write_size_kb": write_kb,
@@ -37,7 +34,7 @@ print(json.dumps(out, indent=1))
 
 import os
 m = d[main]
-waves = m["SQ_WAVES"]["sum"]  # one wavefront per sentence in this kernel's first pass (4096-sentence batches, 4096 wave slots)
+waves = m["SQ_WAVES"]["sum"]  # one wavefront per sentence (4096-sentence batches, 4096 wavefronts)
 ins = {
     "source": f"profiles/{tag}_pmc_summary.json, kernel {main}: SQ_INSTS_* / SQ_WAVES (every wavefront of a full batch tokenizes one sentence)",
     "valu_per_sentence": m["SQ_INSTS_VALU"]["sum"] / waves, "salu_per_sentence": m["SQ_INSTS_SALU"]["sum"] / waves,
