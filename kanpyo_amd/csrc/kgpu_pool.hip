@@ -226,7 +226,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         // pool is routed on without paying for a trie walk that would be thrown away.
         // a parked match: {trie id, chars | records << 8}; one word id (21 bits) | chars (8) | records (3; 0 = look the count up)
         // when the ids fit (DictView::leaf_dup: fewer than 2^21 morphs)
-        const uint32_t MS = d.leaf_dup ? 4u : 8u;
+        const uint32_t MS = (d.leaf_dup && d.n_unk_morph < (1u << 21)) ? 4u : 8u;
         const uint32_t need1 = align_up(B + 4, 4) + 24 * (C + 2) + 2 * align_up(C + 2, 4) + align_up(C * MAXM * MS, 16) + 32;
         const uint32_t est = max(need1, (uint32_t)(((uint64_t)B * a.est_q8) >> 8) + 768);
         uint32_t npg = pages_for(est);
@@ -359,6 +359,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                         }
                         cnt += ci.unk_count;
                         atomicAdd(&boff[i + span], ci.unk_count);
+                        if (m < MAXM) {  // the unknown records ride behind the matches: the emit phase reads no category table
+                            if (MS == 4) mbuf[i * MAXM + m] = (uint32_t)ci.unk_first | ((ci.unk_count < 8 ? ci.unk_count : 0u) << 29);
+                            else *(uint2 *)(mbuf + 2 * (i * MAXM + m)) = make_uint2((uint32_t)ci.unk_first, ci.unk_count);
+                        }
                     }
                     uspan[i] = (uint16_t)span;
                     nb[i] = cnt;
@@ -432,8 +436,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         for (uint32_t i = lane; i < C; i += 64) {
             uint32_t t = nb[i];
             const uint32_t nm = mcnt[i], span = uspan[i];
-            CatInfo ci{};
-            if (span) ci = d.cinfo[ccat[i]];  // in flight while the matches are written out
+            uint32_t ufirst = 0, ucnt = 0;
+            if (span) {
+                if (nm < MAXM) {
+                    if (MS == 4) { const uint32_t w = mbuf[i * MAXM + nm]; ufirst = w & 0x1FFFFFu; ucnt = w >> 29; }
+                    else { const uint2 w = *(const uint2 *)(mbuf + 2 * (i * MAXM + nm)); ufirst = w.x; ucnt = w.y; }
+                }
+                if (ucnt == 0) { const CatInfo ci = d.cinfo[ccat[i]]; ufirst = (uint32_t)ci.unk_first; ucnt = ci.unk_count; }  // no room, or eight or more
+            }
             for (uint32_t m = 0; m < nm; ++m) {
                 uint32_t id, end, nrec;
                 if (MS == 4) {
@@ -447,7 +457,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                 for (uint32_t r = 0; r < nrec; ++r, ++t) { nSid[t] = (int32_t)(id + r); nStart[t] = (uint16_t)i; nLeft[t] = (uint16_t)end; }
             }
             if (span)   // lattice.rs:87-97,190-201
-                for (uint32_t r = 0; r < ci.unk_count; ++r, ++t) { nSid[t] = -(ci.unk_first + (int32_t)r); nStart[t] = (uint16_t)i; nLeft[t] = (uint16_t)(i + span); }
+                for (uint32_t r = 0; r < ucnt; ++r, ++t) { nSid[t] = -(int32_t)(ufirst + r); nStart[t] = (uint16_t)i; nLeft[t] = (uint16_t)(i + span); }
         }
         wave_sync();
         // 3b, lane = node: its morph record (one gather per 64 nodes instead of one dependent load per record of the
@@ -456,22 +466,24 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         // (with the tiled matrix the bucket carries the right id as its tile offset, (r >> 3) * 64 + (r & 7): the gather adds it as is)
         const bool tiled = d.conn_tiled != nullptr;
         auto rword = [&](uint32_t r) { return tiled ? ((r >> 3) << 6) | (r & 7u) : r; };
-        for (uint32_t t0 = 1; t0 < N - 1; t0 += 128) {
-            const uint32_t ta = t0 + lane, tb = ta + 64;
-            const bool va = ta < N - 1, vb = tb < N - 1;
-            const int32_t sa = va ? nSid[ta] : 1, sb = vb ? nSid[tb] : 1;
-            const uint32_t ea = va ? nLeft[ta] : 0u, eb = vb ? nLeft[tb] : 0u;
-            const Morph8 ma = *(sa > 0 ? d.morph + (sa - 1) : d.unk_morph + (-sa - 1));
-            const Morph8 mb = *(sb > 0 ? d.morph + (sb - 1) : d.unk_morph + (-sb - 1));
-            if (va) {
-                const uint32_t slot = boff[ea] + atomicAdd(&bfill[ea], 1u);
-                nLeft[ta] = (uint16_t)ma.left; nCS[ta] = (uint32_t)(uint16_t)ma.cost | (slot << 16);
-                bk[slot].y = rword((uint32_t)(uint16_t)ma.right) | (ta << 16);
+        for (uint32_t t0 = 1; t0 < N - 1; t0 += 256) {  // four nodes per lane: the four record gathers are in flight together
+            uint32_t tt[4], ee[4];
+            Morph8 mm[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                tt[k] = t0 + 64 * k + lane;
+                const bool v = tt[k] < N - 1;
+                const int32_t sid = v ? nSid[tt[k]] : 1;
+                ee[k] = v ? nLeft[tt[k]] : 0u;
+                mm[k] = *(sid > 0 ? d.morph + (sid - 1) : d.unk_morph + (-sid - 1));
             }
-            if (vb) {
-                const uint32_t slot = boff[eb] + atomicAdd(&bfill[eb], 1u);
-                nLeft[tb] = (uint16_t)mb.left; nCS[tb] = (uint32_t)(uint16_t)mb.cost | (slot << 16);
-                bk[slot].y = rword((uint32_t)(uint16_t)mb.right) | (tb << 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (tt[k] < N - 1) {
+                    const uint32_t slot = boff[ee[k]] + atomicAdd(&bfill[ee[k]], 1u);
+                    nLeft[tt[k]] = (uint16_t)mm[k].left; nCS[tt[k]] = (uint32_t)(uint16_t)mm[k].cost | (slot << 16);
+                    bk[slot].y = rword((uint32_t)(uint16_t)mm[k].right) | (tt[k] << 16);
+                }
             }
         }
         if (lane == 0) {
