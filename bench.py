@@ -113,9 +113,11 @@ class GpuEngine:
                         for u, o in p] for p in wl.packed]
         self.cap = wl.cap()
         nbmax = max(len(p) for p in wl.packed)
-        self.out = [[(torch.empty((self.cap, 6), dtype=torch.int32, device=dev),
-                      torch.empty(wl.batch + 1, dtype=torch.int64, device=dev),
-                      torch.empty(wl.batch, dtype=torch.uint8, device=dev)) for _ in range(nbmax)] for _ in range(ring)]
+        # token offsets of a step's batches: rows of ONE tensor, so that results() gets the per-sentence counts of the whole
+        # step with two tensor ops instead of three per batch (the host side of a gather chunk is what limits N = 8)
+        self.off2d = [torch.zeros((nbmax, wl.batch + 1), dtype=torch.int64, device=dev) for _ in range(ring)]
+        self.out = [[(torch.empty((self.cap, 6), dtype=torch.int32, device=dev), self.off2d[r][b],
+                      torch.empty(wl.batch, dtype=torch.uint8, device=dev)) for b in range(nbmax)] for r in range(ring)]
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, min(streams, self.Q)))]
         self.ctxs = [DeviceContext(tok, self.streams[i % len(self.streams)].cuda_stream) for i in range(self.Q)]
         self.seq, self.occupant, self.where, self.ntok = 0, [None] * self.Q, {}, {}
@@ -144,20 +146,29 @@ class GpuEngine:
 
     def results(self, step):
         """Waits for the step's batches; -> (token views [k, 6] int32, per-sentence token counts int64), all in HBM."""
-        views, counts = [], []
-        for b in range(self.nb(step)):
+        views, nb, total = [], self.nb(step), 0
+        for b in range(nb):
             k = self._retire((step, b))
-            t, o, _ = self.out[step % self.ring][b]
+            views.append(self.out[step % self.ring][b][0][:k])
             n = self.inputs[step % len(self.inputs)][b][2]
-            views.append(t[:k])
-            counts.append(o[1 : n + 1] - o[:n])
-        return views, (self.torch.cat(counts) if counts else self.torch.zeros(0, dtype=self.torch.int64, device=self.dev))
+            assert n == self.wl.batch or b == nb - 1, "only the last batch of a step may be ragged"
+            total += n
+        if nb == 0:
+            return views, self.torch.zeros(0, dtype=self.torch.int64, device=self.dev)
+        o = self.off2d[step % self.ring][:nb]
+        return views, (o[:, 1:] - o[:, :-1]).reshape(-1)[:total]  # row-major: the full batches, then the ragged one's prefix
 
     def after_gather(self):
-        """Order the contexts' streams behind the transfers just waited for: on the RCCL backend work.wait() only makes
-        torch's current stream wait, neither the host nor the streams the tokenize kernels run on."""
+        """Marks the transfers just waited for (on the RCCL backend work.wait() only makes torch's current stream wait,
+        neither the host nor the streams the tokenize kernels run on); order_behind(mark) puts the contexts' streams
+        behind it.  The caller does that one chunk LATER, when the ring slot is actually reused: ordering the streams
+        behind a mark just recorded stalls every tokenize stream until the copy kernels queued on a full chip are through
+        (measured: 57 instead of 68 M sentences/s on the one-rank self-test)."""
         ev = self.torch.cuda.Event()
         ev.record(self.torch.cuda.current_stream(self.dev))
+        return ev
+
+    def order_behind(self, ev):
         for st in self.streams:
             st.wait_event(ev)
 
@@ -189,8 +200,11 @@ def run_job(engine, nsteps, gather=None, chunk_steps=1, on_chunk=None):
         engine.drain()
         return
     posted = []  # first step of every chunk posted, in order; finished ones are consumed from the front
+    trace = os.environ.get("BENCH_TRACE_HOST")  # where the host's time goes: results / post / finish / enqueue, ms per chunk on stderr
+    acc = {"results": 0.0, "post": 0.0, "finish": 0.0, "enqueue": 0.0}
 
     def post(c0):
+        t0 = time.perf_counter()
         views, counts = [], []
         for s in range(c0, min(c0 + chunk_steps, nsteps)):
             v, c = engine.results(s)
@@ -198,29 +212,42 @@ def run_job(engine, nsteps, gather=None, chunk_steps=1, on_chunk=None):
             counts.append(c)
         import torch
 
+        t1 = time.perf_counter()
         gather.post_steps(views, torch.cat(counts), copy_own=True)
         posted.append(c0)
+        acc["results"] += t1 - t0
+        acc["post"] += time.perf_counter() - t1
 
     def finish_all():
+        t0 = time.perf_counter()
         for c0, r in zip(posted, gather.finish()):
             if on_chunk is not None:
                 on_chunk(c0, r)
         posted.clear()
-        engine.after_gather()  # the engine may overwrite those chunks' buffers only behind the transfers
+        acc["finish"] += time.perf_counter() - t0
+        return engine.after_gather()
 
     starts = list(range(0, nsteps, chunk_steps))
+    mark = None  # transfers of the chunks <= k - 3, marked one iteration ago
     for k, c0 in enumerate(starts):
+        if mark is not None:
+            engine.order_behind(mark)  # chunk k reuses chunk k - 3's ring slot: only behind that chunk's transfers
+            mark = None
         if k >= 2:
-            finish_all()  # chunks <= k - 2: their buffers are free again (chunk k reuses chunk k - 3's ring slot)
+            mark = finish_all()  # chunks <= k - 2 have left their buffers (host-side on gloo, stream-side on RCCL)
+        t0 = time.perf_counter()
         for s in range(c0, min(c0 + chunk_steps, nsteps)):
             for b in range(engine.nb(s)):
                 engine.enqueue(s, b)
+        acc["enqueue"] += time.perf_counter() - t0
         if k >= 1:
             post(starts[k - 1])
     if starts:
         post(starts[-1])
     finish_all()
     engine.drain()
+    if trace:
+        print("host ms per chunk:", {k: round(1e3 * v / max(len(starts), 1), 3) for k, v in acc.items()}, file=sys.stderr)
 
 
 def chunk_steps_for(nb_per_step):
