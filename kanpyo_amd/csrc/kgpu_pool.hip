@@ -528,12 +528,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                 const uint32_t base = ebase[q] - eb0 + ti * P;  // pair (ti, j) lives at ti*P + j
                 const uint32_t L = nLeft[t];
                 const int16_t *col = d.conn_tiled ? d.conn_tiled + ((size_t)(L >> 3) * d.conn_rt64 + (L & 7u) * 8u) : d.conn + (size_t)d.conn_rows * L;
-                for (uint32_t j = 0; j < P; j += 4) {
+                for (uint32_t j = 0; j < P; j += 8) {  // two groups of four per round, the second only where the row goes on
                     const uint32_t j1 = min(j + 1, P - 1), j2 = min(j + 2, P - 1), j3 = min(j + 3, P - 1);
+                    const bool more = j + 4 < P;
+                    const uint32_t j4 = j + 4, j5 = min(j + 5, P - 1), j6 = min(j + 6, P - 1), j7 = min(j + 7, P - 1);
                     const uint32_t r0 = bk[p0 + j].y & 0xFFFFu, r1 = bk[p0 + j1].y & 0xFFFFu;
                     const uint32_t r2 = bk[p0 + j2].y & 0xFFFFu, r3 = bk[p0 + j3].y & 0xFFFFu;
+                    uint32_t r4 = 0, r5 = 0, r6 = 0, r7 = 0;
+                    if (more) { r4 = bk[p0 + j4].y & 0xFFFFu; r5 = bk[p0 + j5].y & 0xFFFFu; r6 = bk[p0 + j6].y & 0xFFFFu; r7 = bk[p0 + j7].y & 0xFFFFu; }
                     const int16_t c0 = col[r0], c1 = col[r1], c2 = col[r2], c3 = col[r3];
+                    int16_t c4 = 0, c5 = 0, c6 = 0, c7 = 0;
+                    if (more) { c4 = col[r4]; c5 = col[r5]; c6 = col[r6]; c7 = col[r7]; }
                     mpair[base + j] = c0; mpair[base + j1] = c1; mpair[base + j2] = c2; mpair[base + j3] = c3;
+                    if (more) { mpair[base + j4] = c4; mpair[base + j5] = c5; mpair[base + j6] = c6; mpair[base + j7] = c7; }
                 }
             }
             wave_sync();
