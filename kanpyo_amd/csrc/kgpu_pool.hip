@@ -44,6 +44,12 @@ namespace {
 
 constexpr uint32_t MAXM = 8;         // trie matches buffered per start position
 constexpr uint32_t NONE16 = 0xFFFFu;
+#ifndef KGPU_POOL_SLEEP
+#define KGPU_POOL_SLEEP 16
+#endif
+#ifndef KGPU_EST_SLACK
+#define KGPU_EST_SLACK 768
+#endif
 #ifndef KGPU_PAIR_CAP
 #define KGPU_PAIR_CAP 1024
 #endif
@@ -146,7 +152,7 @@ __device__ __forceinline__ uint32_t pool_wait_alloc(uint64_t *bm, uint32_t k, ui
     for (uint32_t spin = 0; spin < (1u << 20); ++spin) {
         const uint32_t pg = pool_try_alloc(bm, k, lane);
         if (pg != NONE) return pg;
-        __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_s_sleep(KGPU_POOL_SLEEP);
     }
     return NONE;
 }
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         // when the ids fit (DictView::leaf_dup: fewer than 2^21 morphs)
         const uint32_t MS = (d.leaf_dup && d.n_unk_morph < (1u << 21)) ? 4u : 8u;
         const uint32_t need1 = align_up(B + 4, 4) + 24 * (C + 2) + 2 * align_up(C + 2, 4) + align_up(C * MAXM * MS, 16) + 32;
-        const uint32_t est = max(need1, (uint32_t)(((uint64_t)B * a.est_q8) >> 8) + 768);
+        const uint32_t est = max(need1, (uint32_t)(((uint64_t)B * a.est_q8) >> 8) + KGPU_EST_SLACK);
         uint32_t npg = pages_for(est);
         // routing: a sentence expected to need more than max_pages would hold a large part of the pool for a long
         // time (LDS x time grows with the square of the length); it is better served by the long-sentence kernel
