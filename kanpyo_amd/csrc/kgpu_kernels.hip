@@ -80,6 +80,16 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
     Slab sa{nullptr, 0}, sn{nullptr, 0};
     const int32_t base_root = d.da[1].base;
     uint64_t accW[7] = {0, 0, 0, 0, 0, 0, 0};  // work counters of this workgroup, flushed once at exit
+#ifdef KGPU_STEP_TIMING  // measurement build: s_memtime ticks of this kernel's phases and of the pieces of a sweep block
+    uint64_t gt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // decode+count, scan, emit, block set-up, targets+gather, chain, write-back, global steps, backtrace+tokens, blocks
+#define KGPU_GT(k, expr) do { const uint64_t t0_ = __builtin_amdgcn_s_memtime(); expr; gt[k] += __builtin_amdgcn_s_memtime() - t0_; } while (0)
+#define KGPU_GTICK(v) const uint64_t v = __builtin_amdgcn_s_memtime()
+#define KGPU_GADD(k, a_, b_) gt[k] += (b_) - (a_)
+#else
+#define KGPU_GT(k, expr) expr
+#define KGPU_GTICK(v)
+#define KGPU_GADD(k, a_, b_)
+#endif
 
     for (uint32_t iter = 0;; ++iter) {
         uint64_t s = 0;
@@ -88,6 +98,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         const uint64_t b0 = a.offsets[s];
         const uint32_t B = (uint32_t)(a.offsets[s + 1] - b0);
         const uint8_t *text = a.utf8 + b0;
+        KGPU_GTICK(g_t0);
 
         // ---- slab A: per-char arrays (C <= B) --------------------------------
         const uint64_t na = (uint64_t)B + 4;
@@ -204,6 +215,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
 
 #define KGPU_GSTOP(k) if (stop_after == (k)) { if (lane == 0) { a.status[s] = KGPU_SENT_TRUNCATED; a.tok_count[s] = 0; } continue; }
         KGPU_GSTOP(3)
+        KGPU_GTICK(g_t1); KGPU_GADD(0, g_t0, g_t1);
         // ---- phase 2: prefix sums ------------------------------------------------
         uint32_t ncarry = 1, bcarry = 0;  // node 0 is BOS
         for (uint32_t i0 = 0; i0 < C + 2; i0 += 64) {
@@ -228,6 +240,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         uint2 *nodeB = (uint2 *)(bucket + N);  // {start char, end char}
         uint32_t *pre = (uint32_t *)(nodeB + N);
 
+        KGPU_GTICK(g_t2); KGPU_GADD(1, g_t1, g_t2);
         // ---- phase 3: emit -----------------------------------------------------------
         for (uint32_t i = lane; i < C; i += 64) {
             uint32_t t = nb[i];
@@ -273,6 +286,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         __syncthreads();
 
         KGPU_GSTOP(5)
+        KGPU_GTICK(g_t3); KGPU_GADD(2, g_t2, g_t3);
         // ---- phase 4: Viterbi sweep ---------------------------------------------------
         // one position through global memory (lattice.rs:116-142): lanes take targets, every lane
         // walks the whole predecessor bucket
@@ -336,6 +350,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             uint32_t *posT0 = (uint32_t *)lds, *posP0 = posT0 + 64, *posP = posP0 + 64, *posEb = posP + 64;
             const uint32_t cap = lds_bytes - 1040;  // 1024 B of position tables + 16 B of store sinks
             for (uint32_t qa = 0; qa <= C;) {
+                KGPU_GTICK(g_b0);
                 const uint32_t ql = qa + lane;
                 const bool in = ql <= C;
                 const uint32_t t0g = in ? nb[ql] : 0, t1g = in ? nb[ql + 1] : 0;
@@ -350,7 +365,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                 const uint32_t cE = wave_incl_scan(pairs, lane);
                 const bool fit = in && cneed <= cap && cP < 0xFFFFu && cT < 0xFFFFu && cE < 0x1FFFFu;
                 const uint32_t nq = (uint32_t)__popcll(__ballot(fit));  // a prefix of the lanes: every sum is monotone
-                if (nq == 0) { global_step(qa); ++qa; continue; }       // one position too large for the budget
+                if (nq == 0) { KGPU_GT(7, global_step(qa)); ++qa; continue; }       // one position too large for the budget
                 const uint32_t tA = bcast32(t0g), pA = bcast32(p0g);
                 const uint32_t nt = (uint32_t)__shfl((int)cT, (int)nq - 1, 64), nbk = (uint32_t)__shfl((int)cP, (int)nq - 1, 64);
                 const uint32_t np = (uint32_t)__shfl((int)cE, (int)nq - 1, 64);
@@ -371,6 +386,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                     dpL[i] = e.x; ndL[i] = e.z; rtL[i] = (uint16_t)e.y;
                 }
                 wave_fence();
+                KGPU_GTICK(g_b1); KGPU_GADD(3, g_b0, g_b1);
                 // targets + gather (lane = target, 4 gathers in flight; issuing the node records and sixteen gathers of four
                 // targets at once was measured and is slower: cfg 3 11.6 -> 10.1 M sentences/s)
                 for (uint32_t t = lane; t < nt; t += 64) {
@@ -388,6 +404,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                     }
                 }
                 wave_fence();
+                KGPU_GTICK(g_b2); KGPU_GADD(4, g_b1, g_b2);
                 // The chain (same step as kgpu_pool.hip's, see there for the measurements behind it): descriptors in lanes,
                 // d0 = first target | first bucket slot << 16, d1 = pair offset (17 bits) | T (7) << 17 | P (6) << 24, bit 31 =
                 // not the straight-line shape.  ONE straight-line body for P <= 16 (eight lanes per target, lane j takes
@@ -481,6 +498,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                     wave_fence();
                 }
                 wave_fence();
+                KGPU_GTICK(g_b3); KGPU_GADD(5, g_b2, g_b3);
                 // dp of the nodes that end beyond the block goes back to their HBM bucket entries
                 for (uint32_t t = lane; t < nt; t += 64) {
                     pre[tA + t] = preL[t];
@@ -490,12 +508,17 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                     }
                 }
                 __syncthreads();  // single wavefront: a fence that also drains the global stores before the next block reads
+                KGPU_GTICK(g_b4); KGPU_GADD(6, g_b3, g_b4);
+#ifdef KGPU_STEP_TIMING
+                gt[9] += 1;
+#endif
                 qa += nq;
             }
             wE = wave_sum(wE);
         }
 
         KGPU_GSTOP(7)
+        KGPU_GTICK(g_t4);
         // ---- phase 5: backtrace + tokens -----------------------------------------------
         uint32_t K = 0;
         if constexpr (!LDS_SWEEP) {
@@ -550,6 +573,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             }
         }
         if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; }
+        KGPU_GTICK(g_t5); KGPU_GADD(8, g_t4, g_t5);
         if (a.dump_lattice && lane == 0) {  // kgpu_lattice_dump: the host reads the lattice straight out of the two slabs
             a.ctl->dump[0] = (unsigned long long)(sa.ptr - a.arena); a.ctl->dump[1] = (unsigned long long)(sn.ptr - a.arena);
             a.ctl->dump[2] = B; a.ctl->dump[3] = C; a.ctl->dump[4] = N; a.ctl->dump[5] = 1;
@@ -562,6 +586,13 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
     }
     if (a.count_work && lane == 0)
         for (int k = 0; k < 7; ++k) atomicAdd(&a.ctl->work[k], (unsigned long long)accW[k]);
+#ifdef KGPU_STEP_TIMING
+    if (LDS_SWEEP && a.stat_slots) {  // the workgroup's own slot (summed on the host): words 16.. = Control::phase
+        uint64_t v = 0;
+        for (int k = 0; k < 10; ++k) if (lane == 16u + k) v = gt[k];
+        if (lane >= 16 && lane < 26) a.stat_slots[((uint64_t)blockIdx.x & (STAT_SLOTS - 1)) * STAT_WORDS + lane] += v;
+    }
+#endif
 }
 
 // Exclusive scan of per-sentence token counts -> tok_offsets (single workgroup;
