@@ -135,6 +135,58 @@ __device__ __forceinline__ uint32_t da_walk_first(const DictView &d, const uint8
     return steps;
 }
 
+// Two walks of one lane side by side (the long-sentence kernel's count phase: positions i and i + 64): the same steps as
+// da_walk_first, but the loads of both walks are issued before either is consumed, so a chunk pair costs the longer of
+// its two longest walks instead of their sum.  A walk that is not `on`, or whose character is not in the first table's
+// range (cp = 0xFFFF), is left to the caller (plain da_walk).  Returns the byte steps taken by both.
+template <class FA, class FB>
+__device__ __forceinline__ uint32_t da_walk_first2(const DictView &d, const uint8_t *text, uint32_t B,
+                                                   bool onA, uint32_t cpA, uint32_t kbA, uint32_t knA, FA &&matchA,
+                                                   bool onB, uint32_t cpB, uint32_t kbB, uint32_t knB, FB &&matchB) {
+    struct W { int32_t p, bp; uint32_t k, nstart; bool live; };
+    W a{0, 0, knA, 1, false}, b{0, 0, knB, 1, false};
+    uint32_t steps = 0;
+    DaNode fa{0, 0}, fb{0, 0};
+    if (onA) fa = d.first[cpA];
+    if (onB) fb = d.first[cpB];
+    if (onA) { if (fa.base == 0) steps += (uint32_t)fa.check; else { a.p = fa.base; a.bp = fa.check; a.live = true; steps += knA - kbA; } }
+    if (onB) { if (fb.base == 0) steps += (uint32_t)fb.check; else { b.p = fb.base; b.bp = fb.check; b.live = true; steps += knB - kbB; } }
+    while (a.live || b.live) {
+        // issue: next byte, terminator probe (only where a key can end: a character boundary), child
+        const bool moreA = a.live && a.k < B, moreB = b.live && b.k < B;
+        const uint32_t cA = moreA ? text[a.k] : 0u, cB = moreB ? text[b.k] : 0u;
+        const bool bndA = !moreA || (cA & 0xC0) != 0x80, bndB = !moreB || (cB & 0xC0) != 0x80;
+        const uint32_t qA = (uint32_t)(a.bp + (int32_t)cA), qB = (uint32_t)(b.bp + (int32_t)cB);
+        const bool prA = a.live && bndA && (uint32_t)a.bp < d.da_len, prB = b.live && bndB && (uint32_t)b.bp < d.da_len;
+        const bool nxA = moreA && qA < d.da_len, nxB = moreB && qB < d.da_len;
+        DaNode tA{0, 0}, nA{0, 0}, tB{0, 0}, nB{0, 0};
+        if (prA) tA = d.da[a.bp];
+        if (nxA) nA = d.da[qA];
+        if (prB) tB = d.da[b.bp];
+        if (nxB) nB = d.da[qB];
+        // consume
+        if (a.live) {
+            if (prA && tA.check == a.p && tA.base < 0) { uint32_t id, dup; leaf_decode(d, tA.base, id, dup); matchA(id, a.nstart, dup); }
+            if (!moreA) a.live = false;
+            else {
+                ++steps;
+                if (!nxA || nA.check != a.p) a.live = false;  // da.rs:162-165
+                else { a.p = (int32_t)qA; a.bp = nA.base; a.nstart += bndA; ++a.k; }
+            }
+        }
+        if (b.live) {
+            if (prB && tB.check == b.p && tB.base < 0) { uint32_t id, dup; leaf_decode(d, tB.base, id, dup); matchB(id, b.nstart, dup); }
+            if (!moreB) b.live = false;
+            else {
+                ++steps;
+                if (!nxB || nB.check != b.p) b.live = false;
+                else { b.p = (int32_t)qB; b.bp = nB.base; b.nstart += bndB; ++b.k; }
+            }
+        }
+    }
+    return steps;
+}
+
 // Work-list plumbing shared by the kernels of a launch chain: launch k takes its sentence ids
 // from list `in_list` (nullptr = identity over [0, n)) and pushes the ones it does not
 // serve (LDS budget, routing) onto the next launch's list.  Work is a

@@ -170,33 +170,56 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         const int nchunks = (int)((C + 63) / 64);
         uint32_t carry_end = C;
         uint32_t wT = 0, wE = 0;  // work counters (only reduced when a.count_work)
-        for (int ch = nchunks - 1; ch >= 0; --ch) {
-            const uint32_t i = (uint32_t)ch * 64 + lane;
-            const bool active = i < C;
-            const uint32_t cat = active ? ccat[i] : 0x1FFu;
-            const uint32_t ncat = (i + 1 < C) ? ccat[i + 1] : 0x2FFu;
-            const uint64_t bm = __ballot(active && ncat != cat);
-            const uint64_t rest = bm >> lane;
-            const uint32_t run_end = rest ? i + (uint32_t)__ffsll((unsigned long long)rest) : carry_end;
-            carry_end = bcast32(run_end);
-            if (active) {
-                uint32_t cnt = 0, m = 0;
-                wT += da_walk_first(d, text, cp16[i], cbyte[i], cbyte[i + 1], B, base_root, [&](uint32_t id, uint32_t nch, uint32_t dup) {
+        // two chunks of 64 start positions per round, walked side by side (da_walk_first2): a chunk costs its longest
+        // walk, a pair the longer of the two -- not their sum (the count walk is 21-28 % of this kernel)
+        for (int ch = nchunks - 1; ch >= 0; ch -= 2) {
+            uint32_t iX[2], catX[2], runX[2], cntX[2] = {0, 0}, mX[2] = {0, 0};
+            bool actX[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {  // x = 0: chunk ch, x = 1: chunk ch - 1 (run ends carry from the later chunk to the earlier)
+                const bool have = ch - x >= 0;
+                const uint32_t i = have ? (uint32_t)(ch - x) * 64 + lane : 0xFFFFFFF0u;
+                const bool active = have && i < C;
+                const uint32_t cat = active ? ccat[i] : 0x1FFu;
+                const uint32_t ncat = (have && i + 1 < C) ? ccat[i + 1] : 0x2FFu;
+                const uint64_t bm = __ballot(active && ncat != cat);
+                const uint64_t rest = bm >> lane;
+                const uint32_t run_end = rest ? i + (uint32_t)__ffsll((unsigned long long)rest) : carry_end;
+                if (have) carry_end = bcast32(run_end);
+                iX[x] = i; actX[x] = active; catX[x] = cat; runX[x] = run_end;
+            }
+            auto on_match = [&](int x) {
+                return [&, x](uint32_t id, uint32_t nch, uint32_t dup) {
+                    const uint32_t i = iX[x];
+                    uint32_t &m = mX[x];
                     if (m < GMAXM && nch < 256) { mid[(size_t)i * GMAXM + m] = id; mnch[(size_t)i * GMAXM + m] = (uint8_t)nch; }
                     else m = 0x100;  // does not fit the parking area: the emit phase walks again
                     ++m;
                     uint32_t nrec = 1u + (dup != NONE ? dup : (uint32_t)d.morph[id - 1].dup);  // index.rs:46-51
-                    cnt += nrec;
+                    cntX[x] += nrec;
                     atomicAdd(&cnt_e[i + nch], nrec);
-                });
+                };
+            };
+            uint32_t cpX[2], kbX[2], knX[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) { cpX[x] = actX[x] ? cp16[iX[x]] : 0xFFFFu; kbX[x] = actX[x] ? cbyte[iX[x]] : 0u; knX[x] = actX[x] ? cbyte[iX[x] + 1] : 0u; }
+            wT += da_walk_first2(d, text, B, actX[0] && cpX[0] != 0xFFFFu, cpX[0], kbX[0], knX[0], on_match(0),
+                                 actX[1] && cpX[1] != 0xFFFFu, cpX[1], kbX[1], knX[1], on_match(1));
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                if (!actX[x]) continue;
+                const uint32_t i = iX[x];
+                if (cpX[x] == 0xFFFFu) wT += da_walk(d, text, kbX[x], B, base_root, on_match(x));  // first character outside the BMP: no table entry
+                uint32_t cnt = cntX[x];
+                const uint32_t m = mX[x];
                 mcnt[i] = (uint8_t)(m > GMAXM ? 0xFFu : m);
-                const CatInfo ci = d.cinfo[cat];
+                const CatInfo ci = d.cinfo[catX[x]];
                 uint32_t span = 0;
                 // lattice.rs:54: !matched_known || invoke_list[cat]; lattice.rs:87-92: no unk entry -> nothing
                 if ((cnt == 0 || (ci.flags & CAT_INVOKE)) && (ci.flags & CAT_HAS_UNK) && ci.unk_count) {
                     span = 1;
                     if (ci.flags & CAT_GROUP) {  // lattice.rs:66-84
-                        uint32_t r = run_end - i;
+                        uint32_t r = runX[x] - i;
                         span = r < MAX_UNKNOWN_LEN ? r : MAX_UNKNOWN_LEN;
                     }
                     cnt += ci.unk_count;
