@@ -90,7 +90,7 @@ struct kgpu_dict {
     std::atomic<int> big_pool_batches{0};
     // Same for the long-sentence kernel (its workgroups hold 32 KB of LDS each): issued while recent
     // batches still had sentences left after the pools.
-    std::atomic<int> long_batches{0};
+    std::atomic<int> long_batches{64};  // starts armed: a corpus of long sentences does not spend its first batches in the last-resort kernel (3.8 ms per batch on cfg 3)
     // Streams handed round-robin to contexts created without one.  HIP multiplexes streams onto three
     // hardware queues: a 4th stream queues behind the 1st and unbalances them (measured -25 %), so any
     // number of contexts shares three streams; each context waits on its own completion event.
