@@ -55,6 +55,11 @@ def algorithmic_bytes(w):
     return a, b, c
 
 
+def result_rate_guess(rate_1thread, nthreads):
+    """Sentences per second to expect from `nthreads` host threads (sizes the all-core leg to about two seconds)."""
+    return rate_1thread * max(1.0, 0.5 * nthreads)
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -721,17 +726,26 @@ def main():
         g_tok, g_off = sample_tokens
         exact = bool(np.array_equal(g_off.astype(np.uint64), exp0.offsets[: BATCH + 1])
                      and np.array_equal(g_tok.reshape(-1), exp0.tokens[:n0].view(np.int32).reshape(-1).astype(np.int32)))
-        orc.tokenize_batch(utf8, offs, ncores, out=bufs, copy=False)
-        reps_all = 3
-        t1 = time.perf_counter()
-        for _ in range(reps_all):
-            orc.tokenize_batch(utf8, offs, ncores, out=bufs, copy=False)
-        t_all = (time.perf_counter() - t1) / reps_all
+        # all cores: per-sentence slots in one preallocated buffer (no allocator, no merge copy inside the timed call), threads claim
+        # runs of 64 sentences, several passes per call so that starting the threads is paid once; hardware threads and physical cores both tried
+        slots = (np.zeros(int(offs[-1]) + n_c, dtype=oracle.TOKEN_DTYPE), np.zeros(n_c, dtype=np.uint32))
+        orc.tokenize_slots(utf8, offs, ncores, 1, out=slots)  # untimed: pages touched
+        all_cores = None
+        for nthr in sorted({ncores, max(1, ncores // 2)}, reverse=True):
+            reps_all = max(4, int(2.0 * result_rate_guess(done / t_cpu, nthr) / n_c))
+            t1 = time.perf_counter()
+            orc.tokenize_slots(utf8, offs, nthr, reps_all, out=slots)
+            t_all = (time.perf_counter() - t1) / reps_all
+            cand = {"value": n_c / t_all, "cores": nthr, "passes": reps_all,
+                    "what": "korc_tokenize_slots: one preallocated slot range per sentence, threads claim runs of 64 sentences"}
+            if all_cores is None or cand["value"] > all_cores["value"]:
+                all_cores = cand
+        all_cores["scaling_vs_1thread"] = all_cores["value"] / (done / t_cpu)
         result["cpu_baseline"] = {
             "value": done / t_cpu, "unit": "sentences/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"the same 100k-sentence cfg2 corpus, {done // n_c} pass(es), {t_cpu:.1f} s, single pass per sentence into a "
                       "preallocated worst-case buffer, oracle/kanpyo_oracle.c (CPU restatement of Kanpyo's algorithm, gcc -O2), single thread",
-            "all_cores": {"value": n_c / t_all, "cores": ncores, "what": "one contiguous sentence range per hardware thread"},
+            "all_cores": all_cores,
             "gpu_batch0_bit_exact": exact,
         }
         result["speedup_vs_cpu_1thread"] = result["value"] / result["cpu_baseline"]["value"]

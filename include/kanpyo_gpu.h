@@ -96,15 +96,20 @@ typedef struct kgpu_dict_info {
 } kgpu_dict_info;
 
 /* Per-launch timing of the dominant kernel, collected with HIP events on the
- * ctx stream (bench.py roofline leg). */
+ * ctx stream (bench.py roofline leg).  24 bytes, layout frozen: callers built against round 1 of this header
+ * pass a buffer of exactly this size. */
 typedef struct kgpu_profile {
     uint64_t launches;     /* tokenize kernel launches timed                  */
     double tokenize_ms;    /* sum over the timed batches of the whole tokenize launch chain (dominant kernel, long-sentence and
                               last-resort kernels, and whatever time those small launches wait for a slot on a busy chip) */
     double aux_ms;         /* sum of scan + compaction kernel durations         */
-    /* Routing counters, always on (they cost nothing: read from the batch's control block at
-     * kgpu_ctx_sync).  A dictionary or text whose lattices outgrow the LDS-resident kernel shows up
-     * here long before it shows up as a throughput cliff. */
+} kgpu_profile;
+
+/* Routing counters, always on (they cost nothing: read from the batch's control block at
+ * kgpu_ctx_sync).  A dictionary or text whose lattices outgrow the LDS-resident kernel shows up
+ * here long before it shows up as a throughput cliff.  Read with kgpu_ctx_get_routing, which takes the
+ * caller's sizeof(kgpu_routing): fields may be appended in later versions, never moved. */
+typedef struct kgpu_routing {
     uint64_t batches;         /* batches completed                                            */
     uint64_t sentences;       /* sentences in them                                            */
     uint64_t deferred[4];     /* sentences handed from launch k of the chain to launch k+1
@@ -114,9 +119,12 @@ typedef struct kgpu_profile {
                                  (LDS reservation too small: the sentence was redone)         */
     uint64_t long_launches;   /* batches for which the long-sentence kernel was launched      */
     uint64_t arena_regrows;   /* batches rerun because the HBM scratch arena was too small    */
-    double first_ms;          /* sum over the timed batches of the FIRST launch alone: the dominant kernel
-                                 (k_tokenize_pool), the number rocprofv3's kernel stats report for it        */
-} kgpu_profile;
+    double first_ms;          /* with KGPU_PROFILE_EVENTS: sum over the timed batches of the FIRST launch alone, the dominant
+                                 kernel (k_tokenize_pool) -- the number rocprofv3's kernel stats report for it        */
+    uint64_t small_calls;     /* kgpu_tokenize_batch calls served by the single-launch path                          */
+    uint64_t small_fallbacks; /* ... that had to be redone on the general path (a sentence too long for LDS, or the
+                                 in-kernel rendezvous timed out)                                                     */
+} kgpu_routing;
 
 /* Work counters of one or more batches, counted on the device when
  * kgpu_ctx_set_profiling(ctx, KGPU_PROFILE_WORK) is on (the
@@ -186,6 +194,8 @@ int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_o
 int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens);
 int kgpu_ctx_set_profiling(kgpu_ctx *c, int mode /* KGPU_PROFILE_* bit mask */);
 int kgpu_ctx_get_profile(kgpu_ctx *c, kgpu_profile *out, int reset);
+/* Copies min(out_size, sizeof(kgpu_routing)) bytes: a caller built against an older, shorter kgpu_routing stays valid. */
+int kgpu_ctx_get_routing(kgpu_ctx *c, kgpu_routing *out, size_t out_size, int reset);
 /* Measurement only (bench.py's per-stage roofline): every sentence of the following batches stops
  * after the given stage of the fused kernel, yields zero tokens and status KGPU_SENT_TRUNCATED.
  * 0 = off (normal operation).  Stages: 5 = lattice built (SURVEY.md 8d Stage A: load, decode, trie

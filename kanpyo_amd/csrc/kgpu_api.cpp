@@ -72,6 +72,26 @@ struct DevBuf {
 
 }  // namespace
 
+// Test-only environment hooks.  getenv is not thread-safe against setenv, and kgpu_tokenize_batch may be called from many
+// threads: the hooks are read under a mutex, ONCE per process -- unless KGPU_TEST_HOOKS_REREAD is set (tests/conftest.py sets
+// it: the tests flip the hooks between calls).
+struct TestHooks { bool no_small_calls = false; uint64_t chunk_bytes = 4ull << 20, chunk_sents = 16384; };
+static bool env_flag_now(const char *name) { const char *e = getenv(name); return e && *e && *e != '0'; }
+static TestHooks test_hooks() {
+    static std::mutex mu;
+    static TestHooks cur;
+    static bool init = false;
+    std::lock_guard<std::mutex> g(mu);
+    if (!init || env_flag_now("KGPU_TEST_HOOKS_REREAD")) {
+        init = true;
+        cur = TestHooks{};
+        cur.no_small_calls = env_flag_now("KGPU_NO_SMALL_CALLS");
+        if (const char *e = getenv("KGPU_HOST_CHUNK_BYTES")) cur.chunk_bytes = strtoull(e, nullptr, 10);
+        if (const char *e = getenv("KGPU_HOST_CHUNK_SENTS")) cur.chunk_sents = strtoull(e, nullptr, 10);
+    }
+    return cur;
+}
+
 struct kgpu_dict {
     int device = 0;
     DictView view{};
@@ -144,6 +164,7 @@ struct kgpu_ctx {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     kgpu_profile prof{};
+    kgpu_routing rt{};
 };
 
 extern "C" const char *kgpu_last_error(void) { return g_err; }
@@ -348,7 +369,7 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
     // anyway, and the record count of the surface (index.rs:46-51) is the next thing it needs: with ids below 2^21 the spare
     // bits hold it (1023 = larger, look it up), and one dependent load per match disappears from the walk.
     uint32_t leaf_dup = 0;
-    if (morphs.size() < (1u << 21) && !getenv("KGPU_PLAIN_LEAVES") /* tests: the layout of a dictionary with 2^21 morphs or more */) {
+    if (morphs.size() < (1u << 21) && !env_flag_now("KGPU_PLAIN_LEAVES") /* tests: the layout of a dictionary with 2^21 morphs or more */) {
         leaf_dup = 1;
         for (size_t a2 = 0; a2 < da.size(); ++a2) {
             DaNode &nd = da[a2];
@@ -594,16 +615,18 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
             if (rc) { c->pending = false; return rc; }
             BatchArgs a = c->last;
             a.arena = (uint8_t *)c->arena.p; a.arena_bytes = c->arena.bytes;
-            c->prof.arena_regrows++;
+            c->rt.arena_regrows++;
+            // the rerun counts everything again: drop what the aborted run left in the per-wavefront slots (ctl->work went with the control block)
+            if (a.stat_slots) HIPCHECK(hipMemsetAsync(a.stat_slots, 0, (size_t)STAT_SLOTS * STAT_WORDS * 8, c->stream));
             if ((rc = enqueue(c, a))) { c->pending = false; return rc; }
             continue;
         }
         break;
     }
     c->pending = false;
-    c->prof.batches++; c->prof.sentences += c->last.n;
-    for (int k = 0; k < 4; ++k) { c->prof.deferred[k] += c->h_ctl->ovf_count[k]; c->prof.redone[k] += c->h_ctl->late_count[k]; }
-    if (c->last_long && c->last.n) c->prof.long_launches++;
+    c->rt.batches++; c->rt.sentences += c->last.n;
+    for (int k = 0; k < 4; ++k) { c->rt.deferred[k] += c->h_ctl->ovf_count[k]; c->rt.redone[k] += c->h_ctl->late_count[k]; }
+    if (c->last_long && c->last.n) c->rt.long_launches++;
     if (c->last.n && c->plan.n_pools) {
         // The pool kernel reserves est LDS bytes per input byte up front: a reservation that proves
         // too small costs a redo (late_count), one that is too large only idles pages until the
@@ -631,7 +654,7 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
             if (hipEventElapsedTime(&t0f, c->ev_pool[i], c->ev_pool[i + 1]) == hipSuccess &&
                 hipEventElapsedTime(&t01, c->ev_pool[i], c->ev_pool[i + 2]) == hipSuccess &&
                 hipEventElapsedTime(&t12, c->ev_pool[i + 2], c->ev_pool[i + 3]) == hipSuccess) {
-                c->prof.launches++; c->prof.first_ms += t0f; c->prof.tokenize_ms += t01; c->prof.aux_ms += t12;
+                c->prof.launches++; c->rt.first_ms += t0f; c->prof.tokenize_ms += t01; c->prof.aux_ms += t12;
             }
         }
         c->ev_used = 0;
@@ -695,6 +718,13 @@ extern "C" int kgpu_ctx_get_profile(kgpu_ctx *c, kgpu_profile *out, int reset) {
     if (!c || !out) { set_error("kgpu_ctx_get_profile: null argument"); return KGPU_ERR_INVALID_ARG; }
     *out = c->prof;
     if (reset) c->prof = kgpu_profile{};
+    return KGPU_OK;
+}
+
+extern "C" int kgpu_ctx_get_routing(kgpu_ctx *c, kgpu_routing *out, size_t out_size, int reset) {
+    if (!c || !out || out_size < 8) { set_error("kgpu_ctx_get_routing: bad argument"); return KGPU_ERR_INVALID_ARG; }
+    std::memcpy(out, &c->rt, std::min(out_size, sizeof(kgpu_routing)));
+    if (reset) c->rt = kgpu_routing{};
     return KGPU_OK;
 }
 
@@ -817,9 +847,13 @@ static int small_call(kgpu_dict *d, kgpu_ctx *c, const uint8_t *utf8, const uint
 #endif
     }
     c->ctl_dirty = false;  // the publishing wavefront zeroed the device block
-    c->prof.batches++; c->prof.sentences += n;
-    c->prof.deferred[0] += c->h_ctl->ovf_count[0]; c->prof.redone[0] += c->h_ctl->late_count[0];
-    if (c->h_ctl->ovf_count[0] != 0 || c->h_ctl->arena_overflow) return -1;  // a sentence left for the long / HBM-scratch kernels
+    c->rt.batches++; c->rt.sentences += n;
+    c->rt.deferred[0] += c->h_ctl->ovf_count[0]; c->rt.redone[0] += c->h_ctl->late_count[0];
+    c->rt.small_calls++;
+    if (c->h_ctl->ovf_count[0] != 0 || c->h_ctl->arena_overflow || c->h_ctl->small_abort) {  // a sentence left for the long / HBM-scratch kernels, or the rendezvous timed out
+        c->rt.small_fallbacks++;
+        return -1;
+    }
     const uint64_t got = c->h_ctl->n_tokens;
     if (n_tokens) *n_tokens = got;
     const uint64_t *h_toff = (const uint64_t *)(c->sm_host + SM_OFF_TOFF);
@@ -845,7 +879,7 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
     if (offsets[n] - offsets[0] && !utf8) { set_error("kgpu_tokenize_batch: null utf8"); return KGPU_ERR_INVALID_ARG; }
     HIPCHECK(hipSetDevice(d->device));
 
-    if (n >= 1 && n <= SMALL_MAX_N && offsets[n] - offsets[0] <= SMALL_MAX_BYTES && !getenv("KGPU_NO_SMALL_CALLS")) {
+    if (n >= 1 && n <= SMALL_MAX_N && offsets[n] - offsets[0] <= SMALL_MAX_BYTES && !test_hooks().no_small_calls) {
         kgpu_ctx *c = nullptr;
         {
             std::lock_guard<std::mutex> g(d->pool_mu);
@@ -864,8 +898,7 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
     // A large call goes through in chunks (bounded device staging: 24 B per input byte), three of them in
     // flight on pooled contexts: while chunk k's results travel to the host, chunk k+1's kernels run and
     // chunk k+2's input is on its way.  Results are delivered in order, so the tokens stay dense.
-    const uint64_t CHUNK_BYTES = getenv("KGPU_HOST_CHUNK_BYTES") ? strtoull(getenv("KGPU_HOST_CHUNK_BYTES"), nullptr, 10) : (4ull << 20);
-    const uint64_t CHUNK_SENTS = getenv("KGPU_HOST_CHUNK_SENTS") ? strtoull(getenv("KGPU_HOST_CHUNK_SENTS"), nullptr, 10) : 16384;
+    const uint64_t CHUNK_BYTES = test_hooks().chunk_bytes, CHUNK_SENTS = test_hooks().chunk_sents;
     constexpr int DEPTH = 4;
     HostJob jobs[DEPTH];
     int rc = KGPU_OK, njobs = 0;

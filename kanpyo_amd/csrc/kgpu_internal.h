@@ -62,7 +62,7 @@ struct Control {
     unsigned int waves_done;          // single-launch small calls: wavefronts through with their sentence ...
     unsigned int waves_copied;        // ... and through with moving its tokens to the caller's (pinned) buffers
     unsigned int small_flag;          // the call's sequence number, stored LAST into the host copy: the host polls it
-    unsigned int pad1;
+    unsigned int small_abort;         // ... a wavefront gave up waiting at the rendezvous: the host redoes the call on the general path
     unsigned long long dump[8];       // kgpu_lattice_dump: arena offsets of the sentence's two slabs, B, C, N, 1 = valid, dp of EOS
 };
 

@@ -776,7 +776,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                 for (int k = 0; k < 9; ++k) if (lane == 16u + k) v = accP[k];
             }
             if (a.stat_slots) {
-                if (lane < STAT_WORDS) a.stat_slots[(((uint64_t)blockIdx.x * W + wave) & (STAT_SLOTS - 1)) * STAT_WORDS + lane] += v;
+                // one slot per wavefront; a launch of more than STAT_SLOTS wavefronts shares them (atomically)
+                unsigned long long *slot = a.stat_slots + (((uint64_t)blockIdx.x * W + wave) & (STAT_SLOTS - 1)) * STAT_WORDS + lane;
+                if (lane < STAT_WORDS) { if ((uint64_t)gridDim.x * W <= STAT_SLOTS) *slot += v; else atomicAdd(slot, (unsigned long long)v); }
             } else {
                 if (lane < 7) atomicAdd(&a.ctl->work[lane], (unsigned long long)v);
                 if (lane >= 16 && lane < 26) atomicAdd(&a.ctl->phase[lane - 16], (unsigned long long)v);
@@ -793,12 +795,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         const uint64_t my = (uint64_t)blockIdx.x + (uint64_t)gridDim.x * wave;
         __threadfence();  // release: status, token count, staged tokens of my sentence
         if (lane == 0) atomicAdd(&a.ctl->waves_done, 1u);
-        for (uint32_t spin = 0; spin < (1u << 22); ++spin) {  // bounded: every wavefront of this small grid is resident
-            if (bcast32(__hip_atomic_load(&a.ctl->waves_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= total_waves) break;
+        bool met = false;
+        for (uint32_t spin = 0; spin < (1u << 22); ++spin) {  // bounded: every wavefront of this small grid is normally resident
+            if (bcast32(__hip_atomic_load(&a.ctl->waves_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= total_waves) { met = true; break; }
             __builtin_amdgcn_s_sleep(4);
         }
+        // not met (the grid's workgroups were not co-resident for that long: a chip saturated by other streams): the counts read
+        // below may be stale, so the call is flagged and the host redoes it on the general path instead of trusting the result
+        if (!met && lane == 0) atomicExch(&a.ctl->small_abort, 1u);
         __threadfence();  // acquire
-        const bool clean = bcast32(ld_l2(&a.ctl->ovf_count[0])) == 0;  // every sentence was served here (else the host takes the long way)
+        const bool clean = met && bcast32(ld_l2(&a.ctl->ovf_count[0])) == 0 && bcast32(ld_l2(&a.ctl->small_abort)) == 0;  // every sentence was served here (else the host takes the long way)
         uint32_t before = 0, total = 0;
         if (clean) {
             for (uint64_t i0 = 0; i0 < a.n; i0 += 64) {

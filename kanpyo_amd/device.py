@@ -51,12 +51,15 @@ class DeviceContext:
         _lib.check(_lib.lib().kgpu_ctx_set_profiling(self._h, int(mode)))
 
     def profile(self, reset: bool = True) -> dict:
-        p = _lib.Profile()
+        """Event timings (kgpu_profile) and routing counters (kgpu_routing) in one dict."""
+        p, r = _lib.Profile(), _lib.Routing()
         _lib.check(_lib.lib().kgpu_ctx_get_profile(self._h, C.byref(p), int(reset)))
+        _lib.check(_lib.lib().kgpu_ctx_get_routing(self._h, C.byref(r), C.sizeof(r), int(reset)))
         return {"launches": int(p.launches), "tokenize_ms": float(p.tokenize_ms), "aux_ms": float(p.aux_ms),
-                "batches": int(p.batches), "sentences": int(p.sentences), "deferred": [int(x) for x in p.deferred],
-                "redone": [int(x) for x in p.redone], "long_launches": int(p.long_launches),
-                "arena_regrows": int(p.arena_regrows), "first_ms": float(p.first_ms)}
+                "batches": int(r.batches), "sentences": int(r.sentences), "deferred": [int(x) for x in r.deferred],
+                "redone": [int(x) for x in r.redone], "long_launches": int(r.long_launches),
+                "arena_regrows": int(r.arena_regrows), "first_ms": float(r.first_ms),
+                "small_calls": int(r.small_calls), "small_fallbacks": int(r.small_fallbacks)}
 
     def set_ablation(self, stop_after_stage: int):
         """Measurement only: following batches stop after the given stage (STAGE_*), zero tokens; 0 = off."""

@@ -66,6 +66,9 @@ def unk_blob(char_category_to_morph_id: Mapping[int, tuple], unk_morphs) -> byte
 
 
 @dataclass
+NPZ_FORMAT = 2  # save_npz / load_npz: bumped whenever the set or encoding of the arrays changes
+
+
 class Dict:
     index_dict: bytes
     connection_dict: bytes
@@ -115,13 +118,20 @@ class Dict:
             connection_dict=np.frombuffer(self.connection_dict, dtype=np.uint8),
             morph_dict=np.frombuffer(self.morph_dict, dtype=np.uint8),
             unk_dict=np.frombuffer(self.unk_dict, dtype=np.uint8), char_category=self.char_category,
-            invoke_list=self.invoke_list, group_list=self.group_list,
+            invoke_list=self.invoke_list, group_list=self.group_list, format=np.int64(NPZ_FORMAT),
             char_class=np.frombuffer(json.dumps(list(self.char_class), ensure_ascii=False).encode("utf-8"), dtype=np.uint8),
         )
 
     @classmethod
     def load_npz(cls, path) -> "Dict":
-        z = np.load(path, allow_pickle=False)  # plain arrays only: a dictionary cache must not be able to run code
-        return cls(z["index_dict"].tobytes(), z["connection_dict"].tobytes(), z["morph_dict"].tobytes(),
-                   z["unk_dict"].tobytes(), z["char_category"], z["invoke_list"], z["group_list"],
-                   [str(x) for x in json.loads(z["char_class"].tobytes().decode("utf-8"))])
+        """Raises ValueError("stale dictionary cache ...") for a file written by another revision of save_npz (e.g. the
+        pickled char_class of round 1): callers rebuild instead of failing inside numpy / json."""
+        try:
+            z = np.load(path, allow_pickle=False)  # plain arrays only: a dictionary cache must not be able to run code
+            if "format" not in z.files or int(z["format"]) != NPZ_FORMAT:
+                raise ValueError("format key missing or different")
+            return cls(z["index_dict"].tobytes(), z["connection_dict"].tobytes(), z["morph_dict"].tobytes(),
+                       z["unk_dict"].tobytes(), z["char_category"], z["invoke_list"], z["group_list"],
+                       [str(x) for x in json.loads(z["char_class"].tobytes().decode("utf-8"))])
+        except (ValueError, KeyError, UnicodeDecodeError, OSError) as e:
+            raise ValueError(f"stale dictionary cache {path}: {e}; delete it and rebuild") from e

@@ -261,3 +261,45 @@ def make_corpus(sd: SynthDict, n: int, seed: int, kind: str = "cfg2") -> list:
             have += len(seg)
         out.append("".join(parts)[:L])
     return out
+
+
+def dense_case(rng):
+    """A tiny alphabet with many duplicate records per surface (rng: random.Random): buckets of 1..200 predecessors, up to
+    ~150 targets per position -- every shape of the sweep step (P <= 8, <= 16, <= 32, beyond; T beyond one pass; T > 127)
+    and the parked-match overflow (more than 8 prefixes at a position), which the IPADIC-shaped corpora never reach.
+    -> (Dict, sentences)"""
+    nr = np.random.default_rng(rng.randrange(1 << 30))
+    alpha = "あいうえおか"[: rng.choice([2, 3, 6])]
+    words = set()
+    for _ in range(rng.choice([20, 80, 300])):
+        words.add("".join(nr.choice(list(alpha), size=int(nr.integers(1, rng.choice([3, 5, 12]))))))
+    recs = []
+    for w in sorted(words, key=lambda x: x.encode()):
+        recs += [w] * int(nr.choice([1, 1, 2, 3, 9, rng.choice([17, 33, 70])]))
+    nctx = rng.choice([1, 3, 40])
+    morphs = np.stack([nr.integers(0, nctx, len(recs)), nr.integers(0, nctx, len(recs)), nr.integers(-2000, 9000, len(recs))], axis=1)
+    cat = np.zeros(65536, dtype=np.uint8)
+    for ch in alpha:
+        cat[ord(ch)] = 1
+    unk = {0: (1, 1), 1: (2, rng.choice([1, 3]))}
+    um = [(0, 0, 5000)] + [(int(nr.integers(0, nctx)), int(nr.integers(0, nctx)), int(nr.integers(1000, 9000))) for _ in range(unk[1][1])]
+    d = Dict.from_parts(recs, morphs, nctx, nctx, nr.integers(-3000, 3000, nctx * nctx), ["DEFAULT", "H"], cat,
+                        np.array([0, rng.choice([0, 1])], dtype=np.uint8), np.array([1, rng.choice([0, 1])], dtype=np.uint8), unk, um)
+    sents = ["".join(nr.choice(list(alpha + "xy"), size=int(nr.integers(1, rng.choice([8, 40, 120])))))
+             for _ in range(rng.choice([1, 7, 128, 129, 700, 3000]))]
+    return d, sents
+
+
+EDGE_SENTENCES = ["", "あ", "ア" * 700, "a" * 300, "𠮷野家で𩸽", "すもももももももものうち", "　　", "1234567890" * 40, "。" * 65]
+
+
+def mixed_case(sd: SynthDict, rng, sizes=(1, 5, 50, 120, 700, 4096, 9000)):
+    """One shuffled batch over the IPADIC-shaped generator: cfg 2 text, often cfg 3, sometimes cfg 5 documents, edge sentences."""
+    mix = make_corpus(sd, rng.choice(list(sizes)), rng.randrange(1 << 30), "cfg2")
+    if rng.random() < 0.7:
+        mix += make_corpus(sd, rng.choice([3, 100, 600]), rng.randrange(1 << 30), "cfg3")
+    if rng.random() < 0.3:
+        mix += make_corpus(sd, rng.choice([1, 4]), rng.randrange(1 << 30), "cfg5")
+    mix += rng.sample(EDGE_SENTENCES, rng.randrange(len(EDGE_SENTENCES)))
+    rng.shuffle(mix)
+    return mix

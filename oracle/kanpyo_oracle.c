@@ -539,6 +539,65 @@ int korc_tokenize_batch(const korc_dict *d, const uint8_t *utf8, const uint64_t 
     return err;
 }
 
+/* All-core timing form: nothing but tokenization inside the threads.  Sentence i owns the token slots
+ * out[offsets[i] - offsets[0] + i ..] (tokens <= chars + 1 <= bytes + 1, so B_i + 1 slots always suffice: disjoint
+ * ranges known up front, no per-thread buffers, no merge copy, no allocator); tok_count[i] = its token count.
+ * Threads claim runs of 64 sentences from one counter and go over the corpus `reps` times (thread start-up is paid
+ * once per call).  The reference hands every caller its own Vec<Token> (src/tokenizer.rs:16-45): per-sentence
+ * slots are the closest flat equivalent. */
+typedef struct {
+    const korc_dict *d; const uint8_t *utf8; const uint64_t *off; uint64_t n;
+    korc_token *out; uint32_t *tok_count; int reps;
+    volatile uint64_t *next; korc_counters ctr; int err;
+} slot_job_t;
+
+static void *slot_job_run(void *arg) {
+    slot_job_t *j = (slot_job_t *)arg;
+    ws_t w; memset(&w, 0, sizeof w);
+    const uint64_t total = j->n * (uint64_t)j->reps, RUN = 64;
+    for (;;) {
+        uint64_t g = __atomic_fetch_add(j->next, RUN, __ATOMIC_RELAXED);
+        if (g >= total) break;
+        uint64_t ge = g + RUN < total ? g + RUN : total;
+        for (; g < ge; g++) {
+            uint64_t i = g % j->n;
+            size_t nb = (size_t)(j->off[i + 1] - j->off[i]);
+            korc_token *dst = j->out + (j->off[i] - j->off[0]) + i;
+            int64_t k = tokenize_ws(j->d, j->utf8 + j->off[i], nb, dst, nb + 1, &j->ctr, &w);
+            if (k < 0) { if (k != KORC_INVALID_UTF8 || !j->err) j->err = (int)k; k = 0; }
+            j->tok_count[i] = (uint32_t)k;
+        }
+    }
+    ws_free(&w);
+    return NULL;
+}
+
+int korc_tokenize_slots(const korc_dict *d, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
+                        korc_token *out, uint32_t *tok_count, int nthreads, int reps, korc_counters *ctr) {
+    if (nthreads < 1) nthreads = 1;
+    if (reps < 1) reps = 1;
+    slot_job_t *jobs = (slot_job_t *)calloc((size_t)nthreads, sizeof(slot_job_t));
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    volatile uint64_t next = 0;
+    int err = 0;
+    for (int t = 0; t < nthreads; t++) {
+        slot_job_t *j = &jobs[t];
+        j->d = d; j->utf8 = utf8; j->off = offsets; j->n = n; j->out = out; j->tok_count = tok_count; j->reps = reps; j->next = &next;
+        if (n == 0) continue;
+        if (nthreads == 1) slot_job_run(j); else pthread_create(&th[t], NULL, slot_job_run, j);
+    }
+    for (int t = 0; t < nthreads; t++) {
+        if (nthreads > 1 && n) pthread_join(th[t], NULL);
+        if (jobs[t].err && jobs[t].err != KORC_INVALID_UTF8) err = jobs[t].err;
+        if (ctr) {
+            ctr->sentences += jobs[t].ctr.sentences; ctr->B += jobs[t].ctr.B; ctr->C += jobs[t].ctr.C;
+            ctr->T += jobs[t].ctr.T; ctr->N += jobs[t].ctr.N; ctr->E += jobs[t].ctr.E; ctr->K += jobs[t].ctr.K;
+        }
+    }
+    free(jobs); free(th);
+    return err;
+}
+
 /* ----------------------------------------------------- double-array builder */
 
 #define INIT_BUFFER_SIZE (50 * 1024) /* trie/da.rs:6 */

@@ -85,6 +85,13 @@ int korc_tokenize_batch(const korc_dict *d, const uint8_t *utf8, const uint64_t 
                         uint64_t n, korc_token *out, uint64_t cap, uint64_t *tok_offsets,
                         int nthreads, korc_counters *ctr);
 
+/* All-core timing form (bench.py's cpu_baseline.all_cores): sentence i writes its tokens to
+ * out[offsets[i] - offsets[0] + i ..] (B_i + 1 slots, always enough) and its count to tok_count[i]; threads
+ * claim runs of 64 sentences from one counter and go over the corpus `reps` times.  No allocation, no
+ * merge copy inside the call.  `out` needs (offsets[n] - offsets[0]) + n slots. */
+int korc_tokenize_slots(const korc_dict *d, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
+                        korc_token *out, uint32_t *tok_count, int nthreads, int reps, korc_counters *ctr);
+
 /* IndexTable::search_common_prefix_of (kanpyo-dict/src/index.rs:40-53) for the
  * known-answer tests: writes up to cap (id, byte_len) pairs, returns the count
  * (0 == None). */

@@ -62,6 +62,8 @@ def lib():
         L.korc_tokenize_batch.argtypes = [
             C.c_void_p, u8p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p,
         ]
+        L.korc_tokenize_slots.restype = C.c_int
+        L.korc_tokenize_slots.argtypes = [C.c_void_p, u8p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.korc_common_prefix.restype = C.c_int64
         L.korc_common_prefix.argtypes = [C.c_void_p, u8p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         L.korc_da_search.restype = C.c_int64
@@ -184,3 +186,22 @@ class OracleTokenizer:
             raise RuntimeError(f"oracle batch failed rc={rc}: " + lib().korc_last_error().decode())
         toks = out_t[: int(toff[n])]
         return OracleResult(toks.copy() if copy else toks, toff[: n + 1].copy() if copy and out is not None else toff[: n + 1], ctr.as_dict())
+
+    def tokenize_slots(self, utf8: np.ndarray, offsets: np.ndarray, nthreads: int, reps: int = 1, out=None):
+        """All-core timing form (korc_tokenize_slots): sentence i writes to out[offsets[i] - offsets[0] + i ..], its count to
+        tok_count[i]; no allocation or merge copy inside the call.  -> (slots, tok_count, counters)."""
+        utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        cap = int(offsets[-1] - offsets[0]) + n
+        if out is None:
+            out = (np.zeros(cap, dtype=TOKEN_DTYPE), np.zeros(max(n, 1), dtype=np.uint32))
+        slots, cnt = out
+        if slots.dtype != TOKEN_DTYPE or cnt.dtype != np.uint32 or slots.size < cap or cnt.size < n:
+            raise ValueError("out=(slots[TOKEN_DTYPE, >= bytes + n], tok_count[uint32, >= n])")
+        ctr = Counters()
+        rc = lib().korc_tokenize_slots(self._h, utf8.ctypes.data if utf8.size else None, offsets.ctypes.data, n, slots.ctypes.data,
+                                       cnt.ctypes.data, int(nthreads), int(reps), C.byref(ctr))
+        if rc != 0:
+            raise RuntimeError(f"oracle slots batch failed rc={rc}: " + lib().korc_last_error().decode())
+        return slots, cnt[:n], ctr.as_dict()

@@ -10,6 +10,7 @@ try:  # torch ships its own libamdhip64: load it BEFORE libkanpyo_gpu.so so the 
 except Exception:  # pragma: no cover
     torch = None
 
+os.environ.setdefault("KGPU_TEST_HOOKS_REREAD", "1")  # the runtime's test-only hooks (KGPU_NO_SMALL_CALLS, KGPU_HOST_CHUNK_*) are re-read per call
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -331,8 +331,21 @@ def test_built_and_reloaded_dictionary(libs, tmp_path):
     tok, orc = Tokenizer(back.dict), oracle.OracleTokenizer.from_dict(df.dict)
     sents = ["東京都に住む", "東京に住む東京都", "トウキョウ 123 に", "", "a,b都", "住", "にににに"]
     assert_same(tok, orc, sents, nthreads=1)
-    lines = format_tokens(tok.tokenize("東京都に住む"), back)
-    assert lines.splitlines()[-1] == "EOS\t" and "トウキョウト" in lines
+    # 8(f) rank 3: the CLI's lines (src/bin/kanpyo.rs:174-197) from the GPU's tokens == the same lines from the oracle's tokens
+    from kanpyo_amd.token import Token, TokenClass
+
+    for text in sents:
+        rec, _ = orc.tokenize(text)
+        raw = text.encode("utf-8")
+        from_oracle = [Token(int(r["id"]), TokenClass(int(r["cls"])), int(r["position"]), int(r["start"]), int(r["end"]),
+                             "EOS" if int(r["cls"]) == 0 else raw[int(r["position"]) : int(r["position"]) + int(r["byte_len"])].decode("utf-8"))
+                       for r in rec]
+        got = tok.tokenize(text)
+        assert got == from_oracle, text
+        assert format_tokens(got, back) == format_tokens(from_oracle, df), text
+    lines = format_tokens(tok.tokenize("東京都に住む"), back).splitlines()
+    assert lines[-1] == "EOS\t" and len(lines) >= 2 and all(l.count("\t") == 1 for l in lines)
+    assert any(l.split("\t")[1].endswith("トウキョウト") or "トウキョウト" in l.split("\t")[1] for l in lines[:-1])
 
 
 def test_host_entry_point_chunks_and_capacity(small, monkeypatch):

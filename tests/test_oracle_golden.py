@@ -154,3 +154,25 @@ def test_invalid_utf8_is_rejected():
     for bad in (b"\xff", b"\xe3\x81", b"\x80", b"\xc0\xaf", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", b"a\xe3\x81\x82\xe3"):
         with pytest.raises(UnicodeDecodeError):
             o.tokenize(bad)
+
+
+def test_slots_form_equals_dense_form(oracle_mod):
+    """korc_tokenize_slots (the all-core timing form of bench.py's cpu_baseline: per-sentence slots, claimed runs,
+    several passes) yields the same records as the dense single-thread batch."""
+    from kanpyo_amd import synth
+    from kanpyo_amd.tokenizer import pack_sentences
+
+    sd = synth.build_dict(6000, seed=3)
+    orc = oracle_mod.OracleTokenizer.from_dict(sd.dict)
+    sents = synth.make_corpus(sd, 700, 5, "cfg2") + ["", "あ"] + synth.make_corpus(sd, 50, 6, "cfg3")
+    utf8, offs = pack_sentences(sents)
+    exp = orc.tokenize_batch(utf8, offs, 1)
+    for nthreads, reps in ((1, 1), (4, 1), (7, 3)):
+        slots, cnt, ctr = orc.tokenize_slots(utf8, offs, nthreads, reps)
+        assert np.array_equal(cnt.astype(np.uint64), exp.offsets[1:] - exp.offsets[:-1])
+        for i in (0, 1, 350, 699, 700, 701, len(sents) - 1):
+            lo = int(offs[i]) + i
+            assert np.array_equal(slots[lo : lo + int(cnt[i])], exp.tokens[int(exp.offsets[i]) : int(exp.offsets[i + 1])])
+        dense = np.concatenate([slots[int(offs[i]) + i : int(offs[i]) + i + int(cnt[i])] for i in range(len(sents))])
+        assert np.array_equal(dense, exp.tokens)
+        assert ctr["sentences"] == reps * len(sents) and ctr["K"] == reps * exp.counters["K"]

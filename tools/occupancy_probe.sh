@@ -1,0 +1,16 @@
+#!/bin/bash
+# more wavefronts per CU when LDS is not the limit?  (sentences cut to 65 % of their length) -> gpurun_out/occupancy_probe.txt
+mkdir -p gpurun_out
+OUT=gpurun_out/occupancy_probe.txt; : > $OUT
+run() { timeout 300 python tools/resident_probe.py 4096 8 2>/dev/null | tail -1 | tee -a $OUT; }
+for len in 0.65 0.5 1.0; do
+  export PROBE_LEN=$len
+  KGPU_LIB=$PWD/kanpyo_amd/libkanpyo_gpu.so KGPU_POOL=40:4:48 run
+  KGPU_LIB=$PWD/kanpyo_amd/libkanpyo_gpu.so KGPU_POOL=20:2:48 run
+  KGPU_LIB=$PWD/kanpyo_amd/libkanpyo_gpu_w5.so KGPU_POOL=32:4:48 run
+  KGPU_LIB=$PWD/kanpyo_amd/libkanpyo_gpu_w5.so KGPU_POOL=40:5:48 run
+  KGPU_LIB=$PWD/kanpyo_amd/libkanpyo_gpu_w5.so KGPU_POOL=40:4:48 run
+  KGPU_LIB=$PWD/kanpyo_amd/libkanpyo_gpu_w6.so KGPU_POOL=26:4:48 run
+  KGPU_LIB=$PWD/kanpyo_amd/libkanpyo_gpu_w6.so KGPU_POOL=40:6:48 run
+  KGPU_LIB=$PWD/kanpyo_amd/libkanpyo_gpu_w6.so KGPU_POOL=20:3:64 run
+done
