@@ -65,10 +65,10 @@ def unk_blob(char_category_to_morph_id: Mapping[int, tuple], unk_morphs) -> byte
     return b"".join(out)
 
 
-@dataclass
 NPZ_FORMAT = 2  # save_npz / load_npz: bumped whenever the set or encoding of the arrays changes
 
 
+@dataclass
 class Dict:
     index_dict: bytes
     connection_dict: bytes

@@ -127,3 +127,17 @@ def test_no_cpu_fallback_without_device():
     with pytest.raises(_lib.KgpuError) as e:
         Tokenizer(Dict.from_parts(**fixture_dict_parts()))
     assert e.value.code == _lib.KGPU_ERR_NO_DEVICE
+
+
+def test_npz_cache_round_trip_and_stale_format(tmp_path, fixture_dict):
+    """Dict.save_npz / load_npz: plain arrays only; a cache written by another revision is reported as stale (rebuild),
+    not as an opaque numpy / json error."""
+    from kanpyo_amd.dict import Dict
+
+    p = tmp_path / "d.npz"
+    fixture_dict.save_npz(p)
+    back = Dict.load_npz(p)
+    assert back.index_dict == fixture_dict.index_dict and back.char_class == fixture_dict.char_class
+    np.savez_compressed(tmp_path / "old.npz", index_dict=np.zeros(4, dtype=np.uint8), char_class=np.array(["DEFAULT"]))
+    with pytest.raises(ValueError, match="stale dictionary cache"):
+        Dict.load_npz(tmp_path / "old.npz")
