@@ -347,7 +347,9 @@ def main():
     ap.add_argument("--queue", type=int, default=8, help="batches in flight (one context each)")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams the contexts share round-robin (one hardware queue each with "
                     "GPU_MAX_HW_QUEUES=8; a stream that has to share a queue unbalances them)")
-    ap.add_argument("--corpora", type=int, default=4, help="N>1: distinct cfg 4 corpora (seeds 100..) generated and cycled; 100 = all of cfg 4")
+    ap.add_argument("--corpora", type=int, default=0, help="N>1: distinct cfg 4 corpora (seeds 100..) generated and cycled; 0 = one per step, "
+                    "at most 100 (100 = all of cfg 4: 10 M sentences)")
+    ap.add_argument("--no-one-gpu-leg", action="store_true", help="N>1: skip the untimed-region leg in which rank 0 runs the same steps alone (speedup_vs_1gpu)")
     ap.add_argument("--prewarm-seconds", type=float, default=1.5, help="untimed: the same steps for this long before the W warmup steps "
                     "(the first process on a freshly started box measures ~4 %% low for its first second: clocks / page tables still settling)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="lower bound of CPU-baseline work")
@@ -399,6 +401,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from kanpyo_amd import Tokenizer
+    from kanpyo_amd._lib import kernel_source_hash
     from kanpyo_amd.device import PROFILE_EVENTS, PROFILE_OFF, PROFILE_SAMPLED, PROFILE_WORK, STAGE_ALL, STAGE_LATTICE, STAGE_VITERBI, DeviceContext
     from kanpyo_amd.dist import ChunkedGather, reassemble
     from kanpyo_amd.tokenizer import pack_sentences
@@ -408,7 +411,7 @@ def main():
         corpora = [synth.make_corpus(sd, N_SENT, seed=1, kind="cfg2")]
         label = "BASELINE configs[1] (cfg 2): 100k synthetic ~40-char sentences (seed 1)"
     else:
-        ncorp = max(1, min(args.corpora, 100, max(K, W, 1)))
+        ncorp = max(1, min(args.corpora if args.corpora > 0 else 100, 100, max(K, 1)))  # distinct seeds for every timed step (SURVEY 8d cfg 4)
         corpora = [synth.make_corpus(sd, N_SENT, seed=100 + k, kind="cfg2") for k in range(ncorp)]
         label = (f"BASELINE configs[3] (cfg 4): 100k-sentence corpora of seeds 100..{99 + ncorp} cycled, sentence i -> GPU i mod {world}, "
                  "token records gathered to rank 0 over xGMI")
@@ -472,6 +475,24 @@ def main():
             del warm
         torch.cuda.synchronize()
 
+    # ---- N > 1: the same steps on ONE GPU (rank 0 alone, the others wait): the denominator of speedup_vs_1gpu
+    one_gpu = None
+    if world > 1 and not args.no_one_gpu_leg:
+        if rank == 0:
+            eng1 = GpuEngine(tok, dev, Workload(corpora, 0, 1), queue=args.queue, streams=args.streams, ring=1)
+            run_job(eng1, max(2, min(W, 5)))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_job(eng1, K)
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            n1 = sum(len(corpora[s_ % len(corpora)]) for s_ in range(K))
+            one_gpu = {"value": n1 / dt1, "unit": "sentences/s", "ms_per_step": dt1 / K * 1e3,
+                       "what": f"the same {K} steps (same corpora, unsharded) on rank 0's GPU alone, no gather, before the timed region"}
+            eng1.close()
+            del eng1
+        dist.barrier()
+
     # ---- warmup (also brings up the RCCL channels of the gather)
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.prewarm_seconds:  # untimed, every rank the same number of rounds
@@ -499,13 +520,20 @@ def main():
     t0 = time.perf_counter()
     job(K)
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0  # this rank's own steps (and, on the root, the gathers it waited for)
     if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([float(sum(wl.sentences(s_) for s_ in range(K))), local_elapsed], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "sentences": int(x[0].item()), "seconds": float(x[1].item()),
+                     "sentences_per_s": float(x[0].item()) / max(float(x[1].item()), 1e-9)} for r, x in enumerate(allr)]
 
     if extras_dir:
         open(os.path.join(extras_dir, "go"), "w").close()  # the corpus generator may have its core now
@@ -561,6 +589,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic.get("hbm_bytes_per_launch") if traffic else None,
+            "traffic_stale": (traffic.get("kernel_src_sha16") != kernel_source_hash()) if traffic else None,  # counters measured on other kernel sources than these
             "traffic_source": (traffic.get("source", "profiles/pmc_traffic.json") + " -- separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, "
                                "per launch), NOT measured inside this run") if traffic else None,
             "kernel": "k_tokenize_pool (fused lattice build + Viterbi + backtrace, LDS page pool)",
@@ -577,10 +606,19 @@ def main():
             "achieved_at_job_rate": job_rate_bytes, "frac_at_job_rate": job_rate_bytes / HBM_PEAK_GBS,
         },
     }
+    result["sentences_total"] = sentences
     if multi:
         result["gather"] = {"chunks": gathered["chunks"], "tokens": gathered["tokens"], "sentences": gathered["sentences"],
                             "complete": gathered["sentences"] == sentences, "reassembled_step_equals_one_gpu": gather_check,
-                            "chunk_steps": cs}
+                            "chunk_steps": cs, "record_bytes": 24,
+                            "root_ingest_GB_per_s": gathered["tokens"] * 24 * (world - 1) / max(world, 1) / elapsed / 1e9,
+                            "root_ingest_what": "24-byte token records arriving at rank 0 from the other ranks over xGMI (its own share, 1/N of the "
+                                                "stream, is a local copy), averaged over the timed region"}
+        result["per_rank"] = per_rank
+        result["corpora"] = {"distinct": len(corpora), "seeds": f"100..{99 + len(corpora)}", "sentences_each": N_SENT}
+        if one_gpu is not None:
+            result["one_gpu_leg"] = one_gpu
+            result["speedup_vs_1gpu"] = result["value"] / one_gpu["value"]
         assert gathered["sentences"] == sentences, (gathered, sentences)
         assert gather_check, "gathered + reassembled token stream differs from the single-GPU stream"
 
@@ -635,6 +673,7 @@ def main():
                 rate = result["value"]
                 result["roofline"]["instruction"] = {
                     "valu_per_sentence": valu, "salu_per_sentence": salu, "source": ins.get("source", "profiles/pmc_instructions.json"),
+                    "stale": ins.get("kernel_src_sha16") != kernel_source_hash(),
                     "valu_issue_frac": valu * 2 * rate / (CHIP_SIMDS * CHIP_CLOCK_HZ),  # a wave64 VALU op occupies its SIMD-32 for 2 cycles
                     "what": "wave-VALU-instructions per sentence x 2 cycles x sentences/s / (1024 SIMDs x 2.4 GHz)"}
             except Exception as e:

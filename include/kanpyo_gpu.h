@@ -60,6 +60,21 @@ typedef struct kgpu_token {
     uint32_t byte_len; /* surface length in bytes                         */
 } kgpu_token;
 
+/* The same Token in 8 bytes, for moving results over PCIe / xGMI (a third of the volume): consecutive tokens of a
+ * sentence tile it (a path through the lattice: each word starts where the previous one ends, src/lattice.rs:144-153),
+ * so position and start are running sums over the sentence and need not travel:
+ *   packed = cls | chars << 2 | byte_len << 14     (chars = end - start, 12 bits; byte_len 18 bits; EOS: chars 3, byte_len 0)
+ * plus, per sentence, the first token's (position, start) -- not always (0, 0): when the best chain starts at an
+ * unreachable node that node is dropped (src/lattice.rs:144-153).  kgpu_expand_tokens restores
+ * the 24-byte records exactly. */
+typedef struct kgpu_token8 {
+    int32_t id;
+    uint32_t packed;
+} kgpu_token8;
+#define KGPU_T8_CLS(p) ((p) & 3u)
+#define KGPU_T8_CHARS(p) (((p) >> 2) & 0xFFFu)
+#define KGPU_T8_BYTES(p) ((p) >> 14)
+
 /* The dictionary tables exactly as the reference serialises them
  * (DictReadWrite::write_dict, kanpyo-dict/src/dict.rs:13-18): the hot-path
  * table internals are private in the reference (trie/da.rs:14-20,
@@ -192,6 +207,17 @@ int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_o
                          uint64_t total_bytes, kgpu_token *d_tokens, uint64_t token_capacity,
                          uint64_t *d_tok_offsets, uint8_t *d_status);
 int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens);
+/* Same batch, results as 8-byte records: d_tokens8 (token_capacity entries), d_first (2 n entries: position and start of
+ * each sentence's first token, 0xFFFFFFFF twice for a sentence without tokens), d_tok_offsets, d_status.  The output
+ * pointers may be device pointers of pinned, device-mapped host memory: the compaction kernel's stores are then the
+ * device-to-host transfer.  A token that does not fit the packing (more than 4095 chars or 262143 bytes: no real
+ * dictionary) makes kgpu_ctx_sync return KGPU_ERR_CAPACITY with *n_tokens = 0; use the 24-byte form for such a batch. */
+int kgpu_tokenize_device_compact(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n,
+                                 uint64_t total_bytes, kgpu_token8 *d_tokens8, uint64_t token_capacity,
+                                 uint32_t *d_first, uint64_t *d_tok_offsets, uint8_t *d_status);
+/* Host side: 8-byte records of n sentences -> the 24-byte records (running sums per sentence).  tok_offsets: n + 1
+ * entries delimiting the sentences inside `in`; `out` receives tok_offsets[n] - tok_offsets[0] records. */
+void kgpu_expand_tokens(const kgpu_token8 *in, const uint64_t *tok_offsets, const uint32_t *first, uint64_t n, kgpu_token *out);
 int kgpu_ctx_set_profiling(kgpu_ctx *c, int mode /* KGPU_PROFILE_* bit mask */);
 int kgpu_ctx_get_profile(kgpu_ctx *c, kgpu_profile *out, int reset);
 /* Copies min(out_size, sizeof(kgpu_routing)) bytes: a caller built against an older, shorter kgpu_routing stays valid. */

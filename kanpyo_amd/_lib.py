@@ -22,10 +22,22 @@ KGPU_SENT_TRUNCATED = 3
 # every symbol include/kanpyo_gpu.h declares
 SYMBOLS = [
     "kgpu_last_error", "kgpu_device_count", "kgpu_dict_create", "kgpu_dict_destroy", "kgpu_dict_get_info",
-    "kgpu_tokenize_batch", "kgpu_ctx_create", "kgpu_ctx_destroy", "kgpu_tokenize_device", "kgpu_ctx_sync",
+    "kgpu_tokenize_batch", "kgpu_ctx_create", "kgpu_ctx_destroy", "kgpu_tokenize_device", "kgpu_tokenize_device_compact", "kgpu_expand_tokens", "kgpu_ctx_sync",
     "kgpu_ctx_set_profiling", "kgpu_ctx_set_ablation", "kgpu_ctx_get_profile", "kgpu_ctx_get_routing", "kgpu_ctx_get_work", "kgpu_ctx_get_phase_cycles", "kgpu_index_build", "kgpu_free",
     "kgpu_host_alloc", "kgpu_host_free", "kgpu_lattice_dump", "kgpu_lattice_free",
 ]
+
+
+def kernel_source_hash() -> str:
+    """sha256[:16] over the HIP sources of the library (kanpyo_amd/csrc: kernels, device helpers, shared structs).  Profile-derived
+    files under profiles/ record it, bench.py compares: a counter file measured on other kernel code says so (`stale`)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("kgpu_pool.hip", "kgpu_kernels.hip", "kgpu_device.h", "kgpu_internal.h"):
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 class KgpuError(RuntimeError):
@@ -100,6 +112,9 @@ def lib():
         L.kgpu_ctx_destroy.argtypes = [vp]
         L.kgpu_ctx_destroy.restype = None
         L.kgpu_tokenize_device.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, vp]
+        L.kgpu_tokenize_device_compact.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, vp, vp]
+        L.kgpu_expand_tokens.argtypes = [vp, vp, vp, C.c_uint64, vp]
+        L.kgpu_expand_tokens.restype = None
         L.kgpu_ctx_sync.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.kgpu_ctx_set_profiling.argtypes = [vp, C.c_int]
         L.kgpu_ctx_set_ablation.argtypes = [vp, C.c_int]

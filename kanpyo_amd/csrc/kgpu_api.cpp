@@ -10,10 +10,15 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <vector>
 
@@ -70,12 +75,28 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
+// Pinned host memory, optionally device-mapped (the device then reads / writes it over PCIe by itself).
+struct PinBuf {
+    void *h = nullptr, *d = nullptr; size_t bytes = 0;
+    int ensure(size_t need, bool mapped) {
+        if (need <= bytes) return KGPU_OK;
+        release();
+        size_t want = need + need / 4 + 4096;
+        if (hipHostMalloc(&h, want, mapped ? hipHostMallocMapped : hipHostMallocDefault) != hipSuccess) { h = nullptr; set_error("pinned allocation of %zu bytes failed", want); return KGPU_ERR_HIP; }
+        d = h;
+        if (mapped && hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); h = d = nullptr; set_error("hipHostGetDevicePointer failed"); return KGPU_ERR_HIP; }
+        bytes = want;
+        return KGPU_OK;
+    }
+    void release() { if (h) (void)hipHostFree(h); h = d = nullptr; bytes = 0; }
+};
+
 }  // namespace
 
 // Test-only environment hooks.  getenv is not thread-safe against setenv, and kgpu_tokenize_batch may be called from many
 // threads: the hooks are read under a mutex, ONCE per process -- unless KGPU_TEST_HOOKS_REREAD is set (tests/conftest.py sets
 // it: the tests flip the hooks between calls).
-struct TestHooks { bool no_small_calls = false; uint64_t chunk_bytes = 4ull << 20, chunk_sents = 16384; };
+struct TestHooks { bool no_small_calls = false, legacy_host_path = false; uint64_t chunk_bytes = 4ull << 20, chunk_sents = 16384; };
 static bool env_flag_now(const char *name) { const char *e = getenv(name); return e && *e && *e != '0'; }
 static TestHooks test_hooks() {
     static std::mutex mu;
@@ -86,6 +107,7 @@ static TestHooks test_hooks() {
         init = true;
         cur = TestHooks{};
         cur.no_small_calls = env_flag_now("KGPU_NO_SMALL_CALLS");
+        cur.legacy_host_path = env_flag_now("KGPU_HOST_LEGACY");
         if (const char *e = getenv("KGPU_HOST_CHUNK_BYTES")) cur.chunk_bytes = strtoull(e, nullptr, 10);
         if (const char *e = getenv("KGPU_HOST_CHUNK_SENTS")) cur.chunk_sents = strtoull(e, nullptr, 10);
     }
@@ -145,6 +167,8 @@ struct kgpu_ctx {
     DevBuf arena, stage, tok_count;
     // host-buffer path staging
     DevBuf in_utf8, in_off, out_tok, out_off, out_status;
+    PinBuf pin_in, pin_out;       // large host calls: input staging (offsets | bytes), mapped result block (records | first | token offsets | status)
+    DevBuf in_block;              // ... and the device copy of the input block
     // single-launch small calls: one pinned, device-mapped block (input | offsets | tokens | token offsets | status)
     uint8_t *sm_host = nullptr, *sm_dev = nullptr;
     uint32_t sm_seq = 0;
@@ -511,6 +535,7 @@ extern "C" void kgpu_ctx_destroy(kgpu_ctx *c) {
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     c->arena.release(); c->ovf.release(); c->stat_slots.release(); c->stage.release(); c->tok_count.release();
     c->in_utf8.release(); c->in_off.release(); c->out_tok.release(); c->out_off.release(); c->out_status.release();
+    c->pin_in.release(); c->pin_out.release(); c->in_block.release();
     if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->sm_host) (void)hipHostFree(c->sm_host);
@@ -560,16 +585,16 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
     return KGPU_OK;
 }
 
-extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n,
-                                    uint64_t total_bytes, kgpu_token *d_tokens, uint64_t token_capacity,
-                                    uint64_t *d_tok_offsets, uint8_t *d_status) {
+static int tokenize_device_impl(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n, uint64_t total_bytes,
+                                kgpu_token *d_tokens, kgpu_token8 *d_tokens8, uint32_t *d_first, uint8_t *status8, uint64_t token_capacity,
+                                uint64_t *d_tok_offsets, uint8_t *d_status, const char *who) {
     if (!c || !d_offsets || !d_tok_offsets || (n && !d_status) || (total_bytes && !d_utf8) ||
-        (token_capacity && !d_tokens)) {
-        set_error("kgpu_tokenize_device: null argument");
+        (token_capacity && !d_tokens && !d_tokens8) || (d_tokens8 && n && !d_first)) {
+        set_error("%s: null argument", who);
         return KGPU_ERR_INVALID_ARG;
     }
-    if (n >= (1ull << 32) - 1) { set_error("kgpu_tokenize_device: more than 2^32-2 sentences in one batch; split it"); return KGPU_ERR_INVALID_ARG; }
-    if (total_bytes >= (1ull << 32)) { set_error("kgpu_tokenize_device: batch larger than 4 GiB; split it"); return KGPU_ERR_INVALID_ARG; }
+    if (n >= (1ull << 32) - 1) { set_error("%s: more than 2^32-2 sentences in one batch; split it", who); return KGPU_ERR_INVALID_ARG; }
+    if (total_bytes >= (1ull << 32)) { set_error("%s: batch larger than 4 GiB; split it", who); return KGPU_ERR_INVALID_ARG; }
     HIPCHECK(hipSetDevice(c->dict->device));
     int rc;
     if (c->pending && (rc = kgpu_ctx_sync(c, nullptr)) != KGPU_OK && rc != KGPU_ERR_CAPACITY) return rc;
@@ -583,6 +608,7 @@ extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const ui
     a.stage = (kgpu_token *)c->stage.p;
     a.tok_count = (uint32_t *)c->tok_count.p;
     a.status = d_status; a.out = d_tokens; a.out_cap = token_capacity; a.tok_offsets = d_tok_offsets;
+    a.out8 = d_tokens8; a.first8 = d_first; a.status8 = status8;
     a.count_work = c->count_work ? 1u : 0u;
 #ifdef KGPU_STEP_TIMING
     const bool want_stats = true;
@@ -599,6 +625,34 @@ extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const ui
     a.est_q8 = c->dict->est_q8.load(std::memory_order_relaxed);
     for (int k = 0; k < 4; ++k) a.ovf[k] = (uint32_t *)c->ovf.p + (size_t)k * (n + 1);
     return enqueue(c, a);
+}
+
+extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n,
+                                    uint64_t total_bytes, kgpu_token *d_tokens, uint64_t token_capacity,
+                                    uint64_t *d_tok_offsets, uint8_t *d_status) {
+    return tokenize_device_impl(c, d_utf8, d_offsets, n, total_bytes, d_tokens, nullptr, nullptr, nullptr, token_capacity, d_tok_offsets, d_status,
+                                "kgpu_tokenize_device");
+}
+
+extern "C" int kgpu_tokenize_device_compact(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n,
+                                            uint64_t total_bytes, kgpu_token8 *d_tokens8, uint64_t token_capacity,
+                                            uint32_t *d_first, uint64_t *d_tok_offsets, uint8_t *d_status) {
+    if (token_capacity && !d_tokens8) { set_error("kgpu_tokenize_device_compact: null argument"); return KGPU_ERR_INVALID_ARG; }
+    return tokenize_device_impl(c, d_utf8, d_offsets, n, total_bytes, nullptr, d_tokens8, d_first, nullptr, token_capacity, d_tok_offsets, d_status,
+                                "kgpu_tokenize_device_compact");
+}
+
+// Host side of the 8-byte records: position / start are running sums over the sentence (include/kanpyo_gpu.h, kgpu_token8).
+extern "C" void kgpu_expand_tokens(const kgpu_token8 *in, const uint64_t *tok_offsets, const uint32_t *first, uint64_t n, kgpu_token *out) {
+    const uint64_t base = tok_offsets[0];
+    for (uint64_t s = 0; s < n; ++s) {
+        uint32_t pos = first[2 * s], st = first[2 * s + 1];
+        for (uint64_t k = tok_offsets[s] - base, e = tok_offsets[s + 1] - base; k < e; ++k) {
+            const uint32_t p = in[k].packed, chars = KGPU_T8_CHARS(p), bytes = KGPU_T8_BYTES(p);
+            out[k] = kgpu_token{in[k].id, KGPU_T8_CLS(p), pos, st, st + chars, bytes};
+            pos += bytes; st += chars;
+        }
+    }
 }
 
 extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
@@ -678,6 +732,11 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
         for (int k = 0; k < 10; ++k) c->phase[k] += sum[16 + k];
     }
     uint64_t need = c->h_ctl->n_tokens;
+    if (c->last.out8 && c->h_ctl->pack_overflow) {
+        if (n_tokens) *n_tokens = 0;
+        set_error("a token does not fit the 8-byte record (more than 4095 chars or 262143 bytes): use the 24-byte form for this batch");
+        return KGPU_ERR_CAPACITY;
+    }
     if (n_tokens) *n_tokens = need;
     if (c->h_ctl->n_tokens > c->last.out_cap) {
         set_error("token buffer too small: need %llu, capacity %llu", (unsigned long long)need, (unsigned long long)c->last.out_cap);
@@ -785,6 +844,119 @@ static int host_job_finish(HostJob &j, kgpu_token *tokens, uint64_t token_capaci
     return KGPU_OK;
 }
 
+// ---- large host calls: 8-byte records over PCIe, expanded by a few host threads ---------------------------
+// What a large call moves device -> host is 24 bytes per token, seven times its input (32 tokens per 113-byte sentence on the
+// cfg 2 corpus): ~65 M sentences/s at PCIe speed, and through pageable destinations far less.  Here the compaction kernel writes
+// 8-byte kgpu_token8 records straight into pinned, device-mapped host memory (its stores are the transfer: no copy node, no
+// D2H call), and worker threads expand them into the caller's 24-byte records (any memory: the expansion replaces the copy
+// a pageable destination costs anyway) while the next chunks compute.
+struct WorkerPool {
+    std::mutex mu; std::condition_variable cv; std::deque<std::function<void()>> q; std::vector<std::thread> th; bool stop = false;
+    void start() {
+        std::lock_guard<std::mutex> g(mu);
+        if (!th.empty()) return;
+        unsigned n = 0;
+        if (const char *e = getenv("KGPU_HOST_THREADS")) n = (unsigned)atoi(e);
+        if (n == 0) n = std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 8));
+        for (unsigned i = 0; i < n; ++i) th.emplace_back([this] {
+            for (;;) {
+                std::function<void()> f;
+                { std::unique_lock<std::mutex> l(mu); cv.wait(l, [this] { return stop || !q.empty(); }); if (q.empty()) return; f = std::move(q.front()); q.pop_front(); }
+                f();
+            }
+        });
+    }
+    void submit(std::function<void()> f) { { std::lock_guard<std::mutex> g(mu); q.push_back(std::move(f)); } cv.notify_one(); }
+    ~WorkerPool() { { std::lock_guard<std::mutex> g(mu); stop = true; } cv.notify_all(); for (auto &t : th) t.join(); }
+};
+static WorkerPool &workers() { static WorkerPool w; return w; }
+
+struct PipeJob {
+    kgpu_ctx *c = nullptr;
+    uint64_t lo = 0, m = 0, total = 0, cap = 0;
+    size_t off_first = 0, off_toff = 0, off_status = 0;  // inside pin_out: records | first | token offsets | status
+    std::atomic<int> tasks{0};                          // expansion tasks still reading pin_out
+    bool active = false;
+};
+
+static int pipe_submit(PipeJob &j, const uint8_t *utf8, const uint64_t *offsets) {
+    kgpu_ctx *c = j.c;
+    while (j.tasks.load(std::memory_order_acquire) != 0) std::this_thread::yield();  // the block's previous results are still being expanded
+    const uint64_t *off = offsets + j.lo;
+    const uint64_t n = j.m, base = off[0], total = off[n] - base;
+    j.total = total;
+    j.cap = total + n + 1;  // tokens <= chars + 1 <= bytes + 1 per sentence: never too small
+    const size_t in_off_bytes = ((size_t)(n + 1) * 8 + 63) & ~(size_t)63, in_bytes = in_off_bytes + (size_t)total + 16;
+    j.off_first = ((size_t)j.cap * 8 + 63) & ~(size_t)63;
+    j.off_toff = j.off_first + (((size_t)n * 8 + 63) & ~(size_t)63);
+    j.off_status = j.off_toff + (((size_t)(n + 1) * 8 + 63) & ~(size_t)63);
+    int rc;
+    if ((rc = c->pin_in.ensure(in_bytes, false)) || (rc = c->in_block.ensure(in_bytes)) || (rc = c->pin_out.ensure(j.off_status + (size_t)n + 64, true)) ||
+        (rc = c->out_status.ensure((size_t)n + 16)))
+        return rc;
+    uint64_t *rel = (uint64_t *)c->pin_in.h;
+    for (uint64_t i = 0; i <= n; ++i) rel[i] = off[i] - base;
+    if (total) std::memcpy((uint8_t *)c->pin_in.h + in_off_bytes, utf8 + base, (size_t)total);
+    hipError_t e;
+    if ((e = hipMemcpyAsync(c->in_block.p, c->pin_in.h, in_off_bytes + (size_t)total, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { set_error("H2D input block: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    uint8_t *po = (uint8_t *)c->pin_out.d;
+    if ((rc = tokenize_device_impl(c, (const uint8_t *)c->in_block.p + in_off_bytes, (const uint64_t *)c->in_block.p, n, total, nullptr,
+                                   (kgpu_token8 *)po, (uint32_t *)(po + j.off_first), po + j.off_status, j.cap, (uint64_t *)(po + j.off_toff),
+                                   (uint8_t *)c->out_status.p, "kgpu_tokenize_batch")))
+        return rc;
+    j.active = true;
+    return KGPU_OK;
+}
+
+static int host_job_submit(struct HostJob &j, const uint8_t *utf8, const uint64_t *offsets);
+static int host_job_finish(struct HostJob &j, kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets, uint8_t *status, uint64_t &tok_done, bool &overflow);
+
+// Wait for the chunk's kernels (its records are in host memory then), hand the expansion to the workers in slices of 2048 sentences.
+static int pipe_finish(PipeJob &j, const uint8_t *utf8, const uint64_t *offsets, kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets,
+                       uint8_t *status, uint64_t &tok_done, bool &overflow, std::atomic<int> &outstanding) {
+    kgpu_ctx *c = j.c;
+    j.active = false;
+    uint64_t got = 0;
+    int rc = kgpu_ctx_sync(c, &got);
+    if (rc == KGPU_ERR_CAPACITY && c->h_ctl->pack_overflow) {  // a token beyond the 8-byte packing: this chunk once more, 24-byte records, the plain way
+        HostJob hj;
+        hj.c = c; hj.lo = j.lo; hj.m = j.m;
+        if ((rc = host_job_submit(hj, utf8, offsets))) return rc;
+        return host_job_finish(hj, tokens, token_capacity, tok_offsets, status, tok_done, overflow);
+    }
+    if (rc) return rc;
+    if (tok_done + got > token_capacity) overflow = true;
+    const uint64_t tok_base = tok_done;
+    tok_done += got;
+    const uint8_t *ph = (const uint8_t *)c->pin_out.h;
+    const kgpu_token8 *rec = (const kgpu_token8 *)ph;
+    const uint32_t *first = (const uint32_t *)(ph + j.off_first);
+    const uint64_t *toff = (const uint64_t *)(ph + j.off_toff);
+    const uint8_t *st = ph + j.off_status;
+    constexpr uint64_t SLICE = 2048;
+    const int nt = (int)((j.m + SLICE - 1) / SLICE);
+    if (nt == 0) { if (!overflow) tok_offsets[j.lo] = tok_base; return KGPU_OK; }
+    j.tasks.store(nt, std::memory_order_release);
+    outstanding.fetch_add(nt, std::memory_order_acq_rel);
+    const bool ovf = overflow;
+    const uint64_t lo = j.lo, m = j.m;
+    for (int t = 0; t < nt; ++t) {
+        const uint64_t a = (uint64_t)t * SLICE, b = std::min(m, a + SLICE);
+        std::atomic<int> *jt = &j.tasks, *out = &outstanding;
+        workers().submit([=] {
+            if (!ovf) {
+                kgpu_expand_tokens(rec + toff[a], toff + a, first + 2 * a, b - a, tokens + tok_base + toff[a]);
+                for (uint64_t i = a; i < b; ++i) tok_offsets[lo + i] = tok_base + toff[i];
+                if (b == m) tok_offsets[lo + m] = tok_base + toff[m];
+            }
+            if (status) std::memcpy(status + lo + a, st + a, (size_t)(b - a));
+            jt->fetch_sub(1, std::memory_order_acq_rel);
+            out->fetch_sub(1, std::memory_order_acq_rel);
+        });
+    }
+    return KGPU_OK;
+}
+
 // ---- small calls: ONE launch, no copies ------------------------------------------------------------------
 // The reference's call shape is one sentence per call (src/bin/kanpyo.rs:106-126); the general path costs such a call
 // five dependent launches, two host-to-device and three device-to-host copies (~120 us).  Here the sentences and the
@@ -867,38 +1039,14 @@ static int small_call(kgpu_dict *d, kgpu_ctx *c, const uint8_t *utf8, const uint
     return KGPU_OK;
 }
 
-extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
-                                   kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets,
-                                   uint8_t *status, uint64_t *n_tokens) {
-    if (!d || !offsets || !tok_offsets || (token_capacity && !tokens)) {
-        set_error("kgpu_tokenize_batch: null argument");
-        return KGPU_ERR_INVALID_ARG;
-    }
-    for (uint64_t i = 0; i < n; ++i)
-        if (offsets[i + 1] < offsets[i]) { set_error("kgpu_tokenize_batch: offsets not monotone at %llu", (unsigned long long)i); return KGPU_ERR_INVALID_ARG; }
-    if (offsets[n] - offsets[0] && !utf8) { set_error("kgpu_tokenize_batch: null utf8"); return KGPU_ERR_INVALID_ARG; }
-    HIPCHECK(hipSetDevice(d->device));
-
-    if (n >= 1 && n <= SMALL_MAX_N && offsets[n] - offsets[0] <= SMALL_MAX_BYTES && !test_hooks().no_small_calls) {
-        kgpu_ctx *c = nullptr;
-        {
-            std::lock_guard<std::mutex> g(d->pool_mu);
-            if (!d->pool.empty()) { c = d->pool.back(); d->pool.pop_back(); }
-        }
-        int rc = c ? KGPU_OK : kgpu_ctx_create(d, nullptr, &c);
-        if (rc) return rc;
-        rc = c->plan.n_pools ? small_call(d, c, utf8, offsets, n, tokens, token_capacity, tok_offsets, status, n_tokens) : -1;
-        {
-            std::lock_guard<std::mutex> g(d->pool_mu);
-            d->pool.push_back(c);
-        }
-        if (rc != -1) return rc;  // -1: a sentence needs a kernel this path does not launch: take the general path below
-    }
-
+// The plain form of a large call (24-byte records, device-to-host copies on the context's stream): what a chunk falls back to when
+// a token does not fit the 8-byte packing, and the whole call under KGPU_HOST_LEGACY (tests: both forms give the same records).
+static int tokenize_batch_legacy(kgpu_dict *d, const uint8_t *utf8, const uint64_t *offsets, uint64_t n, kgpu_token *tokens, uint64_t token_capacity,
+                                 uint64_t *tok_offsets, uint8_t *status, uint64_t *n_tokens, const TestHooks &hooks) {
     // A large call goes through in chunks (bounded device staging: 24 B per input byte), three of them in
     // flight on pooled contexts: while chunk k's results travel to the host, chunk k+1's kernels run and
     // chunk k+2's input is on its way.  Results are delivered in order, so the tokens stay dense.
-    const uint64_t CHUNK_BYTES = test_hooks().chunk_bytes, CHUNK_SENTS = test_hooks().chunk_sents;
+    const uint64_t CHUNK_BYTES = hooks.chunk_bytes, CHUNK_SENTS = hooks.chunk_sents;
     constexpr int DEPTH = 4;
     HostJob jobs[DEPTH];
     int rc = KGPU_OK, njobs = 0;
@@ -940,6 +1088,90 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
             if (jobs[k].c) d->pool.push_back(jobs[k].c);
     }
     (void)njobs;
+    if (n_tokens) *n_tokens = tok_done;
+    if (!rc && overflow) {
+        set_error("token buffer too small: need %llu, capacity %llu", (unsigned long long)tok_done, (unsigned long long)token_capacity);
+        return KGPU_ERR_CAPACITY;
+    }
+    return rc;
+}
+
+extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
+                                   kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets,
+                                   uint8_t *status, uint64_t *n_tokens) {
+    if (!d || !offsets || !tok_offsets || (token_capacity && !tokens)) {
+        set_error("kgpu_tokenize_batch: null argument");
+        return KGPU_ERR_INVALID_ARG;
+    }
+    for (uint64_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i]) { set_error("kgpu_tokenize_batch: offsets not monotone at %llu", (unsigned long long)i); return KGPU_ERR_INVALID_ARG; }
+    if (offsets[n] - offsets[0] && !utf8) { set_error("kgpu_tokenize_batch: null utf8"); return KGPU_ERR_INVALID_ARG; }
+    HIPCHECK(hipSetDevice(d->device));
+
+    if (n >= 1 && n <= SMALL_MAX_N && offsets[n] - offsets[0] <= SMALL_MAX_BYTES && !test_hooks().no_small_calls) {
+        kgpu_ctx *c = nullptr;
+        {
+            std::lock_guard<std::mutex> g(d->pool_mu);
+            if (!d->pool.empty()) { c = d->pool.back(); d->pool.pop_back(); }
+        }
+        int rc = c ? KGPU_OK : kgpu_ctx_create(d, nullptr, &c);
+        if (rc) return rc;
+        rc = c->plan.n_pools ? small_call(d, c, utf8, offsets, n, tokens, token_capacity, tok_offsets, status, n_tokens) : -1;
+        {
+            std::lock_guard<std::mutex> g(d->pool_mu);
+            d->pool.push_back(c);
+        }
+        if (rc != -1) return rc;  // -1: a sentence needs a kernel this path does not launch: take the general path below
+    }
+
+    // A large call goes through in chunks on pooled contexts, several in flight: while chunk k's records are expanded on the host,
+    // chunk k+1 .. k+4 compute and chunk k+5's input is on its way.  Results are delivered in order, so the tokens stay dense.
+    const TestHooks hooks = test_hooks();
+    if (hooks.legacy_host_path) return tokenize_batch_legacy(d, utf8, offsets, n, tokens, token_capacity, tok_offsets, status, n_tokens, hooks);
+    workers().start();
+    const uint64_t CHUNK_BYTES = std::min<uint64_t>(hooks.chunk_bytes, 2ull << 20);
+    const uint64_t CHUNK_SENTS = std::min<uint64_t>(hooks.chunk_sents, std::min<uint64_t>(16384, std::max<uint64_t>(4096, n / 12)));
+    constexpr int DEPTH = 8;
+    PipeJob jobs[DEPTH];
+    std::atomic<int> outstanding{0};
+    int rc = KGPU_OK;
+    uint64_t done = 0, tok_done = 0;
+    bool overflow = false;
+    tok_offsets[0] = 0;
+    int head = 0, inflight = 0;  // jobs[head .. head + inflight) (mod DEPTH) are active, oldest first
+    while (!rc && (done < n || (n == 0 && done == 0 && inflight == 0))) {
+        if (inflight == DEPTH - 2) {  // two slots stay out of the GPU pipeline: their blocks are being expanded
+            rc = pipe_finish(jobs[head], utf8, offsets, tokens, token_capacity, tok_offsets, status, tok_done, overflow, outstanding);
+            head = (head + 1) % DEPTH; --inflight;
+            if (rc) break;
+        }
+        PipeJob &j = jobs[(head + inflight) % DEPTH];
+        if (!j.c) {
+            {
+                std::lock_guard<std::mutex> g(d->pool_mu);
+                if (!d->pool.empty()) { j.c = d->pool.back(); d->pool.pop_back(); }
+            }
+            if (!j.c && (rc = kgpu_ctx_create(d, nullptr, &j.c))) break;
+        }
+        uint64_t m = 0;
+        while (done + m < n && m < CHUNK_SENTS && (m == 0 || offsets[done + m + 1] - offsets[done] <= CHUNK_BYTES)) ++m;
+        j.lo = done; j.m = m;
+        if ((rc = pipe_submit(j, utf8, offsets))) break;
+        ++inflight;
+        done += m;
+        if (n == 0) break;
+    }
+    while (inflight) {  // drain in order (also after an error: the contexts go back to the pool idle)
+        int r2 = pipe_finish(jobs[head], utf8, offsets, tokens, token_capacity, tok_offsets, status, tok_done, overflow, outstanding);
+        if (!rc) rc = r2;
+        head = (head + 1) % DEPTH; --inflight;
+    }
+    while (outstanding.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    {
+        std::lock_guard<std::mutex> g(d->pool_mu);
+        for (int k = 0; k < DEPTH; ++k)
+            if (jobs[k].c) d->pool.push_back(jobs[k].c);
+    }
     if (n_tokens) *n_tokens = tok_done;
     if (!rc && overflow) {
         set_error("token buffer too small: need %llu, capacity %llu", (unsigned long long)tok_done, (unsigned long long)token_capacity);
@@ -1043,3 +1275,33 @@ extern "C" void *kgpu_host_alloc(uint64_t bytes) {
     return p;
 }
 extern "C" void kgpu_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+// ---- measurement only (tools/anyorder_probe.py; not part of include/kanpyo_gpu.h): `reps` launches of the pool kernel over one
+// batch on the ctx stream with nothing in between, optionally any-order.  Returns the wall milliseconds from first launch to stream idle.
+namespace kgpu { int launch_pool_repeat(const DictView &d, const BatchArgs &a, uint32_t pool_bytes, uint32_t waves, uint32_t max_pages,
+                                        int n_workgroups, int reps, bool any_order, void *stream); }
+extern "C" double kgpu_debug_pool_repeat(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n, uint64_t total_bytes,
+                                         int reps, int any_order) {
+    if (!c || !c->plan.n_pools) return -1.0;
+    if (hipSetDevice(c->dict->device) != hipSuccess) return -1.0;
+    if (c->pending) (void)kgpu_ctx_sync(c, nullptr);
+    if (c->arena.ensure(ARENA_INITIAL) || c->stage.ensure((size_t)(total_bytes + n + 1) * sizeof(kgpu_token) + 64) ||
+        c->tok_count.ensure((size_t)(n + 1) * 4) || c->ovf.ensure((size_t)(n + 1) * 4 * 4) || c->out_status.ensure((size_t)n + 16)) return -1.0;
+    BatchArgs a{};
+    a.utf8 = d_utf8; a.offsets = d_offsets; a.n = n; a.ctl = c->d_ctl;
+    a.arena = (uint8_t *)c->arena.p; a.arena_bytes = c->arena.bytes;
+    a.stage = (kgpu_token *)c->stage.p; a.tok_count = (uint32_t *)c->tok_count.p; a.status = (uint8_t *)c->out_status.p;
+    a.est_q8 = c->dict->est_q8.load(std::memory_order_relaxed);
+    for (int k = 0; k < 4; ++k) a.ovf[k] = (uint32_t *)c->ovf.p + (size_t)k * (n + 1);
+    if (hipMemsetAsync(c->d_ctl, 0, sizeof(Control), c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1.0;
+    c->ctl_dirty = true;
+    uint64_t wg = c->plan.pool_workgroups[0];
+    const uint64_t want = (n + c->plan.pool_waves[0] - 1) / c->plan.pool_waves[0];
+    if (want < wg) wg = want;
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    if (launch_pool_repeat(c->dict->view, a, c->plan.pool_bytes[0], c->plan.pool_waves[0], c->plan.pool_max_pages[0], (int)wg, reps, any_order != 0, c->stream)) return -1.0;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1.0;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+}

@@ -62,6 +62,8 @@ struct Control {
     unsigned int waves_done;          // single-launch small calls: wavefronts through with their sentence ...
     unsigned int waves_copied;        // ... and through with moving its tokens to the caller's (pinned) buffers
     unsigned int small_flag;          // the call's sequence number, stored LAST into the host copy: the host polls it
+    unsigned int pack_overflow;       // compact records: a token did not fit kgpu_token8 (chars > 4095 or bytes > 262143): the host falls back to 24-byte records
+    unsigned int pad2;
     unsigned int small_abort;         // ... a wavefront gave up waiting at the rendezvous: the host redoes the call on the general path
     unsigned long long dump[8];       // kgpu_lattice_dump: arena offsets of the sentence's two slabs, B, C, N, 1 = valid, dp of EOS
 };
@@ -84,6 +86,12 @@ struct BatchArgs {
     Control *fused_host;          // non-null: single-launch small call -- the pool kernel also scans, compacts into the (pinned,
     uint32_t fused_seq;           // device-mapped) output and publishes the control block with this sequence number
     unsigned long long *stat_slots;  // profiling runs: STAT_SLOTS x STAT_WORDS counters, one slot per wavefront of the pool launch
+    // compact result records (host-buffer path, kgpu_tokenize_device_compact): when out8 is set the compaction kernel writes 8-byte
+    // kgpu_token8 records (and per sentence the first token's position / start) instead of 24-byte kgpu_token records;
+    // out8 / first8 may be device-mapped pinned host memory: the kernel's stores then ARE the device-to-host transfer
+    kgpu_token8 *out8;
+    uint32_t *first8;                // [2 n]: position, start of sentence s's first token (0xFFFFFFFF twice: no tokens)
+    uint8_t *status8;                // optional (host path): the compaction kernel mirrors status[] there (mapped host memory)
 };                                   // (added to by its owner, summed on the host: hot atomics on a few words would distort the run)
 constexpr uint32_t STAT_SLOTS = 16384, STAT_WORDS = 32;  // words 0..6: Control::work, 16..25: Control::phase
 

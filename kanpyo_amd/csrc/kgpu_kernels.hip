@@ -672,6 +672,34 @@ __global__ __launch_bounds__(256) void k_compact(BatchArgs a) {
     }
 }
 
+// Staging -> dense sentence order as 8-byte records (kgpu_token8) + the first token's (position, start) per sentence.
+// One wavefront per sentence, one 8-byte store per token: when a.out8 is pinned host memory these stores are the transfer.
+// (runs behind k_scan_counts, which has already published and zeroed the control block: the packing-overflow flag goes straight to the host copy)
+__global__ __launch_bounds__(256) void k_compact8(BatchArgs a, Control *host_ctl) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    for (uint64_t s = wave; s < a.n; s += nwaves) {
+        const uint32_t cnt = a.tok_count[s];
+        const uint64_t dst = a.tok_offsets[s];
+        const kgpu_token *src = a.stage + (a.offsets[s] - a.offsets[0] + s);
+        if (lane == 0) {
+            const uint2 f = cnt ? make_uint2(src[0].position, src[0].start) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            *(uint2 *)(a.first8 + 2 * s) = f;
+            if (a.status8) a.status8[s] = a.status[s];
+        }
+        if (dst + cnt > a.out_cap) continue;
+        bool bad = false;
+        for (uint32_t k = lane; k < cnt; k += 64) {
+            const kgpu_token t = src[k];
+            const uint32_t chars = t.end - t.start;
+            bad |= chars > 0xFFFu || t.byte_len > 0x3FFFFu;
+            *(uint2 *)(a.out8 + dst + k) = make_uint2((uint32_t)t.id, t.cls | (chars << 2) | (t.byte_len << 14));
+        }
+        if (__ballot(bad) != 0 && lane == 0) __hip_atomic_store(&host_ctl->pack_overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t pool_bytes, uint32_t waves,
                          uint32_t max_pages, int n_workgroups, uint32_t stop_after, void *stream);  // kgpu_pool.hip
 int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
@@ -736,7 +764,8 @@ int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream) {
     uint64_t blocks = (a.n + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.out8) hipLaunchKernelGGL(k_compact8, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, host_ctl);
+    else hipLaunchKernelGGL(k_compact, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -34,6 +34,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "kgpu_device.h"
 
 namespace kgpu {
@@ -190,7 +192,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
     const uint32_t lane = threadIdx.x & 63u, wave = bcast32(threadIdx.x >> 6) /* SGPR: everything per-sentence is wave-uniform */, W = blockDim.x >> 6;
     const int32_t base_root = d.da[1].base;
     uint64_t *bm = (uint64_t *)pool;
-    const uint32_t page = ((pool_bytes - POOL_HDR) / POOL_PAGES) & ~15u;
+    // W == 1: the workgroup is one wavefront with a pool of its own -- a fixed LDS slice.  Nothing to share, nothing to wait for:
+    // every sentence gets the whole slice (no estimate, no redo), what does not fit goes to the next launch.
+    const bool own_slice = W == 1;
+    const uint32_t page = ((pool_bytes - POOL_HDR) / POOL_PAGES) & (own_slice ? ~7u : ~15u);
     auto pages_for = [&](uint32_t bytes) { return (bytes + page - 1) / page; };  // (a reciprocal multiply instead: measured, no difference)
     if (threadIdx.x == 0) *bm = 0;
 #ifdef KGPU_STEP_TIMING
@@ -235,10 +240,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         const uint32_t MS = (d.leaf_dup && d.n_unk_morph < (1u << 21)) ? 4u : 8u;
         const uint32_t need1 = align_up(B + 4, 4) + 24 * (C + 2) + 2 * align_up(C + 2, 4) + align_up(C * MAXM * MS, 16) + 32;
         const uint32_t est = max(need1, (uint32_t)(((uint64_t)B * a.est_q8) >> 8) + KGPU_EST_SLACK);
-        uint32_t npg = pages_for(est);
+        uint32_t npg = own_slice ? POOL_PAGES : pages_for(est);
         // routing: a sentence expected to need more than max_pages would hold a large part of the pool for a long
         // time (LDS x time grows with the square of the length); it is better served by the long-sentence kernel
-        if (npg > max_pages) { work_defer(io, lane, s); continue; }
+        if (own_slice ? need1 > pool_cap : npg > max_pages) { work_defer(io, lane, s); continue; }
         KGPU_TM(const uint64_t tm_p0 = __builtin_amdgcn_s_memtime();)
         uint32_t pg = pool_wait_alloc(bm, npg, lane);
         KGPU_TM(const uint64_t tm_p1 = __builtin_amdgcn_s_memtime(); tmPool += tm_p1 - tm_p0;)
@@ -869,6 +874,25 @@ int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const WorkIO &io
         hipLaunchKernelGGL(k_tokenize_pool<true>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, PoolArgs{d, a, io, pool_bytes, max_pages, stop_after});
     } else {
         hipLaunchKernelGGL(k_tokenize_pool<false>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, PoolArgs{d, a, io, pool_bytes, max_pages, stop_after});
+    }
+    return (int)hipGetLastError();
+}
+
+// Measurement only (tools/anyorder_probe.py): the pool kernel `reps` times over the same batch on one stream, nothing between the
+// launches; any_order: without the barrier bit (hipExtAnyOrderLaunch), so that consecutive launches of ONE stream may overlap.
+int launch_pool_repeat(const DictView &d, const BatchArgs &a, uint32_t pool_bytes, uint32_t waves, uint32_t max_pages,
+                       int n_workgroups, int reps, bool any_order, void *stream) {
+    const WorkIO io{nullptr, nullptr, a.ovf[0], &a.ctl->ovf_count[0], &a.ctl->late_count[0]};
+    if (pool_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    for (int r = 0; r < reps; ++r) {
+        if (any_order)
+            hipExtLaunchKernelGGL(k_tokenize_pool<false>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, nullptr, nullptr,
+                                  hipExtAnyOrderLaunch, PoolArgs{d, a, io, pool_bytes, max_pages, 0u});
+        else
+            hipLaunchKernelGGL(k_tokenize_pool<false>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, PoolArgs{d, a, io, pool_bytes, max_pages, 0u});
     }
     return (int)hipGetLastError();
 }

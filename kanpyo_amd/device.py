@@ -41,6 +41,14 @@ class DeviceContext:
             self._h, C.c_void_p(d_utf8), C.c_void_p(d_offsets), n, total_bytes, C.c_void_p(d_tokens), token_capacity,
             C.c_void_p(d_tok_offsets), C.c_void_p(d_status)))
 
+    def tokenize_compact(self, d_utf8: int, d_offsets: int, n: int, total_bytes: int, d_tokens8: int, token_capacity: int,
+                         d_first: int, d_tok_offsets: int, d_status: int):
+        """Same batch, results as 8-byte kgpu_token8 records + the first token's (position, start) per sentence: a third of
+        the volume for whatever moves them next (PCIe, the xGMI gather); expand_tokens() restores the 24-byte records."""
+        _lib.check(_lib.lib().kgpu_tokenize_device_compact(
+            self._h, C.c_void_p(d_utf8), C.c_void_p(d_offsets), n, total_bytes, C.c_void_p(d_tokens8), token_capacity,
+            C.c_void_p(d_first), C.c_void_p(d_tok_offsets), C.c_void_p(d_status)))
+
     def sync(self) -> int:
         """Wait for the enqueued batch; returns its dense token count."""
         n = C.c_uint64(0)
@@ -76,3 +84,20 @@ class DeviceContext:
         _lib.check(_lib.lib().kgpu_ctx_get_phase_cycles(self._h, C.byref(arr), int(reset)))
         names = ["load", "decode", "walk", "scan", "emit", "gather", "sweep", "backtrace_tokens", "sentences", "spare"]
         return {n: int(arr[i]) for i, n in enumerate(names)}
+
+
+def expand_tokens(tokens8, tok_offsets, first):
+    """kgpu_expand_tokens: 8-byte records (uint32 [T, 2] or uint64 [T]) + token offsets [n + 1] + first [n, 2] -> TOKEN_DTYPE [T]
+    (host side, numpy arrays)."""
+    import numpy as np
+
+    from .tokenizer import TOKEN_DTYPE
+
+    t8 = np.ascontiguousarray(tokens8).view(np.uint32).reshape(-1, 2)
+    toff = np.ascontiguousarray(tok_offsets, dtype=np.uint64)
+    fs = np.ascontiguousarray(first, dtype=np.uint32).reshape(-1)
+    n = toff.size - 1
+    out = np.empty(int(toff[n] - toff[0]), dtype=TOKEN_DTYPE)
+    if out.size:
+        _lib.lib().kgpu_expand_tokens(t8[int(toff[0]):].ctypes.data, toff.ctypes.data, fs.ctypes.data, n, out.ctypes.data)
+    return out

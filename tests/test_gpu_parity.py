@@ -484,3 +484,69 @@ def test_plain_leaves_layout(small, monkeypatch):
     assert_same(tok, orc, synth.make_corpus(sd, 3000, 31, "cfg2"))
     assert_same(tok, orc, synth.make_corpus(sd, 300, 32, "cfg3"))
     assert_same(tok, orc, synth.make_corpus(sd, 5, 33, "cfg2"))  # small-call path
+
+
+def test_compact_records_device_api(full):
+    """kgpu_tokenize_device_compact: 8-byte records + the first token's (position, start) per sentence, expanded on the host by
+    kgpu_expand_tokens, equal the 24-byte records of kgpu_tokenize_device (and the oracle's) bit for bit."""
+    import torch
+
+    from kanpyo_amd import synth
+    from kanpyo_amd.device import DeviceContext, expand_tokens
+    from kanpyo_amd.tokenizer import pack_sentences
+
+    sd, tok, orc = full
+    sents = synth.make_corpus(sd, 3000, 51, "cfg2") + ["", "あ"] + synth.make_corpus(sd, 120, 52, "cfg3") + synth.make_corpus(sd, 2, 53, "cfg5")
+    utf8, offs = pack_sentences(sents)
+    dev = torch.device("cuda", 0)
+    n, cap = len(sents), int(offs[-1]) + len(sents)
+    d_utf8, d_off = torch.from_numpy(utf8.copy()).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_t8 = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+    d_first = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    d_toff = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    d_st = torch.empty(n, dtype=torch.uint8, device=dev)
+    ctx = DeviceContext(tok)
+    ctx.tokenize_compact(d_utf8.data_ptr(), d_off.data_ptr(), n, int(offs[-1]), d_t8.data_ptr(), cap, d_first.data_ptr(), d_toff.data_ptr(), d_st.data_ptr())
+    nt = ctx.sync()
+    exp = orc.tokenize_batch(utf8, offs, 8)
+    toff = d_toff.cpu().numpy().astype(np.uint64)
+    assert nt == len(exp.tokens) and np.array_equal(toff, exp.offsets) and not d_st.cpu().numpy().any()
+    got = expand_tokens(d_t8[:nt].cpu().numpy(), toff, d_first.cpu().numpy())
+    assert np.array_equal(got, exp.tokens)
+
+
+def test_large_host_call_compact_pipeline_quirks_and_fallback(libs, small, monkeypatch):
+    """The large-call pipeline of kgpu_tokenize_batch (8-byte records into mapped host memory, expanded by worker threads):
+    chains whose first token does not start at 0 (an unreachable node heads the best chain and is dropped),
+    empty results, a token beyond the 8-byte packing (the chunk falls back to 24-byte records), the legacy form of the whole call."""
+    from kanpyo_amd import Dict, Tokenizer, synth
+    from kanpyo_amd.tokenizer import pack_sentences
+
+    _, oracle = libs
+    p = fixture_dict_parts()
+    p["conn_data"] = [0, 100, 200, 100, -30000, 100, 200, 100, -30000]
+    p["morphs"] = [[0, 0, 1000], [1, 1, -20000], [2, 2, 1100]]
+    d = Dict.from_parts(**p)
+    tok, orc = Tokenizer(d), oracle.OracleTokenizer.from_dict(d)
+    quirks = ["テ", "テあ", "テ辞書", "テ辞書形態素", "テスト辞書", "ト辞書あ", "辞書テ", "形態素テ形態素", "テテ辞書辞書", ""]
+    exp = assert_same(tok, orc, quirks * 60, nthreads=2)  # 600 sentences: beyond the single-launch path
+    first_pos = exp.tokens["position"][exp.offsets[:-1][(exp.offsets[1:] - exp.offsets[:-1]) > 0].astype(np.int64)]
+    assert (first_pos != 0).any(), "the corpus must contain a chain whose head was dropped"
+    # a dictionary word of 5000 characters: its token does not fit kgpu_token8 (chars > 4095)
+    p2 = fixture_dict_parts()
+    long_word = "あ" * 5000
+    kws = sorted(p2["sorted_keywords"] + [long_word], key=lambda s: s.encode())
+    morphs = {k: m for k, m in zip(p2["sorted_keywords"], p2["morphs"])}
+    morphs[long_word] = [0, 0, -30000]
+    p2["sorted_keywords"], p2["morphs"] = kws, [morphs[k] for k in kws]
+    d2 = Dict.from_parts(**p2)
+    tok2, orc2 = Tokenizer(d2), oracle.OracleTokenizer.from_dict(d2)
+    exp2 = assert_same(tok2, orc2, ["テスト"] * 150 + [long_word + "テスト"] + ["辞書"] * 150, nthreads=2)
+    assert (exp2.tokens["end"] - exp2.tokens["start"] == 5000).any()
+    # the legacy form of a large call gives the same records
+    sd, tok3, orc3 = small
+    sents = synth.make_corpus(sd, 9000, 61, "cfg2") + [""] + synth.make_corpus(sd, 300, 62, "cfg3")
+    a = assert_same(tok3, orc3, sents)
+    monkeypatch.setenv("KGPU_HOST_LEGACY", "1")
+    b = assert_same(tok3, orc3, sents)
+    assert np.array_equal(a.tokens, b.tokens)

@@ -40,3 +40,8 @@ def test_traffic_is_per_full_batch_launch(tmp_path):
     assert ins["valu_per_sentence"] == 3000 and ins["salu_per_sentence"] == 2000 and ins["wave_cycles_per_sentence"] == 100000
     s = json.load(open(summ))
     assert s[POOL.split("(")[0]]["FETCH_SIZE"]["dispatches"] == 5  # the mix is still reported, under the plain name
+    # both files name the kernel sources they were measured on; bench.py flags them when the tree has moved on
+    sys.path.insert(0, ROOT)
+    from kanpyo_amd._lib import kernel_source_hash
+
+    assert t["kernel_src_sha16"] == ins["kernel_src_sha16"] == kernel_source_hash() and len(kernel_source_hash()) == 16

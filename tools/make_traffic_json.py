@@ -4,7 +4,11 @@ batch of the tokenize kernels, FETCH_SIZE corrected as MI355X_MICROARCH.md's HBM
 Also writes pmc_instructions.json next to it (wave-instructions per sentence of the pool kernel: bench.py's instruction roofline).
 usage: python tools/make_traffic_json.py <pmc_summary.json> <out.json> [round tag]"""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kanpyo_amd._lib import kernel_source_hash  # the sources the profiled library was built from (run this on the tree that was profiled)
 
 src, dst = sys.argv[1], sys.argv[2]
 tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
@@ -17,6 +21,7 @@ batches = d[main]["FETCH_SIZE"]["dispatches"]
 fetch_kb = d[main]["FETCH_SIZE"]["per_dispatch"]  # per launch of the dominant kernel over a full batch (the general kernel
 write_kb = d[main]["WRITE_SIZE"]["per_dispatch"]  # behind it finds an empty list on cfg 2)
 out = {
+    "kernel_src_sha16": kernel_source_hash(),
     "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
               "`python bench.py --steps 2 --warmup 1 --queue 1 --no-cpu --no-extras`, tools/pmc_passes.sh)",
     "per": "one k_tokenize_pool launch over a full batch of 4096 sentences (grid 1024 x 256): " + main,
@@ -32,10 +37,10 @@ out = {
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
 
-import os
 m = d[main]
 waves = m["SQ_WAVES"]["sum"]  # one wavefront per sentence (4096-sentence batches, 4096 wavefronts)
 ins = {
+    "kernel_src_sha16": kernel_source_hash(),
     "source": f"profiles/{tag}_pmc_summary.json, kernel {main}: SQ_INSTS_* / SQ_WAVES (every wavefront of a full batch tokenizes one sentence)",
     "valu_per_sentence": m["SQ_INSTS_VALU"]["sum"] / waves, "salu_per_sentence": m["SQ_INSTS_SALU"]["sum"] / waves,
     "lds_per_sentence": m["SQ_INSTS_LDS"]["sum"] / waves, "vmem_rd_per_sentence": m["SQ_INSTS_VMEM_RD"]["sum"] / waves,
