@@ -296,13 +296,26 @@ class PackedWorkload(Workload):
         self.packed = [p]
 
 
-def measure_config(tok, dev, wl, n_chars, passes, queue, streams, label):
-    """One extra config: algorithmic bytes from the device work counters, then `passes` timed passes."""
+def measure_config(tok, dev, wl, n_chars, passes, queue, streams, label, orc=None):
+    """One extra config: algorithmic bytes from the device work counters, then `passes` timed passes.  orc (the CPU checker):
+    the first batch's records are compared with the oracle's before anything is timed."""
     import torch
 
     from kanpyo_amd.device import PROFILE_OFF, PROFILE_WORK
 
     eng = GpuEngine(tok, dev, wl, queue=queue, streams=streams, ring=1)
+    plan = eng.ctxs[0].plan()
+    bit_exact = None
+    if orc is not None:
+        eng.enqueue(0, 0)
+        k = eng._retire((0, 0))
+        t, o, _ = eng.out[0][0]
+        u0, o0 = wl.packed[0][0]
+        n0 = len(o0) - 1
+        exp = orc.tokenize_batch(u0, o0, min(os.cpu_count() or 1, 64))
+        bit_exact = bool(k == len(exp.tokens) and np.array_equal(o[: n0 + 1].cpu().numpy().astype(np.uint64), exp.offsets)
+                         and np.array_equal(t[:k].cpu().numpy().reshape(-1), exp.tokens.view(np.int32).reshape(-1)))
+        eng.drain()
     for c in eng.ctxs:
         c.set_profiling(PROFILE_WORK)
     run_job(eng, 1)
@@ -334,6 +347,12 @@ def measure_config(tok, dev, wl, n_chars, passes, queue, streams, label):
         "algorithmic_bytes_per_pass": a + b + c_,
         "roofline_at_job_rate": {"achieved": (a + b + c_) / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (a + b + c_) / dt / 1e9 / HBM_PEAK_GBS},
         "routing": prof,
+        "batch": wl.batch, "batches_per_pass": wl.nb(0), "batches_in_flight": eng.Q,
+        "first_batch_bit_exact_vs_oracle": bit_exact,
+        "launch_plan": plan,
+        "lds_bytes_per_workgroup": {"pool_kernel": plan["pool_lds_bytes"], "long_sentence_kernel": plan["long_lds_bytes"]},
+        "resident_workgroups_per_cu": {"pool_kernel": plan["pool_workgroups_per_cu"], "long_sentence_kernel": plan["long_workgroups_per_cu"]},
+        "resident_wavefronts_per_cu": {"pool_kernel": plan["pool_workgroups_per_cu"] * plan["pool_wavefronts"], "long_sentence_kernel": plan["long_workgroups_per_cu"]},
     }
 
 
@@ -730,19 +749,30 @@ def main():
                                                          "path (pinned in/out, the kernel compacts and publishes itself), of which ~40 us are the one "
                                                          "sentence's own dependent chain on one wavefront")
         if not args.no_extras:
-            nbf = len(full_batches)
-            utf8_all, offs_all = pack_sentences(corpora[0][: nbf * BATCH])
-            capall = int(offs_all[-1]) // 2 + nbf * BATCH  # tokens <= chars + 1 per sentence; the text is 3 bytes per char
+            # one large call: the whole 100k-sentence corpus four times over (400k sentences, ~45 MB in, ~300 MB of 24-byte records out)
+            reps_c = 4
+            utf8_1, offs_1 = pack_sentences(corpora[0])
+            n_big = reps_c * len(corpora[0])
+            utf8_all = np.tile(utf8_1, reps_c)
+            offs_all = np.concatenate([[0]] + [offs_1[1:] + k * int(offs_1[-1]) for k in range(reps_c)]).astype(np.uint64)
+            capall = int(offs_all[-1]) // 2 + n_big  # tokens <= chars + 1 per sentence; the text is 3 bytes per char
             for name, alloc in (("large_call_pageable", np.empty), ("large_call_pinned", pinned_empty)):
                 u = alloc(utf8_all.shape, dtype=np.uint8); u[:] = utf8_all
                 o = alloc(offs_all.shape, dtype=np.uint64); o[:] = offs_all
-                big = (alloc(capall, dtype=TOKEN_DTYPE), alloc(nbf * BATCH + 1, dtype=np.uint64), alloc(nbf * BATCH, dtype=np.uint8))
-                tok.tokenize_packed(u, o, out=big)  # untimed: scratch allocation, pages touched
+                big = (alloc(capall, dtype=TOKEN_DTYPE), alloc(n_big + 1, dtype=np.uint64), alloc(n_big, dtype=np.uint8))
+                big[0].view(np.uint8)[::4096] = 0  # pages touched
+                tok.tokenize_packed(u, o, out=big)  # untimed: scratch allocation, staging buffers, worker threads
                 t1 = time.perf_counter()
                 for _ in range(3):
                     tok.tokenize_packed(u, o, out=big)
-                result["pcie_inclusive"][name] = 3 * nbf * BATCH / (time.perf_counter() - t1)
+                result["pcie_inclusive"][name] = 3 * n_big / (time.perf_counter() - t1)
                 del big
+            result["pcie_inclusive"]["large_call_what"] = (f"kgpu_tokenize_batch, ONE call over {n_big} sentences (the cfg 2 corpus x {reps_c}), host memory in, dense 24-byte "
+                                                          "records out: chunks of <= 16384 sentences, 8-byte records written by the compaction kernel into mapped pinned "
+                                                          "memory, expanded into the caller's buffer by worker threads while later chunks compute")
+            result["value_end_to_end"] = {"value": max(result["pcie_inclusive"]["large_call_pageable"], result["pcie_inclusive"]["large_call_pinned"]),
+                                          "unit": "sentences/s", "what": "SURVEY 8(d) end-to-end incl. H2D / D2H: the better of pcie_inclusive.large_call_{pageable,pinned}; "
+                                                                         "`value` is the device-resident rate"}
 
     # ---- CPU baseline (rank 0, N==1 only): the oracle restatement on the host cores, every sentence tokenized once
     if world == 1 and not args.no_cpu:
@@ -793,8 +823,13 @@ def main():
     if world == 1 and not args.no_extras:
         eng.close()
         extra = []
+        extras_orc = None
+        if not args.no_cpu:  # the checker: first batch of each extra config against the oracle (not timed)
+            from oracle import oracle as _orc
+
+            extras_orc = _orc.OracleTokenizer.from_dict(sd.dict)
         for kind, passes, lab in (("cfg5", 5, "BASELINE configs[4] (cfg 5): 1k sentences of 2048 chars, each with a same-category run > 1024 chars"),
-                                  ("cfg3", 2, f"BASELINE configs[2] (cfg 3): {args.cfg3_sentences} mixed-length (8-512 char) sentences incl. unknown-word path")):
+                                  ("cfg3", 2, f"BASELINE configs[2] (cfg 3): {args.cfg3_sentences} mixed-length (8-512 char) sentences incl. unknown-word path, batches of 16384")):
             flag = os.path.join(extras_dir, kind + "_done.npy")
             t_wait = time.perf_counter()
             while not os.path.exists(flag) and extras_proc.is_alive() and time.perf_counter() - t_wait < 600:
@@ -806,7 +841,10 @@ def main():
             o = np.load(os.path.join(extras_dir, kind + "_offs.npy"))
             n_chars = int(np.load(flag)[0])
             try:
-                extra.append(measure_config(tok, dev, PackedWorkload(u, o), n_chars, passes, args.queue, args.streams, lab))
+                # cfg 3 names no batch size (BASELINE configs[2]): batches of 16384 -- a launch lasts as long as its longest sentence, and with one
+                # sentence per wavefront slot (4096) a few 500-char sentences decide a launch whose average is 120 (12.8 vs 15.6 M sentences/s)
+                wl_x = PackedWorkload(u, o, batch=16384 if kind == "cfg3" else BATCH)
+                extra.append(measure_config(tok, dev, wl_x, n_chars, passes, args.queue, args.streams, lab, orc=extras_orc))
             except Exception as e:
                 print(f"{kind} leg failed: {e}", file=sys.stderr)
         result["extra"] = extra

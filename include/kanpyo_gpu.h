@@ -141,6 +141,20 @@ typedef struct kgpu_routing {
                                  in-kernel rendezvous timed out)                                                     */
 } kgpu_routing;
 
+/* The launch plan a context runs with (SURVEY.md 8d cfg 5: "LDS bytes / workgroup and achieved occupancy" as data). */
+typedef struct kgpu_plan_info {
+    uint32_t compute_units;
+    uint32_t pool_lds_bytes;          /* LDS-resident kernel: bytes of the page pool one workgroup owns            */
+    uint32_t pool_wavefronts;         /* ... independent wavefronts (= sentences in flight) sharing it             */
+    uint32_t pool_workgroups_per_cu;  /* ... workgroups resident per CU (occupancy API)                            */
+    uint32_t pool_max_pages;          /* ... pages of 64 a sentence may take before it is routed to the long path  */
+    uint32_t long_lds_bytes;          /* long-sentence kernel: LDS per single-wavefront workgroup (sweep blocks)    */
+    uint32_t long_workgroups_per_cu;  /* ... resident per CU (occupancy API)                                       */
+    uint32_t long_workgroups;         /* ... grid of one launch                                                    */
+    uint32_t reserved[8];
+} kgpu_plan_info;
+int kgpu_ctx_get_plan(kgpu_ctx *c, kgpu_plan_info *out, size_t out_size);
+
 /* Work counters of one or more batches, counted on the device when
  * kgpu_ctx_set_profiling(ctx, KGPU_PROFILE_WORK) is on (the
  * algorithmic-byte formulas are written in these).  Slower: not for timed runs. */

@@ -23,7 +23,7 @@ KGPU_SENT_TRUNCATED = 3
 SYMBOLS = [
     "kgpu_last_error", "kgpu_device_count", "kgpu_dict_create", "kgpu_dict_destroy", "kgpu_dict_get_info",
     "kgpu_tokenize_batch", "kgpu_ctx_create", "kgpu_ctx_destroy", "kgpu_tokenize_device", "kgpu_tokenize_device_compact", "kgpu_expand_tokens", "kgpu_ctx_sync",
-    "kgpu_ctx_set_profiling", "kgpu_ctx_set_ablation", "kgpu_ctx_get_profile", "kgpu_ctx_get_routing", "kgpu_ctx_get_work", "kgpu_ctx_get_phase_cycles", "kgpu_index_build", "kgpu_free",
+    "kgpu_ctx_set_profiling", "kgpu_ctx_set_ablation", "kgpu_ctx_get_profile", "kgpu_ctx_get_routing", "kgpu_ctx_get_plan", "kgpu_ctx_get_work", "kgpu_ctx_get_phase_cycles", "kgpu_index_build", "kgpu_free",
     "kgpu_host_alloc", "kgpu_host_free", "kgpu_lattice_dump", "kgpu_lattice_free",
 ]
 
@@ -69,6 +69,11 @@ class Routing(C.Structure):  # kgpu_routing: read with its size, fields are only
     _fields_ = [("batches", C.c_uint64), ("sentences", C.c_uint64), ("deferred", C.c_uint64 * 4), ("redone", C.c_uint64 * 4),
                 ("long_launches", C.c_uint64), ("arena_regrows", C.c_uint64), ("first_ms", C.c_double),
                 ("small_calls", C.c_uint64), ("small_fallbacks", C.c_uint64)]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("compute_units", "pool_lds_bytes", "pool_wavefronts", "pool_workgroups_per_cu", "pool_max_pages",
+                                          "long_lds_bytes", "long_workgroups_per_cu", "long_workgroups")] + [("reserved", C.c_uint32 * 8)]
 
 
 class LatticeNode(C.Structure):
@@ -120,6 +125,7 @@ def lib():
         L.kgpu_ctx_set_ablation.argtypes = [vp, C.c_int]
         L.kgpu_ctx_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
         L.kgpu_ctx_get_routing.argtypes = [vp, C.POINTER(Routing), C.c_size_t, C.c_int]
+        L.kgpu_ctx_get_plan.argtypes = [vp, C.POINTER(PlanInfo), C.c_size_t]
         L.kgpu_ctx_get_work.argtypes = [vp, C.POINTER(Work), C.c_int]
         L.kgpu_ctx_get_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64 * 10), C.c_int]
         L.kgpu_index_build.argtypes = [vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_size_t)]

@@ -780,6 +780,22 @@ extern "C" int kgpu_ctx_get_profile(kgpu_ctx *c, kgpu_profile *out, int reset) {
     return KGPU_OK;
 }
 
+extern "C" int kgpu_ctx_get_plan(kgpu_ctx *c, kgpu_plan_info *out, size_t out_size) {
+    if (!c || !out || out_size < 4) { set_error("kgpu_ctx_get_plan: bad argument"); return KGPU_ERR_INVALID_ARG; }
+    HIPCHECK(hipSetDevice(c->dict->device));
+    kgpu_plan_info p{};
+    hipDeviceProp_t prop;
+    p.compute_units = hipGetDeviceProperties(&prop, c->dict->device) == hipSuccess ? (uint32_t)prop.multiProcessorCount : 0u;
+    if (c->plan.n_pools) {
+        p.pool_lds_bytes = c->plan.pool_bytes[0]; p.pool_wavefronts = c->plan.pool_waves[0]; p.pool_max_pages = c->plan.pool_max_pages[0];
+        p.pool_workgroups_per_cu = (uint32_t)pool_workgroups_per_cu(c->plan.pool_bytes[0], c->plan.pool_waves[0]);
+    }
+    p.long_lds_bytes = c->plan.long_lds_bytes; p.long_workgroups = (uint32_t)c->plan.long_workgroups;
+    p.long_workgroups_per_cu = c->plan.long_lds_bytes ? (uint32_t)long_workgroups_per_cu(c->plan.long_lds_bytes) : 0u;
+    std::memcpy(out, &p, std::min(out_size, sizeof p));
+    return KGPU_OK;
+}
+
 extern "C" int kgpu_ctx_get_routing(kgpu_ctx *c, kgpu_routing *out, size_t out_size, int reset) {
     if (!c || !out || out_size < 8) { set_error("kgpu_ctx_get_routing: bad argument"); return KGPU_ERR_INVALID_ARG; }
     std::memcpy(out, &c->rt, std::min(out_size, sizeof(kgpu_routing)));

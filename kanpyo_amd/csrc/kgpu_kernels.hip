@@ -769,6 +769,14 @@ int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream) {
     return (int)hipGetLastError();
 }
 
+int long_workgroups_per_cu(uint32_t lds_bytes) {  // resident workgroups of the long-sentence kernel per CU at this LDS size
+    if (lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)k_tokenize_general<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return 0;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_general<true>, 64, (size_t)lds_bytes) != hipSuccess) return 0;
+    return n;
+}
+
 LaunchPlan default_launch_plan(int device) {
     hipDeviceProp_t p;
     int cus = 256;

@@ -69,6 +69,12 @@ class DeviceContext:
                 "arena_regrows": int(r.arena_regrows), "first_ms": float(r.first_ms),
                 "small_calls": int(r.small_calls), "small_fallbacks": int(r.small_fallbacks)}
 
+    def plan(self) -> dict:
+        """The launch plan (kgpu_plan_info): LDS bytes per workgroup and resident workgroups per CU of both kernels."""
+        p = _lib.PlanInfo()
+        _lib.check(_lib.lib().kgpu_ctx_get_plan(self._h, C.byref(p), C.sizeof(p)))
+        return {n: int(getattr(p, n)) for n, _ in p._fields_ if n != "reserved"}
+
     def set_ablation(self, stop_after_stage: int):
         """Measurement only: following batches stop after the given stage (STAGE_*), zero tokens; 0 = off."""
         _lib.check(_lib.lib().kgpu_ctx_set_ablation(self._h, int(stop_after_stage)))
