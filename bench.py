@@ -60,6 +60,21 @@ def result_rate_guess(rate_1thread, nthreads):
     return rate_1thread * max(1.0, 0.5 * nthreads)
 
 
+def cpu_quota():
+    """CPUs this process may actually use at once: the cgroup's CPU quota (cpu.max = "quota period") if one is set, else the affinity
+    mask.  The GPU boxes of this pool show 256 hardware threads and a quota of 16."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(round(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -800,7 +815,8 @@ def main():
         slots = (np.zeros(int(offs[-1]) + n_c, dtype=oracle.TOKEN_DTYPE), np.zeros(n_c, dtype=np.uint32))
         orc.tokenize_slots(utf8, offs, ncores, 1, out=slots)  # untimed: pages touched
         all_cores = None
-        for nthr in sorted({ncores, max(1, ncores // 2)}, reverse=True):
+        quota = cpu_quota()
+        for nthr in sorted({min(ncores, quota), min(ncores, 2 * quota)}, reverse=True):  # as many threads as CPUs the cgroup grants, and twice that
             reps_all = max(4, int(2.0 * result_rate_guess(done / t_cpu, nthr) / n_c))
             t1 = time.perf_counter()
             orc.tokenize_slots(utf8, offs, nthr, reps_all, out=slots)
@@ -810,6 +826,10 @@ def main():
             if all_cores is None or cand["value"] > all_cores["value"]:
                 all_cores = cand
         all_cores["scaling_vs_1thread"] = all_cores["value"] / (done / t_cpu)
+        all_cores["cpu_quota_cores"] = quota
+        all_cores["host_hardware_threads"] = ncores
+        all_cores["note"] = (f"the container's cgroup grants {quota} CPUs of the host's {ncores} hardware threads (cpu.max): "
+                             "the all-core figure is bounded by that quota, not by the oracle") if quota < ncores else "no CPU quota"
         result["cpu_baseline"] = {
             "value": done / t_cpu, "unit": "sentences/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"the same 100k-sentence cfg2 corpus, {done // n_c} pass(es), {t_cpu:.1f} s, single pass per sentence into a "

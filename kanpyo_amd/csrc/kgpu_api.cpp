@@ -96,7 +96,7 @@ struct PinBuf {
 // Test-only environment hooks.  getenv is not thread-safe against setenv, and kgpu_tokenize_batch may be called from many
 // threads: the hooks are read under a mutex, ONCE per process -- unless KGPU_TEST_HOOKS_REREAD is set (tests/conftest.py sets
 // it: the tests flip the hooks between calls).
-struct TestHooks { bool no_small_calls = false, legacy_host_path = false; uint64_t chunk_bytes = 4ull << 20, chunk_sents = 16384; };
+struct TestHooks { bool no_small_calls = false, legacy_host_path = false; uint64_t chunk_bytes = 4ull << 20, chunk_sents = 16384, depth = 12; };
 static bool env_flag_now(const char *name) { const char *e = getenv(name); return e && *e && *e != '0'; }
 static TestHooks test_hooks() {
     static std::mutex mu;
@@ -108,6 +108,7 @@ static TestHooks test_hooks() {
         cur = TestHooks{};
         cur.no_small_calls = env_flag_now("KGPU_NO_SMALL_CALLS");
         cur.legacy_host_path = env_flag_now("KGPU_HOST_LEGACY");
+        if (const char *e = getenv("KGPU_HOST_DEPTH")) cur.depth = strtoull(e, nullptr, 10);
         if (const char *e = getenv("KGPU_HOST_CHUNK_BYTES")) cur.chunk_bytes = strtoull(e, nullptr, 10);
         if (const char *e = getenv("KGPU_HOST_CHUNK_SENTS")) cur.chunk_sents = strtoull(e, nullptr, 10);
     }
@@ -895,7 +896,31 @@ struct PipeJob {
     bool active = false;
 };
 
-static int pipe_submit(PipeJob &j, const uint8_t *utf8, const uint64_t *offsets) {
+// memcpy of a large block with the workers' help (the calling thread's staging copy is what limits a large call otherwise)
+static void parallel_copy(void *dst, const void *src, size_t bytes) {
+    constexpr size_t PIECE = 256 * 1024;
+    if (bytes < 2 * PIECE) { std::memcpy(dst, src, bytes); return; }
+    const size_t np = std::min<size_t>(8, bytes / PIECE), each = (bytes / np + 63) & ~(size_t)63;
+    std::atomic<int> left{(int)np - 1};
+    for (size_t k = 1; k < np; ++k) {
+        const size_t lo = k * each, hi = std::min(bytes, lo + each);
+        std::atomic<int> *l = &left;
+        workers().submit([=] { if (hi > lo) std::memcpy((uint8_t *)dst + lo, (const uint8_t *)src + lo, hi - lo); l->fetch_sub(1, std::memory_order_acq_rel); });
+    }
+    std::memcpy(dst, src, std::min(bytes, each));
+    while (left.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+}
+
+static bool is_pinned_host(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+// The chunk's input goes to the device as ONE block [offsets (absolute, as the caller has them) | bytes]; the kernels subtract
+// offsets[0] themselves, the text pointer is biased by it.  Pinned caller memory is copied from directly (DMA), pageable memory through
+// the context's pinned staging block, filled with the workers' help.
+static int pipe_submit(PipeJob &j, const uint8_t *utf8, const uint64_t *offsets, bool pinned_in) {
     kgpu_ctx *c = j.c;
     while (j.tasks.load(std::memory_order_acquire) != 0) std::this_thread::yield();  // the block's previous results are still being expanded
     const uint64_t *off = offsets + j.lo;
@@ -907,16 +932,23 @@ static int pipe_submit(PipeJob &j, const uint8_t *utf8, const uint64_t *offsets)
     j.off_toff = j.off_first + (((size_t)n * 8 + 63) & ~(size_t)63);
     j.off_status = j.off_toff + (((size_t)(n + 1) * 8 + 63) & ~(size_t)63);
     int rc;
-    if ((rc = c->pin_in.ensure(in_bytes, false)) || (rc = c->in_block.ensure(in_bytes)) || (rc = c->pin_out.ensure(j.off_status + (size_t)n + 64, true)) ||
-        (rc = c->out_status.ensure((size_t)n + 16)))
+    if ((rc = c->in_block.ensure(in_bytes)) || (rc = c->pin_out.ensure(j.off_status + (size_t)n + 64, true)) || (rc = c->out_status.ensure((size_t)n + 16)) ||
+        (!pinned_in && (rc = c->pin_in.ensure(in_bytes, false))))
         return rc;
-    uint64_t *rel = (uint64_t *)c->pin_in.h;
-    for (uint64_t i = 0; i <= n; ++i) rel[i] = off[i] - base;
-    if (total) std::memcpy((uint8_t *)c->pin_in.h + in_off_bytes, utf8 + base, (size_t)total);
     hipError_t e;
-    if ((e = hipMemcpyAsync(c->in_block.p, c->pin_in.h, in_off_bytes + (size_t)total, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { set_error("H2D input block: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    uint8_t *dblk = (uint8_t *)c->in_block.p;
+    if (pinned_in) {
+        if ((e = hipMemcpyAsync(dblk, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+            (total && (e = hipMemcpyAsync(dblk + in_off_bytes, utf8 + base, (size_t)total, hipMemcpyHostToDevice, c->stream)) != hipSuccess)) {
+            set_error("H2D input: %s", hipGetErrorString(e)); return KGPU_ERR_HIP;
+        }
+    } else {
+        std::memcpy(c->pin_in.h, off, (size_t)(n + 1) * 8);
+        if (total) parallel_copy((uint8_t *)c->pin_in.h + in_off_bytes, utf8 + base, (size_t)total);
+        if ((e = hipMemcpyAsync(dblk, c->pin_in.h, in_off_bytes + (size_t)total, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { set_error("H2D input block: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    }
     uint8_t *po = (uint8_t *)c->pin_out.d;
-    if ((rc = tokenize_device_impl(c, (const uint8_t *)c->in_block.p + in_off_bytes, (const uint64_t *)c->in_block.p, n, total, nullptr,
+    if ((rc = tokenize_device_impl(c, dblk + in_off_bytes - base, (const uint64_t *)dblk, n, total, nullptr,
                                    (kgpu_token8 *)po, (uint32_t *)(po + j.off_first), po + j.off_status, j.cap, (uint64_t *)(po + j.off_toff),
                                    (uint8_t *)c->out_status.p, "kgpu_tokenize_batch")))
         return rc;
@@ -1145,10 +1177,17 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
     const TestHooks hooks = test_hooks();
     if (hooks.legacy_host_path) return tokenize_batch_legacy(d, utf8, offsets, n, tokens, token_capacity, tok_offsets, status, n_tokens, hooks);
     workers().start();
+    static const bool trace = env_flag_now("KGPU_HOST_TRACE");  // where the calling thread's time goes, per call, on stderr
+    double t_submit = 0, t_finish = 0, t_tail = 0;
+    auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
+    const double t_call = now();
+    // chunks of 8192 sentences, ten in the device pipeline (measured on 400k sentences: 16384 x 6: 55.6, 8192 x 10: 61.2, 4096 x 14: 58.8 M sentences/s)
     const uint64_t CHUNK_BYTES = std::min<uint64_t>(hooks.chunk_bytes, 2ull << 20);
-    const uint64_t CHUNK_SENTS = std::min<uint64_t>(hooks.chunk_sents, std::min<uint64_t>(16384, std::max<uint64_t>(4096, n / 12)));
-    constexpr int DEPTH = 8;
-    PipeJob jobs[DEPTH];
+    const uint64_t CHUNK_SENTS = std::min<uint64_t>(hooks.chunk_sents, std::min<uint64_t>(8192, std::max<uint64_t>(2048, n / 12)));
+    const bool pinned_in = (offsets[n] - offsets[0]) != 0 && is_pinned_host(utf8) && is_pinned_host(offsets);
+    constexpr int MAX_DEPTH = 16;
+    const int DEPTH = (int)std::min<uint64_t>(MAX_DEPTH, std::max<uint64_t>(3, hooks.depth));
+    PipeJob jobs[MAX_DEPTH];
     std::atomic<int> outstanding{0};
     int rc = KGPU_OK;
     uint64_t done = 0, tok_done = 0;
@@ -1157,7 +1196,9 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
     int head = 0, inflight = 0;  // jobs[head .. head + inflight) (mod DEPTH) are active, oldest first
     while (!rc && (done < n || (n == 0 && done == 0 && inflight == 0))) {
         if (inflight == DEPTH - 2) {  // two slots stay out of the GPU pipeline: their blocks are being expanded
+            const double t0 = now();
             rc = pipe_finish(jobs[head], utf8, offsets, tokens, token_capacity, tok_offsets, status, tok_done, overflow, outstanding);
+            t_finish += now() - t0;
             head = (head + 1) % DEPTH; --inflight;
             if (rc) break;
         }
@@ -1172,7 +1213,9 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
         uint64_t m = 0;
         while (done + m < n && m < CHUNK_SENTS && (m == 0 || offsets[done + m + 1] - offsets[done] <= CHUNK_BYTES)) ++m;
         j.lo = done; j.m = m;
-        if ((rc = pipe_submit(j, utf8, offsets))) break;
+        const double t0 = now();
+        if ((rc = pipe_submit(j, utf8, offsets, pinned_in))) break;
+        t_submit += now() - t0;
         ++inflight;
         done += m;
         if (n == 0) break;
@@ -1182,12 +1225,18 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
         if (!rc) rc = r2;
         head = (head + 1) % DEPTH; --inflight;
     }
+    const double t_drained = now();
     while (outstanding.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    t_tail = now() - t_drained;
     {
         std::lock_guard<std::mutex> g(d->pool_mu);
         for (int k = 0; k < DEPTH; ++k)
             if (jobs[k].c) d->pool.push_back(jobs[k].c);
     }
+    if (trace)
+        fprintf(stderr, "kgpu_tokenize_batch: %llu sentences in %.3f ms: submit %.3f (input staging + enqueue), finish while filling %.3f, drain %.3f, "
+                        "waiting for the expansion %.3f; chunks of <= %llu sentences, depth %d\n",
+                (unsigned long long)n, now() - t_call, t_submit, t_finish, t_drained - t_call - t_submit - t_finish, t_tail, (unsigned long long)CHUNK_SENTS, DEPTH);
     if (n_tokens) *n_tokens = tok_done;
     if (!rc && overflow) {
         set_error("token buffer too small: need %llu, capacity %llu", (unsigned long long)tok_done, (unsigned long long)token_capacity);

@@ -119,10 +119,16 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         uint8_t *mnch = mcnt + na;             // [na][GMAXM] match length in chars
 
         // ---- phase 0: decode ------------------------------------------------
+        // The long-sentence kernel keeps the sentence's bytes in LDS while the lattice is built (when they take at most half of its
+        // LDS): every step of a double-array walk reads one text byte and then the node that byte selects -- two dependent loads; from
+        // LDS the first one costs an LDS access instead of a trip through the vector memory path.
+        uint32_t toff = 0;
+        if constexpr (LDS_SWEEP) { const uint32_t tb = (B + 4 + 15) & ~15u; if (2 * tb <= lds_bytes) toff = tb; }
         uint32_t C = 0, bad = 0, lensum = 0;
         for (uint32_t k0 = 0; k0 < B; k0 += 64) {
             uint32_t k = k0 + lane;
             uint32_t b = k < B ? text[k] : 0x80u;
+            if (toff && k < B) lds[k] = (uint8_t)b;
             bool start = k < B && (b & 0xC0) != 0x80;
             uint64_t m = __ballot(start);
             uint32_t ci = C + __popcll(m & ((1ull << lane) - 1));
@@ -160,9 +166,11 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         uint32_t *cnt_e = boff, *fill_e = bfill;
         bool lds_cursors = false;
         if constexpr (LDS_SWEEP) {
-            lds_cursors = (uint64_t)(C + 3) * 4 <= lds_bytes;
-            if (lds_cursors) { cnt_e = (uint32_t *)lds; fill_e = (uint32_t *)lds; }
+            if (toff + (uint64_t)(C + 3) * 4 > lds_bytes && (uint64_t)(C + 3) * 4 <= lds_bytes) toff = 0;  // not both: the cursors (LDS atomics per node) are worth more
+            lds_cursors = toff + (uint64_t)(C + 3) * 4 <= lds_bytes;
+            if (lds_cursors) { cnt_e = (uint32_t *)(lds + toff); fill_e = (uint32_t *)(lds + toff); }
         }
+        const uint8_t *wtext = toff ? (const uint8_t *)lds : text;  // what the walks read (count phase, and the emit phase's re-walks)
         for (uint32_t e = lane; e < C + 3; e += 64) { cnt_e[e] = 0; if (!lds_cursors) bfill[e] = 0; }
         __syncthreads();
 
@@ -203,13 +211,13 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             uint32_t cpX[2], kbX[2], knX[2];
 #pragma unroll
             for (int x = 0; x < 2; ++x) { cpX[x] = actX[x] ? cp16[iX[x]] : 0xFFFFu; kbX[x] = actX[x] ? cbyte[iX[x]] : 0u; knX[x] = actX[x] ? cbyte[iX[x] + 1] : 0u; }
-            wT += da_walk_first2(d, text, B, actX[0] && cpX[0] != 0xFFFFu, cpX[0], kbX[0], knX[0], on_match(0),
+            wT += da_walk_first2(d, wtext, B, actX[0] && cpX[0] != 0xFFFFu, cpX[0], kbX[0], knX[0], on_match(0),
                                  actX[1] && cpX[1] != 0xFFFFu, cpX[1], kbX[1], knX[1], on_match(1));
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 if (!actX[x]) continue;
                 const uint32_t i = iX[x];
-                if (cpX[x] == 0xFFFFu) wT += da_walk(d, text, kbX[x], B, base_root, on_match(x));  // first character outside the BMP: no table entry
+                if (cpX[x] == 0xFFFFu) wT += da_walk(d, wtext, kbX[x], B, base_root, on_match(x));  // first character outside the BMP: no table entry
                 uint32_t cnt = cntX[x];
                 const uint32_t m = mX[x];
                 mcnt[i] = (uint8_t)(m > GMAXM ? 0xFFu : m);
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                 }
             };
             const uint32_t nm = mcnt[i];
-            if (nm == 0xFFu) da_walk(d, text, cbyte[i], B, base_root, emit_match);
+            if (nm == 0xFFu) da_walk(d, wtext, cbyte[i], B, base_root, emit_match);
             else for (uint32_t m = 0; m < nm; ++m) emit_match(mid[(size_t)i * GMAXM + m], mnch[(size_t)i * GMAXM + m]);
             const uint32_t span = uspan[i];
             if (span) {  // lattice.rs:87-97,190-201
