@@ -123,7 +123,9 @@ class GpuEngine:
     """Q device contexts over shared streams; inputs uploaded once, every batch's dense tokens stay in HBM in
     a ring of output buffers (`ring` steps deep: a step's records must survive until its gather is through)."""
 
-    def __init__(self, tok, dev, wl, queue=6, streams=3, ring=1):
+    def __init__(self, tok, dev, wl, queue=6, streams=3, ring=1, compact=False):
+        """compact: results as 8-byte kgpu_token8 records + the first token's (position, start) per sentence (kgpu_tokenize_device_compact):
+        a third of the bytes for the gather; results() then appends the firsts (as int64) behind the counts."""
         import torch
 
         from kanpyo_amd.device import DeviceContext
@@ -136,8 +138,11 @@ class GpuEngine:
         # token offsets of a step's batches: rows of ONE tensor, so that results() gets the per-sentence counts of the whole
         # step with two tensor ops instead of three per batch (the host side of a gather chunk is what limits N = 8)
         self.off2d = [torch.zeros((nbmax, wl.batch + 1), dtype=torch.int64, device=dev) for _ in range(ring)]
-        self.out = [[(torch.empty((self.cap, 6), dtype=torch.int32, device=dev), self.off2d[r][b],
+        self.compact = compact
+        self.out = [[(torch.empty((self.cap, 2 if compact else 6), dtype=torch.int32, device=dev), self.off2d[r][b],
                       torch.empty(wl.batch, dtype=torch.uint8, device=dev)) for b in range(nbmax)] for r in range(ring)]
+        # compact: the firsts of a step's batches, rows of one tensor like the offsets ([batch, sentence, (position, start)])
+        self.first3d = [torch.zeros((nbmax, wl.batch, 2), dtype=torch.int32, device=dev) for _ in range(ring)] if compact else None
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, min(streams, self.Q)))]
         self.ctxs = [DeviceContext(tok, self.streams[i % len(self.streams)].cuda_stream) for i in range(self.Q)]
         self.seq, self.occupant, self.where, self.ntok = 0, [None] * self.Q, {}, {}
@@ -152,7 +157,11 @@ class GpuEngine:
             self.ntok[self.occupant[i]] = self.ctxs[i].sync()
         d_utf8, d_off, n, total = self.inputs[step % len(self.inputs)][b]
         t, o, st = self.out[step % self.ring][b]
-        self.ctxs[i].tokenize(d_utf8.data_ptr(), d_off.data_ptr(), n, total, t.data_ptr(), self.cap, o.data_ptr(), st.data_ptr())
+        if self.compact:
+            self.ctxs[i].tokenize_compact(d_utf8.data_ptr(), d_off.data_ptr(), n, total, t.data_ptr(), self.cap,
+                                          self.first3d[step % self.ring][b].data_ptr(), o.data_ptr(), st.data_ptr())
+        else:
+            self.ctxs[i].tokenize(d_utf8.data_ptr(), d_off.data_ptr(), n, total, t.data_ptr(), self.cap, o.data_ptr(), st.data_ptr())
         self.occupant[i] = (step, b)
         self.where[(step, b)] = i
 
@@ -176,7 +185,11 @@ class GpuEngine:
         if nb == 0:
             return views, self.torch.zeros(0, dtype=self.torch.int64, device=self.dev)
         o = self.off2d[step % self.ring][:nb]
-        return views, (o[:, 1:] - o[:, :-1]).reshape(-1)[:total]  # row-major: the full batches, then the ragged one's prefix
+        counts = (o[:, 1:] - o[:, :-1]).reshape(-1)[:total]  # row-major: the full batches, then the ragged one's prefix
+        if self.compact:  # [counts (total) | firsts (total, one int64 = (position, start) each)]
+            f = self.first3d[step % self.ring][:nb].reshape(-1, 2)[:total].contiguous().view(self.torch.int64).reshape(-1)
+            counts = self.torch.cat([counts, f])
+        return views, counts
 
     def after_gather(self):
         """Marks the transfers just waited for (on the RCCL backend work.wait() only makes torch's current stream wait,
@@ -268,6 +281,30 @@ def run_job(engine, nsteps, gather=None, chunk_steps=1, on_chunk=None):
     engine.drain()
     if trace:
         print("host ms per chunk:", {k: round(1e3 * v / max(len(starts), 1), 3) for k, v in acc.items()}, file=sys.stderr)
+
+
+def expand_gathered(tok8_all, cnt2_all, sizes, steps_sentences):
+    """Host side (checks, consumers): a gathered chunk of 8-byte records -> (24-byte records [T, 6] int32, counts int64), rank-major.
+    cnt2_all holds per rank and step [counts | firsts]; steps_sentences[r] = list of that rank's local sentence counts per step of the chunk."""
+    from kanpyo_amd.device import expand_tokens
+
+    toks, cnts, at_t, at_c = [], [], 0, 0
+    for r, (nt, nc) in enumerate(sizes):
+        seg_t, seg_c = tok8_all[at_t : at_t + nt], cnt2_all[at_c : at_c + nc]
+        at_t += nt
+        at_c += nc
+        t0 = c0 = 0
+        for n_s in steps_sentences[r]:
+            cnt = seg_c[c0 : c0 + n_s].astype(np.int64)
+            first = seg_c[c0 + n_s : c0 + 2 * n_s].astype(np.int64).view(np.uint32).reshape(-1, 2)
+            k = int(cnt.sum())
+            toff = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+            toks.append(expand_tokens(np.ascontiguousarray(seg_t[t0 : t0 + k]), toff, first).view(np.int32).reshape(-1, 6))
+            cnts.append(cnt)
+            t0 += k
+            c0 += 2 * n_s
+        assert t0 == nt and c0 == nc
+    return (np.concatenate(toks) if toks else np.zeros((0, 6), np.int32)), (np.concatenate(cnts) if cnts else np.zeros(0, np.int64))
 
 
 def chunk_steps_for(nb_per_step):
@@ -390,6 +427,8 @@ def main():
     ap.add_argument("--cfg3-sentences", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cfg 3 / cfg 5 / latency / stage legs")
+    ap.add_argument("--gather-records", type=int, default=8, choices=(8, 24), help="N>1: bytes per token record on the wire: 8 = kgpu_token8 (+ the first token's "
+                    "position / start per sentence; kgpu_expand_tokens restores the 24-byte records on the consumer's side), 24 = kgpu_token")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (self-test)")
     args = ap.parse_args()
 
@@ -452,7 +491,8 @@ def main():
     wl = Workload(corpora, rank if world > 1 else 0, world)
     tok = Tokenizer(sd.dict, device=local_rank)
     cs = chunk_steps_for(wl.nb(0))
-    eng = GpuEngine(tok, dev, wl, queue=args.queue, streams=args.streams, ring=3 * cs if multi else 1)
+    compact = multi and args.gather_records == 8
+    eng = GpuEngine(tok, dev, wl, queue=args.queue, streams=args.streams, ring=3 * cs if multi else 1, compact=compact)
     Q = eng.Q
 
     # ---- untimed: device-side work counters of every distinct batch of corpus 0 (algorithmic bytes)
@@ -479,7 +519,7 @@ def main():
     def count_chunk(c0, r):
         if r is not None:
             gathered["tokens"] += int(r[0].shape[0])
-            gathered["sentences"] += int(r[1].shape[0])
+            gathered["sentences"] += int(r[1].shape[0]) // (2 if compact else 1)  # compact: [counts | firsts] per rank and step
             gathered["chunks"] += 1
 
     def job(nsteps, on_chunk=count_chunk):
@@ -493,8 +533,12 @@ def main():
         got = {}
         job(1, lambda c0, r: got.update(r=r))
         if rank == 0:
-            tok_all, cnt_all, _ = got["r"][:3]
-            g_tok, g_off = reassemble(tok_all.cpu().numpy(), cnt_all.cpu().numpy(), len(corpora[0]), world)
+            tok_all, cnt_all, sizes_all = got["r"][:3]
+            tok_np, cnt_np = tok_all.cpu().numpy(), cnt_all.cpu().numpy()
+            if compact:  # the check wants the 24-byte records: expand the gathered chunk on the host (one step per rank here)
+                n0 = len(corpora[0])
+                tok_np, cnt_np = expand_gathered(tok_np, cnt_np, sizes_all, [[(n0 - r + world - 1) // world] for r in range(world)])
+            g_tok, g_off = reassemble(tok_np, cnt_np, len(corpora[0]), world)
             full = GpuEngine(tok, dev, Workload(corpora[:1], 0, 1), queue=2, streams=1, ring=1)
             for b in range(full.nb(0)):
                 full.enqueue(0, b)
@@ -505,7 +549,7 @@ def main():
             full.close()
             del full
         if rank == 0 and world > 1:  # allocator blocks of the chunk sizes: no hipMalloc inside the timed region
-            warm = [torch.empty((cs * N_SENT * 40, 6), dtype=torch.int32, device=dev) for _ in range(3)]
+            warm = [torch.empty((cs * N_SENT * 40, 2 if compact else 6), dtype=torch.int32, device=dev) for _ in range(3)]
             del warm
         torch.cuda.synchronize()
 
@@ -644,9 +688,12 @@ def main():
     if multi:
         result["gather"] = {"chunks": gathered["chunks"], "tokens": gathered["tokens"], "sentences": gathered["sentences"],
                             "complete": gathered["sentences"] == sentences, "reassembled_step_equals_one_gpu": gather_check,
-                            "chunk_steps": cs, "record_bytes": 24,
-                            "root_ingest_GB_per_s": gathered["tokens"] * 24 * (world - 1) / max(world, 1) / elapsed / 1e9,
-                            "root_ingest_what": "24-byte token records arriving at rank 0 from the other ranks over xGMI (its own share, 1/N of the "
+                            "chunk_steps": cs, "record_bytes": 8 if compact else 24,
+                            "records": ("kgpu_token8 (8 bytes) + the first token's (position, start) per sentence; the root holds them as gathered, "
+                                        "kgpu_expand_tokens restores the 24-byte kgpu_token records on the consumer's side (not in the timed region)") if compact
+                                       else "kgpu_token (24 bytes)",
+                            "root_ingest_GB_per_s": gathered["tokens"] * (8 if compact else 24) * (world - 1) / max(world, 1) / elapsed / 1e9,
+                            "root_ingest_what": "token records arriving at rank 0 from the other ranks over xGMI (its own share, 1/N of the "
                                                 "stream, is a local copy), averaged over the timed region"}
         result["per_rank"] = per_rank
         result["corpora"] = {"distinct": len(corpora), "seeds": f"100..{99 + len(corpora)}", "sentences_each": N_SENT}

@@ -900,7 +900,7 @@ struct PipeJob {
 static void parallel_copy(void *dst, const void *src, size_t bytes) {
     constexpr size_t PIECE = 256 * 1024;
     if (bytes < 2 * PIECE) { std::memcpy(dst, src, bytes); return; }
-    const size_t np = std::min<size_t>(8, bytes / PIECE), each = (bytes / np + 63) & ~(size_t)63;
+    const size_t np = std::min<size_t>(8, bytes / PIECE), each = ((bytes + np - 1) / np + 63) & ~(size_t)63;  // np * each >= bytes (rounded UP: a floor here lost the last bytes of a chunk)
     std::atomic<int> left{(int)np - 1};
     for (size_t k = 1; k < np; ++k) {
         const size_t lo = k * each, hi = std::min(bytes, lo + each);

@@ -772,6 +772,8 @@ int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream) {
     uint64_t blocks = (a.n + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
+    // (measured: the compaction of 8-byte records into mapped host memory on a stream of its own, behind an event -- so that the context's
+    // stream goes on with the next batch -- gives 46.8 instead of 68.6 M sentences/s end to end: one more stream than hardware queues)
     if (a.out8) hipLaunchKernelGGL(k_compact8, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, host_ctl);
     else hipLaunchKernelGGL(k_compact, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();

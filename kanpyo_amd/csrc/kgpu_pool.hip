@@ -415,8 +415,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         off = align_up(off, 8);
         uint2 *bk = (uint2 *)(smem + off);          off += 8 * (Nb + 1);  // bucket (= edges[e]): {dp, right | node << 16}; [Nb]: sink for EOS
         int32_t *nSid = (int32_t *)(smem + off);    off += 4 * N;   // +id known, -id unknown, 0 dummy
-        uint16_t *nLeft = (uint16_t *)(smem + off); off += 2 * N;   // left id until the node's block is gathered, then its best predecessor
-        uint32_t *nCS = (uint32_t *)(smem + off);   off += 4 * N;   // word cost (i16) | bucket slot of the node << 16
+        uint32_t *nCS = (uint32_t *)(smem + off);   off += 4 * N;   // word cost (i16) | bucket slot of the node << 16   (all dwords before the half-words:
+        uint16_t *nLeft = (uint16_t *)(smem + off); off += 2 * N;   // left id until the node's block is gathered, then its best predecessor   every array naturally aligned whatever N is)
         uint16_t *nStart = (uint16_t *)(smem + off); off += 2 * N;
         off = align_up(off, 4);
         const uint32_t off_emit_end = off;                          // everything above is written by emit

@@ -178,7 +178,8 @@ class ChunkedGather:
         counts = counts.contiguous()
         if rank == self.dst:
             dev = counts.device
-            tok_all = torch.empty((sum(s[0] for s in sizes), 6), dtype=token_views[0].dtype if token_views else torch.int32, device=dev)
+            width = int(token_views[0].shape[1]) if token_views else 6  # 6: kgpu_token rows, 2: kgpu_token8 rows
+            tok_all = torch.empty((sum(s[0] for s in sizes), width), dtype=token_views[0].dtype if token_views else torch.int32, device=dev)
             cnt_all = torch.empty(sum(s[1] for s in sizes), dtype=counts.dtype, device=dev)
             t0 = c0 = 0
             for r, row in enumerate(table):

@@ -83,9 +83,11 @@ def test_cfg5_all_thousand_documents(full):
     assert exp.counters["C"] == 2048 * 1000
 
 
-def test_cfg4_workload_one_rank_over_rccl(full):
+@pytest.mark.parametrize("compact", [False, True])
+def test_cfg4_workload_one_rank_over_rccl(full, compact):
     """cfg 4 at world size 1 on the RCCL backend (bench.py --force-dist): four corpora of seeds 100..103, every step's records
-    gathered chunk by chunk; each gathered step, reassembled, equals the oracle's stream of the unsharded corpus."""
+    gathered chunk by chunk; each gathered step, reassembled, equals the oracle's stream of the unsharded corpus.  compact: the
+    8-byte records bench.py gathers by default (kgpu_tokenize_device_compact), expanded on the host by kgpu_expand_tokens."""
     import torch
     import torch.distributed as dist
 
@@ -107,14 +109,17 @@ def test_cfg4_workload_one_rank_over_rccl(full):
         corpora = [synth.make_corpus(sd, n_per, seed=100 + k, kind="cfg2") for k in range(4)]
         wl = bench.Workload(corpora, 0, 1)
         cs = bench.chunk_steps_for(wl.nb(0))
-        eng = bench.GpuEngine(tok, dev, wl, queue=8, streams=4, ring=3 * cs)
+        eng = bench.GpuEngine(tok, dev, wl, queue=8, streams=4, ring=3 * cs, compact=compact)
         got = {}
+        nsteps = 6  # corpora 0..3, then 0 and 1 again (ring slots reused)
 
         def on_chunk(c0, r):
-            tok_all, cnt_all = r[0], r[1]
-            got[c0] = (tok_all.cpu().numpy().copy(), cnt_all.cpu().numpy().copy())
+            tok_all, cnt_all = r[0].cpu().numpy().copy(), r[1].cpu().numpy().copy()
+            if compact:
+                steps = range(c0, min(c0 + cs, nsteps))
+                tok_all, cnt_all = bench.expand_gathered(tok_all, cnt_all, r[2], [[len(corpora[s % len(corpora)]) for s in steps]])
+            got[c0] = (tok_all, cnt_all)
 
-        nsteps = 6  # corpora 0..3, then 0 and 1 again (ring slots reused)
         bench.run_job(eng, nsteps, ChunkedGather(dst=0, size_group=size_pg), cs, on_chunk)
         eng.close()
         assert sorted(got) == list(range(0, nsteps, cs))
