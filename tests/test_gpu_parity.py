@@ -550,3 +550,16 @@ def test_large_host_call_compact_pipeline_quirks_and_fallback(libs, small, monke
     monkeypatch.setenv("KGPU_HOST_LEGACY", "1")
     b = assert_same(tok3, orc3, sents)
     assert np.array_equal(a.tokens, b.tokens)
+
+
+def test_large_host_call_chunk_byte_counts(small):
+    """Regression: the staging copy of a chunk is split between the calling thread and the workers; a split rounded DOWN lost the
+    chunk's last bytes (floor(bytes / pieces) a multiple of 64, bytes not a multiple of pieces).  Chunks whose byte counts sit on
+    and around such values, the last sentence of each chunk ending in a distinctive character."""
+    sd, tok, orc = small
+    for extra in (0, 1, 2, 3, 5, 7):
+        body = ["あ" * 85 + "a"] * 2047          # 256 bytes each: chunk 0 = 2048 sentences (the pipeline's chunk for 2049..24576 sentences)
+        last = "あ" * 85 + "a" + "z" * extra + "Q"  # 257 + extra bytes: chunk 0 has 2 * 262144 + 1 + extra bytes
+        sents = body + [last] + ["い" * 30 + "b"] * 200
+        assert sum(len(x.encode()) for x in sents[:2048]) == 2 * 262144 + 1 + extra
+        assert_same(tok, orc, sents)
