@@ -139,6 +139,8 @@ typedef struct kgpu_routing {
     uint64_t small_calls;     /* kgpu_tokenize_batch calls served by the single-launch path                          */
     uint64_t small_fallbacks; /* ... that had to be redone on the general path (a sentence too long for LDS, or the
                                  in-kernel rendezvous timed out)                                                     */
+    uint64_t window_reruns;   /* batches rerun with the HBM-lattice kernel because the windowed long-sentence kernel
+                                 handed a sentence back                                                              */
 } kgpu_routing;
 
 /* The launch plan a context runs with (SURVEY.md 8d cfg 5: "LDS bytes / workgroup and achieved occupancy" as data). */

@@ -68,7 +68,7 @@ class Profile(C.Structure):  # kgpu_profile: 24 bytes, frozen
 class Routing(C.Structure):  # kgpu_routing: read with its size, fields are only ever appended
     _fields_ = [("batches", C.c_uint64), ("sentences", C.c_uint64), ("deferred", C.c_uint64 * 4), ("redone", C.c_uint64 * 4),
                 ("long_launches", C.c_uint64), ("arena_regrows", C.c_uint64), ("first_ms", C.c_double),
-                ("small_calls", C.c_uint64), ("small_fallbacks", C.c_uint64)]
+                ("small_calls", C.c_uint64), ("small_fallbacks", C.c_uint64), ("window_reruns", C.c_uint64)]
 
 
 class PlanInfo(C.Structure):

@@ -164,6 +164,7 @@ struct kgpu_ctx {
     uint32_t launch_seq = 0;
     int last_pools = 0;        // pool launches issued for the pending batch
     bool last_long = false;    // ... and whether the long-sentence kernel was
+    bool force_legacy_long = false;  // the pending batch is a rerun: the windowed kernel handed a sentence back
     uint32_t event_every = 1;  // KGPU_PROFILE_SAMPLED: HIP events on every 4th launch only
     DevBuf arena, stage, tok_count;
     // host-buffer path staging
@@ -570,7 +571,9 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
         const int pools_now = c->dict->big_pool_batches.load(std::memory_order_relaxed) > 0 ? c->plan.n_pools : std::min(c->plan.n_pools, 1);
         c->last_pools = pools_now;
         c->last_long = c->plan.long_lds_bytes && (c->plan.n_pools == 0 || c->dict->long_batches.load(std::memory_order_relaxed) > 0);
-        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->last_long, c->stop_after, c->stream, ef);
+        const bool window_now = c->plan.window_lds_bytes && !c->force_legacy_long && !a.dump_lattice;
+        if (window_now) c->last_long = true;  // (the windowed kernel is always in the chain: it costs an empty launch nothing to find its list empty... and its list is all it serves)
+        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->last_long, c->stop_after, c->stream, ef, window_now);
         if (e != hipSuccess) { set_error("k_tokenize launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     } else if (timed) HIPCHECK(hipEventRecord(ef, c->stream));
     if (timed) HIPCHECK(hipEventRecord(e1, c->stream));
@@ -587,7 +590,7 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
 }
 
 static int tokenize_device_impl(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n, uint64_t total_bytes,
-                                kgpu_token *d_tokens, kgpu_token8 *d_tokens8, uint32_t *d_first, uint8_t *status8, uint64_t token_capacity,
+                                kgpu_token *d_tokens, kgpu_token8 *d_tokens8, uint32_t *d_first, uint8_t *status8, uint64_t *toff8, uint64_t token_capacity,
                                 uint64_t *d_tok_offsets, uint8_t *d_status, const char *who) {
     if (!c || !d_offsets || !d_tok_offsets || (n && !d_status) || (total_bytes && !d_utf8) ||
         (token_capacity && !d_tokens && !d_tokens8) || (d_tokens8 && n && !d_first)) {
@@ -609,7 +612,7 @@ static int tokenize_device_impl(kgpu_ctx *c, const uint8_t *d_utf8, const uint64
     a.stage = (kgpu_token *)c->stage.p;
     a.tok_count = (uint32_t *)c->tok_count.p;
     a.status = d_status; a.out = d_tokens; a.out_cap = token_capacity; a.tok_offsets = d_tok_offsets;
-    a.out8 = d_tokens8; a.first8 = d_first; a.status8 = status8;
+    a.out8 = d_tokens8; a.first8 = d_first; a.status8 = status8; a.toff8 = toff8;
     a.count_work = c->count_work ? 1u : 0u;
 #ifdef KGPU_STEP_TIMING
     const bool want_stats = true;
@@ -631,7 +634,7 @@ static int tokenize_device_impl(kgpu_ctx *c, const uint8_t *d_utf8, const uint64
 extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n,
                                     uint64_t total_bytes, kgpu_token *d_tokens, uint64_t token_capacity,
                                     uint64_t *d_tok_offsets, uint8_t *d_status) {
-    return tokenize_device_impl(c, d_utf8, d_offsets, n, total_bytes, d_tokens, nullptr, nullptr, nullptr, token_capacity, d_tok_offsets, d_status,
+    return tokenize_device_impl(c, d_utf8, d_offsets, n, total_bytes, d_tokens, nullptr, nullptr, nullptr, nullptr, token_capacity, d_tok_offsets, d_status,
                                 "kgpu_tokenize_device");
 }
 
@@ -639,7 +642,7 @@ extern "C" int kgpu_tokenize_device_compact(kgpu_ctx *c, const uint8_t *d_utf8, 
                                             uint64_t total_bytes, kgpu_token8 *d_tokens8, uint64_t token_capacity,
                                             uint32_t *d_first, uint64_t *d_tok_offsets, uint8_t *d_status) {
     if (token_capacity && !d_tokens8) { set_error("kgpu_tokenize_device_compact: null argument"); return KGPU_ERR_INVALID_ARG; }
-    return tokenize_device_impl(c, d_utf8, d_offsets, n, total_bytes, nullptr, d_tokens8, d_first, nullptr, token_capacity, d_tok_offsets, d_status,
+    return tokenize_device_impl(c, d_utf8, d_offsets, n, total_bytes, nullptr, d_tokens8, d_first, nullptr, nullptr, token_capacity, d_tok_offsets, d_status,
                                 "kgpu_tokenize_device_compact");
 }
 
@@ -662,6 +665,23 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
     for (;;) {
         if (!c->pending) { if (n_tokens) *n_tokens = 0; return KGPU_OK; }
         HIPCHECK(hipEventSynchronize(c->done_ev));  // this context's batch only: later work on a shared stream is not waited for
+        if (c->h_ctl->window_fail && !c->h_ctl->arena_overflow && !c->force_legacy_long) {
+            // a sentence the windowed kernel cannot hold: the batch once more, long sentences through the HBM-lattice kernel
+            c->force_legacy_long = true;
+            c->rt.window_reruns++;
+            static const bool wtrace = env_flag_now("KGPU_WINDOW_TRACE");
+            if (wtrace) {
+                const unsigned long long *w = c->h_ctl->phase;
+                fprintf(stderr, "window kernel handed back sentences of a batch of %llu: seeds out of range %llu, > 8 prefixes %llu, node chunks %llu, FIFO full %llu, "
+                                "FIFO chunks %llu, FIFO order %llu, carry list %llu, window LDS %llu\n", (unsigned long long)c->last.n, w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
+            }
+            // the rerun counts everything again: drop what this run left in the per-wavefront slots
+            if (c->last.stat_slots) HIPCHECK(hipMemsetAsync(c->last.stat_slots, 0, (size_t)STAT_SLOTS * STAT_WORDS * 8, c->stream));
+            int rc = enqueue(c, c->last);
+            c->force_legacy_long = false;
+            if (rc) { c->pending = false; return rc; }
+            continue;
+        }
         if (c->h_ctl->arena_overflow) {
             // a lattice did not fit the scratch arena: grow it and redo the batch
             size_t want = c->arena.bytes * 2;
@@ -932,7 +952,7 @@ static int pipe_submit(PipeJob &j, const uint8_t *utf8, const uint64_t *offsets,
     j.off_toff = j.off_first + (((size_t)n * 8 + 63) & ~(size_t)63);
     j.off_status = j.off_toff + (((size_t)(n + 1) * 8 + 63) & ~(size_t)63);
     int rc;
-    if ((rc = c->in_block.ensure(in_bytes)) || (rc = c->pin_out.ensure(j.off_status + (size_t)n + 64, true)) || (rc = c->out_status.ensure((size_t)n + 16)) ||
+    if ((rc = c->in_block.ensure(in_bytes)) || (rc = c->pin_out.ensure(j.off_status + (size_t)n + 64, true)) || (rc = c->out_status.ensure((size_t)n + 16)) || (rc = c->out_off.ensure((size_t)(n + 1) * 8)) ||
         (!pinned_in && (rc = c->pin_in.ensure(in_bytes, false))))
         return rc;
     hipError_t e;
@@ -949,8 +969,8 @@ static int pipe_submit(PipeJob &j, const uint8_t *utf8, const uint64_t *offsets,
     }
     uint8_t *po = (uint8_t *)c->pin_out.d;
     if ((rc = tokenize_device_impl(c, dblk + in_off_bytes - base, (const uint64_t *)dblk, n, total, nullptr,
-                                   (kgpu_token8 *)po, (uint32_t *)(po + j.off_first), po + j.off_status, j.cap, (uint64_t *)(po + j.off_toff),
-                                   (uint8_t *)c->out_status.p, "kgpu_tokenize_batch")))
+                                   (kgpu_token8 *)po, (uint32_t *)(po + j.off_first), po + j.off_status, (uint64_t *)(po + j.off_toff), j.cap,
+                                   (uint64_t *)c->out_off.p, (uint8_t *)c->out_status.p, "kgpu_tokenize_batch")))
         return rc;
     j.active = true;
     return KGPU_OK;

@@ -63,7 +63,7 @@ struct Control {
     unsigned int waves_copied;        // ... and through with moving its tokens to the caller's (pinned) buffers
     unsigned int small_flag;          // the call's sequence number, stored LAST into the host copy: the host polls it
     unsigned int pack_overflow;       // compact records: a token did not fit kgpu_token8 (chars > 4095 or bytes > 262143): the host falls back to 24-byte records
-    unsigned int pad2;
+    unsigned int window_fail;         // the windowed long-sentence kernel met a sentence it cannot hold: the host reruns the batch with the HBM-lattice kernel
     unsigned int small_abort;         // ... a wavefront gave up waiting at the rendezvous: the host redoes the call on the general path
     unsigned long long dump[8];       // kgpu_lattice_dump: arena offsets of the sentence's two slabs, B, C, N, 1 = valid, dp of EOS
 };
@@ -92,6 +92,7 @@ struct BatchArgs {
     kgpu_token8 *out8;
     uint32_t *first8;                // [2 n]: position, start of sentence s's first token (0xFFFFFFFF twice: no tokens)
     uint8_t *status8;                // optional (host path): the compaction kernel mirrors status[] there (mapped host memory)
+    uint64_t *toff8;                 // optional (host path): ... and tok_offsets[] (n + 1), so that it reads its offsets from HBM, not back over PCIe
 };                                   // (added to by its owner, summed on the host: hot atomics on a few words would distort the run)
 constexpr uint32_t STAT_SLOTS = 16384, STAT_WORDS = 32;  // words 0..6: Control::work, 16..25: Control::phase
 
@@ -108,6 +109,8 @@ struct LaunchPlan {
     int general_workgroups;
     uint32_t long_lds_bytes;  // 0: no long-sentence kernel (general kernel with an LDS-blocked sweep)
     int long_workgroups;
+    uint32_t window_lds_bytes;  // > 0: the windowed long-sentence kernel (kgpu_window.hip) takes the long-sentence kernel's place in the chain
+    int window_workgroups;
 };
 
 // Launchers (kgpu_kernels.hip).  `stream` is a hipStream_t.
@@ -115,7 +118,9 @@ struct LaunchPlan {
 // stays complete without the later ones: their work falls through to the next launch).
 int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now,
                     uint32_t stop_after /* kgpu_ctx_set_ablation; 0 = run everything */, void *stream,
-                    void *event_after_first /* hipEvent_t recorded behind the first (dominant) launch, or null */);
+                    void *event_after_first /* hipEvent_t recorded behind the first (dominant) launch, or null */,
+                    bool window_now = false /* the windowed kernel instead of the HBM-lattice one (plan.window_lds_bytes) */);
+int window_workgroups_per_cu(uint32_t lds_bytes);
 int launch_general_only(const DictView &d, const BatchArgs &a, void *stream);
 int launch_small_call(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, void *stream);  // pool kernel alone, one sentence per wavefront  // kgpu_lattice_dump: HBM-scratch kernel alone
 int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream);  // host_ctl: device pointer of the pinned result block

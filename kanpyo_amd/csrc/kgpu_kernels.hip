@@ -695,6 +695,7 @@ __global__ __launch_bounds__(256) void k_compact8(BatchArgs a, Control *host_ctl
             const uint2 f = cnt ? make_uint2(src[0].position, src[0].start) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
             *(uint2 *)(a.first8 + 2 * s) = f;
             if (a.status8) a.status8[s] = a.status[s];
+            if (a.toff8) { a.toff8[s] = dst; if (s + 1 == a.n) a.toff8[a.n] = dst + cnt; }
         }
         if (dst + cnt > a.out_cap) continue;
         bool bad = false;
@@ -714,8 +715,10 @@ int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
 
 // Launch chain: pool kernel(s), then the general (HBM scratch) kernel.  Every launch is a
 // persistent grid over its work list (the first one: the identity over [0, n)).
+int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, void *stream);  // kgpu_window.hip
+
 int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now, uint32_t stop_after, void *stream,
-                    void *event_after_first) {
+                    void *event_after_first, bool window_now) {
     Control *ctl = a.ctl;
     const uint32_t *in_list = nullptr;
     const unsigned int *in_count = nullptr;
@@ -732,6 +735,12 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
         in_count = &ctl->ovf_count[li];
     }
     if (event_after_first && (plan.n_pools == 0 || n_pools_now == 0) && hipEventRecord((hipEvent_t)event_after_first, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
+    if (long_now && window_now && plan.window_lds_bytes && stop_after == 0) {  // windowed lattice in LDS; what it cannot hold it flags (Control::window_fail)
+        WorkIO io{in_list, in_count, nullptr, nullptr, nullptr};
+        uint64_t wg = plan.window_workgroups;
+        if (!in_list && a.n < wg) wg = a.n;
+        return launch_tokenize_window(d, a, io, plan.window_lds_bytes, (int)(wg ? wg : 1), stream);
+    }
     if (long_now && plan.long_lds_bytes) {  // HBM lattice + LDS-blocked sweep; takes its whole list, leaves none
         WorkIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], nullptr};
         uint64_t wg = plan.long_workgroups;
@@ -796,8 +805,8 @@ LaunchPlan default_launch_plan(int device) {
     // long-sentence kernel (HBM lattice, LDS-blocked sweep): KGPU_LONG="<KiB>" per single-wavefront workgroup, "0" = off
     {
         const char *e = getenv("KGPU_LONG");
-        int kib = e ? atoi(e) : 12;
-        if (kib < 0 || kib > 160) kib = 12;
+        int kib = e ? atoi(e) : 10;   // 10 KB: 16 workgroups per CU (cfg 3 in batches of 16384: 16.4-17.2 M sentences/s; 12 KB: 15.7-16.1; 8 KB: 16.9 but
+        if (kib < 0 || kib > 160) kib = 10;  // cfg 5's per-position cursors no longer fit: 0.43 instead of 0.83 M documents/s; 16 KB: 14.0)
         t.long_lds_bytes = (uint32_t)kib * 1024;
         t.long_workgroups = kib ? cus * (160 / kib) : 0;
     }
@@ -839,6 +848,16 @@ LaunchPlan default_launch_plan(int device) {
             while (*q && *q != ',') ++q;
             if (*q == ',') ++q;
         }
+    }
+    // windowed long-sentence kernel: KGPU_WINDOW="<KiB>" of LDS per single-wavefront workgroup, "0" = off (the HBM-lattice kernel serves the long sentences)
+    {
+        const char *e = getenv("KGPU_WINDOW");
+        int kib = e ? atoi(e) : 0;
+        if (kib < 8 || kib > 160) kib = 0;
+        t.window_lds_bytes = (uint32_t)kib * 1024;
+        const int per_cu = kib ? window_workgroups_per_cu(t.window_lds_bytes) : 0;
+        t.window_workgroups = cus * per_cu;
+        if (per_cu <= 0) t.window_lds_bytes = 0;
     }
     if (const char *e = getenv("KGPU_GENERAL_WG")) { int v = atoi(e); if (v > 0) t.general_workgroups = v; }
     if (const char *e = getenv("KGPU_POOL_WG")) { int v = atoi(e); if (v > 0 && t.n_pools) t.pool_workgroups[0] = v; }

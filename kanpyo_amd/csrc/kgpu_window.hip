@@ -1,0 +1,782 @@
+// kanpyo_amd/csrc/kgpu_window.hip -- the windowed long-sentence kernel (gfx950).
+//
+// A sentence of any length with a BOUNDED amount of LDS: the lattice is built and relaxed window by window (WIN start
+// positions at a time, ascending), every window with the phases of the LDS-resident pool kernel (kgpu_pool.hip) -- walk with
+// the text and the parked matches in LDS, node-parallel emit, one parallel gather of the connection costs per block, the
+// Viterbi chain at LDS latency -- and only what outlives a window leaves LDS:
+//   * per node 16 bytes to HBM {best predecessor, morph id, start char, start byte}: what the backtrace and the tokens need
+//     (src/lattice.rs:144-153, src/tokenizer.rs:22-43);
+//   * the bucket entries {end, dp, right id, node} of nodes that end beyond the window: those that end within the next
+//     2 WIN positions stay in LDS (the carry list: they are the seeds of the following window's buckets, exactly as BOS is the
+//     seed of the first, src/lattice.rs:156-164), the others -- unknown words of a long same-category run, up to 1024
+//     characters ahead (src/lattice.rs:66-84) -- go to a FIFO in HBM: their end positions never decrease, so a window takes
+//     what it needs from the head.  A position whose bucket is mostly such entries (the end of a 1024-character run: thousands)
+//     is relaxed by streaming them from the FIFO, 64 per step.
+// The HBM-lattice kernel (k_tokenize_general<true>, kgpu_kernels.hip) keeps every per-character and per-node array in HBM
+// (44 bytes per node, ~70 per byte, read back several times); LDS-resident lattices (kgpu_pool.hip) do not scale to long
+// sentences (LDS x time grows with the square of the length: DESIGN.md section 8).  This kernel's LDS is independent of the
+// length and its HBM traffic is one write per node.
+//
+// What it cannot hold (more than 8 dictionary prefixes at one position, a window whose lattice outgrows the LDS budget, a
+// dictionary word that ends more than 2 WIN positions ahead after an even farther one, node indices beyond the 16-bit
+// window of the tie-break) it reports through Control::window_fail: the host reruns the batch with the HBM-lattice kernel.
+#include <type_traits>
+
+#include "kgpu_device.h"
+
+namespace kgpu {
+
+using namespace dev;
+
+namespace {
+
+constexpr uint32_t WIN = 32;               // start positions per window
+constexpr uint32_t REL = 2 * WIN + 1;      // bucket positions a window holds: relative ends 0 .. 2 WIN
+constexpr uint32_t WMAXM = 8;              // trie matches parked per start position
+constexpr uint32_t LOOKB = 192;            // text bytes staged beyond the window's own characters (a walk that runs past them reads HBM)
+constexpr uint32_t TEXTB = 4 * WIN + LOOKB;
+constexpr uint32_t NCH_LOG = 13, NCHUNKS = 32;   // node records: chunks of 8192 (128 KB), at most 262144 nodes per sentence
+constexpr uint32_t FCH_LOG = 12, FCHUNKS = 16;   // far entries: chunks of 4096 (64 KB), at most 65536 waiting at once
+constexpr uint32_t WIDE_MIN = 96;          // FIFO entries at one end position from which they are streamed instead of staged in LDS
+constexpr uint32_t NONE16 = 0xFFFFu;
+constexpr uint32_t PAIR_MIN = 1024;        // bytes of pair table a window wants beyond its largest position
+
+struct Far { uint32_t end; int32_t dp; uint32_t right; uint32_t node; };          // a bucket entry that outlives its window (16 B)
+struct NodeRec { uint32_t pre; int32_t sid; uint32_t start; uint32_t bstart; };   // what the backtrace and the tokens need (16 B)
+
+template <int CTRL>
+__device__ __forceinline__ int32_t w_dpp(int32_t x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+template <uint32_t LG>
+__device__ __forceinline__ int32_t wmin_i32(int32_t v) {
+    if constexpr (LG >= 1) v = min(v, w_dpp<0xB1>(v));
+    if constexpr (LG >= 2) v = min(v, w_dpp<0x4E>(v));
+    if constexpr (LG >= 3) v = min(v, w_dpp<0x141>(v));
+    if constexpr (LG >= 4) v = min(v, w_dpp<0x140>(v));
+    return v;
+}
+template <uint32_t LG>
+__device__ __forceinline__ uint32_t wmin_u32(uint32_t v) {
+    if constexpr (LG >= 1) v = min(v, (uint32_t)w_dpp<0xB1>((int32_t)v));
+    if constexpr (LG >= 2) v = min(v, (uint32_t)w_dpp<0x4E>((int32_t)v));
+    if constexpr (LG >= 3) v = min(v, (uint32_t)w_dpp<0x141>((int32_t)v));
+    if constexpr (LG >= 4) v = min(v, (uint32_t)w_dpp<0x140>((int32_t)v));
+    return v;
+}
+__device__ __forceinline__ uint64_t wmin_u64_all(uint64_t k) {  // over the 64 lanes
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t oh = (uint32_t)__shfl_xor((int)(uint32_t)(k >> 32), d, 64), ol = (uint32_t)__shfl_xor((int)(uint32_t)k, d, 64);
+        const uint64_t o = ((uint64_t)oh << 32) | ol;
+        k = o < k ? o : k;
+    }
+    return k;
+}
+__device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }
+#define KW_LDS(T) __attribute__((address_space(3))) T
+template <class T> __device__ __forceinline__ T lds_ld(uint32_t addr) { return *(const KW_LDS(T) *)(uintptr_t)addr; }
+template <class T> __device__ __forceinline__ void lds_st(uint32_t addr, T v) { *(KW_LDS(T) *)(uintptr_t)addr = v; }
+__device__ __forceinline__ uint2 lds_ld2(uint32_t addr) { const uint64_t v = lds_ld<uint64_t>(addr); return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); }
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The double-array walk of da_walk_first (kgpu_device.h; trie/da.rs:155-182) with the text read through `byte(k)`.
+template <class BY, class F>
+__device__ __forceinline__ uint32_t win_walk(const DictView &d, BY &&byte, uint32_t cp, uint32_t kb, uint32_t kn, uint32_t B, int32_t base_root, F &&on_match) {
+    int32_t p, bp;
+    uint32_t k, nstart, steps;
+    if (cp != 0xFFFFu) {
+        const DaNode f = d.first[cp];
+        if (f.base == 0) return (uint32_t)f.check;
+        p = f.base; bp = f.check; k = kn; nstart = 1; steps = kn - kb;
+    } else {  // first character outside the BMP: no table entry, walk its bytes from the root
+        p = 1; bp = base_root; k = kb; nstart = 0; steps = 0;
+    }
+    for (;;) {
+        const bool more = k < B;
+        const uint32_t c = more ? byte(k) : 0u;
+        const bool boundary = !more || (c & 0xC0) != 0x80;
+        const uint32_t q = (uint32_t)(bp + (int32_t)c);
+        const bool doprobe = boundary && nstart > 0 && (uint32_t)bp < d.da_len;
+        const bool donext = more && q < d.da_len;
+        DaNode t{0, 0}, nx{0, 0};
+        if (doprobe) t = d.da[bp];  // + TERMINATOR (da.rs:166)
+        if (donext) nx = d.da[q];
+        if (doprobe && t.check == p && t.base < 0) { uint32_t id, dup; leaf_decode(d, t.base, id, dup); on_match(id, nstart, dup); }
+        if (!more) break;
+        ++steps;
+        if (!donext || nx.check != p) break;  // da.rs:162-165
+        p = (int32_t)q;
+        bp = nx.base;
+        nstart += boundary;
+        ++k;
+    }
+    return steps;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a, WorkIO io, uint32_t lds_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t lane = threadIdx.x;
+    const int32_t base_root = d.da[1].base;
+    const bool tiled = d.conn_tiled != nullptr;
+    auto rword = [&](uint32_t r) { return tiled ? ((r >> 3) << 6) | (r & 7u) : r; };
+    Slab sa{nullptr, 0};
+    uint64_t accW[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint64_t tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // shader clocks per phase (only summed when a.count_work): prepass, stage, seeds, walk, scan, emit, gather, sweep, flush, backtrace+tokens
+#define KW_T(k) do { if (a.count_work) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); tph[k] += t_ - tlast; tlast = t_; } } while (0)
+
+    // ---- LDS, fixed part (persists across the windows of a sentence; the chunk tables across sentences) ----
+    uint32_t off0 = 0;
+    uint32_t *nchunk = (uint32_t *)(lds + off0); off0 += 4 * NCHUNKS;   // node-record chunks this workgroup owns (arena offsets / 256)
+    uint32_t *fchunk = (uint32_t *)(lds + off0); off0 += 4 * FCHUNKS;   // far-entry chunks
+    uint8_t *ltext = lds + off0;                 off0 += align_up(TEXTB, 16);
+    uint32_t *cbw = (uint32_t *)(lds + off0);    off0 += 4 * (WIN + 2);   // byte offset of the window's characters (and one past)
+    uint32_t *nb = (uint32_t *)(lds + off0);     off0 += 4 * (WIN + 2);   // nodes starting at position q -> first local node index
+    uint32_t *ebase = (uint32_t *)(lds + off0);  off0 += 4 * (WIN + 2);   // first pair index per position
+    uint32_t *fbase = (uint32_t *)(lds + off0);  off0 += 4 * (WIN + 2);   // first far-out slot per position
+    uint32_t *boff = (uint32_t *)(lds + off0);   off0 += 4 * (REL + 2);   // bucket count -> offset, per relative end position
+    uint32_t *bfill = (uint32_t *)(lds + off0);  off0 += 4 * (REL + 2);
+    uint32_t *fcnt = (uint32_t *)(lds + off0);   off0 += 4 * (WIN + 2);   // FIFO entries ending at position q -> their first FIFO index
+    uint32_t *wideN = (uint32_t *)(lds + off0);  off0 += 4 * (WIN + 2);   // ... how many of them are streamed (0: staged in LDS)
+    uint16_t *cp16w = (uint16_t *)(lds + off0);  off0 += 2 * (WIN + 2);
+    uint16_t *rlenw = (uint16_t *)(lds + off0);  off0 += 2 * (WIN + 2);
+    uint16_t *uspan = (uint16_t *)(lds + off0);  off0 += 2 * (WIN + 2);
+    uint8_t *catw = lds + off0;                  off0 += align_up(WIN + 2, 4);
+    uint8_t *mcnt = lds + off0;                  off0 += align_up(WIN + 2, 4);
+    off0 = align_up(off0, 16);
+    uint32_t nchunks_have = 0, fchunks_have = 0;   // wave-uniform; the tables persist in LDS
+    const uint32_t MS = (d.leaf_dup && d.n_unk_morph < (1u << 21)) ? 4u : 8u;
+    const uint32_t mbytes = WIN * WMAXM * MS;
+    const bool cfg_bad = off0 + mbytes + 2048 > lds_bytes;  // (launch configuration error: every sentence is handed back)
+    // The carry list lives at the top of the LDS, just below the match buffer: n entries {dp, right id | node index relative to the NEXT
+    // window's base} + their relative end positions.  It is written when a window is flushed (the pair table that occupied the region
+    // is dead by then) and read when the next window's buckets are seeded.
+    const uint32_t moff = (lds_bytes - mbytes) & ~15u;
+    auto carry8 = [&](uint32_t n) { return (uint2 *)(lds + moff - align_up(8 * n, 16)); };
+    auto crel = [&](uint32_t n) { return lds + moff - align_up(8 * n, 16) - align_up(n, 16); };
+    auto cbytes = [&](uint32_t n) { return align_up(8 * n, 16) + align_up(n, 16); };
+
+    auto fail = [&](uint64_t s) {  // this sentence needs the HBM-lattice kernel: the host reruns the batch with it
+        if (lane == 0) { a.status[s] = KGPU_SENT_NO_SCRATCH; a.tok_count[s] = 0; atomicExch(&a.ctl->window_fail, 1u); }
+    };
+    auto chunk_get = [&](uint32_t *table, uint32_t &have, uint32_t idx, uint32_t bytes) -> bool {  // make chunk idx exist (bytes: a multiple of 256)
+        while (have <= idx) {
+            uint64_t o = 0;
+            if (lane == 0) o = atomicAdd(&a.ctl->arena_cursor, (unsigned long long)bytes);
+            o = bcast64(o);
+            if (o + bytes > a.arena_bytes || (o >> 8) > 0xFFFFFFFFull) { if (lane == 0) atomicExch(&a.ctl->arena_overflow, 1u); return false; }
+            if (lane == 0) table[have] = (uint32_t)(o >> 8);
+            ++have;
+            wave_sync();
+        }
+        return true;
+    };
+    auto node_rec = [&](uint32_t g) { return (NodeRec *)(a.arena + ((uint64_t)nchunk[g >> NCH_LOG] << 8)) + (g & ((1u << NCH_LOG) - 1)); };
+    auto far_rec = [&](uint32_t f) { return (Far *)(a.arena + ((uint64_t)fchunk[(f >> FCH_LOG) % FCHUNKS] << 8)) + (f & ((1u << FCH_LOG) - 1)); };
+
+    for (uint32_t iter = 0;; ++iter) {
+        uint64_t s = 0;
+        if (!work_next(io, a, iter, s)) break;
+        const uint64_t b0 = a.offsets[s];
+        const uint32_t B = (uint32_t)(a.offsets[s + 1] - b0);
+        const uint8_t *text = a.utf8 + b0;
+        uint64_t tlast = a.count_work ? __builtin_amdgcn_s_memtime() : 0;
+        if (cfg_bad) { if (lane == 0) { a.status[s] = KGPU_SENT_NO_SCRATCH; a.tok_count[s] = 0; atomicExch(&a.ctl->window_fail, 1u); } continue; }
+
+        // ---- slab: per-character arrays in HBM (written once by the decode pass, read once per window) ----
+        const uint64_t na = (uint64_t)B + 4;
+        if (!slab_ensure(sa, na * 13 + 64, a, lane)) {
+            if (lane == 0) { a.status[s] = KGPU_SENT_NO_SCRATCH; a.tok_count[s] = 0; }
+            continue;
+        }
+        uint32_t *cbyte = (uint32_t *)sa.ptr;       // char -> byte offset, [C] = B
+        uint32_t *path = cbyte + na;                // backtrace
+        uint16_t *cp16 = (uint16_t *)(path + na);   // BMP code point (0xFFFF: not BMP)
+        uint16_t *rlen = cp16 + na;                 // same-category run length from here, capped at 1024 (lattice.rs:66-84)
+        uint8_t *ccat = (uint8_t *)(rlen + na);
+
+        // ---- pass 0: decode + validate + category (char_category_def.rs:33-38) ----
+        uint32_t C = 0, bad = 0, lensum = 0;
+        for (uint32_t k0 = 0; k0 < B; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const uint32_t b = k < B ? text[k] : 0x80u;
+            const bool start = k < B && (b & 0xC0) != 0x80;
+            const uint64_t m = __ballot(start);
+            const uint32_t ci = C + __popcll(m & ((1ull << lane) - 1));
+            if (start) {
+                uint32_t l, cp;
+                if (b < 0x80) { l = 1; cp = b; }
+                else if (b >= 0xC2 && b <= 0xDF) { l = 2; cp = b & 0x1F; }
+                else if ((b & 0xF0) == 0xE0) { l = 3; cp = b & 0x0F; }
+                else if (b >= 0xF0 && b <= 0xF4) { l = 4; cp = b & 0x07; }
+                else { l = 1; cp = 0; bad = 1; }
+                if (k + l > B) { bad = 1; l = 1; }
+                for (uint32_t j = 1; j < l; ++j) {
+                    const uint32_t bb = text[k + j];
+                    if ((bb & 0xC0) != 0x80) bad = 1;
+                    cp = (cp << 6) | (bb & 0x3F);
+                }
+                if (l == 3 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) bad = 1;
+                if (l == 4 && (cp < 0x10000 || cp > 0x10FFFF)) bad = 1;
+                lensum += l;
+                cbyte[ci] = k;
+                cp16[ci] = (uint16_t)(cp < 0xFFFFu ? cp : 0xFFFFu);
+                ccat[ci] = bad ? 0 : (cp < d.cat_len ? d.cat[cp] : d.cat[0]);
+            }
+            C += __popcll(m);
+        }
+        lensum = bcast32(wave_sum(lensum));
+        if (__ballot(bad != 0) != 0 || lensum != B) {
+            if (lane == 0) { a.status[s] = KGPU_SENT_INVALID_UTF8; a.tok_count[s] = 0; }
+            continue;
+        }
+        if (lane == 0) cbyte[C] = B;
+        __syncthreads();
+        // ---- pass 1 (descending): length of the same-category run that starts at each character, capped at 1024 ----
+        {
+            uint32_t carry_end = C;
+            for (int ch = (int)((C + 63) / 64) - 1; ch >= 0; --ch) {
+                const uint32_t i = (uint32_t)ch * 64 + lane;
+                const bool active = i < C;
+                const uint32_t cat = active ? ccat[i] : 0x1FFu;
+                const uint32_t ncat = (i + 1 < C) ? ccat[i + 1] : 0x2FFu;
+                const uint64_t bm = __ballot(active && ncat != cat);
+                const uint64_t rest = bm >> lane;
+                const uint32_t run_end = rest ? i + (uint32_t)__ffsll((unsigned long long)rest) : carry_end;
+                carry_end = bcast32(run_end);
+                if (active) { const uint32_t r = run_end - i; rlen[i] = (uint16_t)(r < MAX_UNKNOWN_LEN ? r : MAX_UNKNOWN_LEN); }
+            }
+        }
+        __syncthreads();
+
+        KW_T(0);
+        // ---- the windows ----
+        uint32_t w0 = 0, gw = 1 /* global index of the window's first node: BOS is node 0 */, ncarry = 1, fhead = 0, ftail = 0, last_far_end = 0;
+        uint32_t wT = 0, wE = 0;
+        bool failed = false;
+        uint32_t why = 0;  // which limit a failed sentence ran into (Control::phase[why] counts them: KGPU_WINDOW_TRACE)
+        if (lane == 0) { carry8(1)[0] = make_uint2(0u, rword(d.bos_right)); crel(1)[0] = 0; }  // BOS: node 0, ends at 0, dp None -> 0 (lattice.rs:127,156-164)
+        uint32_t wbyte0 = 0;  // first byte of the next window's characters
+        uint32_t wlim = WIN;  // positions per window: halved when a window's lattice outgrows the LDS, doubled back afterwards
+        wave_sync();
+        uint32_t eos_pre = NONE;
+        for (; w0 <= C && !failed; ) {
+            const uint32_t nw = min(wlim, C + 1 - w0);         // positions of this window; position C (if in it) holds only EOS
+            const uint32_t nwc = min(nw, C - w0);              // ... of which characters
+            const uint32_t rb = gw >= 0x8000u ? gw - 0x8000u : 0u;   // node indices inside the window's LDS are 16-bit offsets from here
+            // -- stage: the window's per-character records and its text (+ LOOKB bytes) into LDS
+            if (lane <= nwc) cbw[lane] = cbyte[w0 + lane];
+            if (lane < nwc) { cp16w[lane] = cp16[w0 + lane]; catw[lane] = ccat[w0 + lane]; rlenw[lane] = rlen[w0 + lane]; }
+            for (uint32_t e = lane; e < REL + 2; e += 64) { boff[e] = 0; bfill[e] = 0; }
+            if (lane < WIN + 2) { fcnt[lane] = 0; wideN[lane] = 0; }
+            // (the text block starts at the byte the previous window's characters ended at -- known without waiting for cbw -- and
+            // has a fixed length: one round trip for the whole stage)
+            const uint32_t tb0 = wbyte0, tlen = min(B - tb0, TEXTB);
+            for (uint32_t k = lane; k < tlen; k += 64) ltext[k] = text[tb0 + k];
+            wave_sync();
+            const uint32_t wbyte_next = cbw[nwc];
+            auto byte = [&](uint32_t k) -> uint32_t { const uint32_t r = k - tb0; return r < tlen ? ltext[r] : text[k]; };
+
+            KW_T(1);
+            // -- seeds: carried entries per relative end; FIFO entries that end inside this window
+            uint32_t seed_bad = 0;
+            for (uint32_t k = lane; k < ncarry; k += 64) atomicAdd(&boff[crel(ncarry)[k]], 1u);
+            uint32_t fin = 0;  // FIFO entries [fhead, fhead + fin) end inside this window
+            for (uint32_t f0 = fhead; f0 < ftail; f0 += 64) {
+                const uint32_t f = f0 + lane;
+                bool in = false;
+                if (f < ftail) { const Far e = *far_rec(f); in = e.end < w0 + nw; if (in) { atomicAdd(&fcnt[e.end - w0], 1u); if (e.node < rb) seed_bad = 1; } }
+                const uint64_t m = __ballot(in);
+                fin += __popcll(m);
+                if (m != ~0ull) break;  // ends never decrease: the first entry beyond the window ends the scan
+            }
+            fin = bcast32(fin);
+            if (__ballot(seed_bad != 0) != 0) { failed = true; why = 1; break; }
+            wave_sync();
+            {   // FIFO entries per position -> first FIFO index; many at one position: streamed (wide), else staged as seeds
+                const uint32_t v = lane < nw ? fcnt[lane] : 0u;
+                const uint32_t vs = wave_incl_scan(v, lane);
+                if (lane < nw) {
+                    fcnt[lane] = fhead + vs - v;
+                    const bool wide = v >= WIDE_MIN;
+                    wideN[lane] = wide ? v : 0u;
+                    if (!wide && v) atomicAdd(&boff[lane], v);
+                }
+            }
+            wave_sync();
+
+            KW_T(2);
+            // -- walk: one double-array walk per start position; count, park the matches (lattice.rs:24-38, 42-99)
+            uint32_t *mbuf = (uint32_t *)(lds + moff);
+            uint32_t ovf = 0, cnt = 0, nfar = 0, wTw = 0, wEw = 0;  // (work of this window: added to the sentence's only when the window goes through)
+            if (lane < nwc) {
+                uint32_t m = 0;
+                auto on_match = [&](uint32_t id, uint32_t nch, uint32_t dup) {
+                    const uint32_t nrec = 1u + (dup != NONE ? dup : (uint32_t)d.morph[id - 1].dup);  // index.rs:46-51
+                    if (m < WMAXM && nch < 256) {
+                        if (MS == 4) mbuf[lane * WMAXM + m] = id | (nch << 21) | ((nrec < 8 ? nrec : 0u) << 29);
+                        else *(uint2 *)(mbuf + 2 * (lane * WMAXM + m)) = make_uint2(id, nch | (nrec << 8));
+                    } else ovf = 1;
+                    ++m;
+                    cnt += nrec;
+                    const uint32_t rel = lane + nch;
+                    if (rel <= 2 * WIN) atomicAdd(&boff[rel], nrec); else nfar += nrec;
+                };
+                wTw += win_walk(d, byte, cp16w[lane], cbw[lane], cbw[lane + 1], B, base_root, on_match);
+                mcnt[lane] = (uint8_t)(m < WMAXM ? m : WMAXM);
+                const CatInfo ci = d.cinfo[catw[lane]];
+                uint32_t span = 0;
+                if ((cnt == 0 || (ci.flags & CAT_INVOKE)) && (ci.flags & CAT_HAS_UNK) && ci.unk_count) {  // lattice.rs:54,87-92
+                    span = (ci.flags & CAT_GROUP) ? (uint32_t)rlenw[lane] : 1u;                             // lattice.rs:66-84
+                    cnt += ci.unk_count;
+                    const uint32_t rel = lane + span;
+                    if (rel <= 2 * WIN) atomicAdd(&boff[rel], ci.unk_count); else nfar += ci.unk_count;
+                    if (m < WMAXM) {
+                        if (MS == 4) mbuf[lane * WMAXM + m] = (uint32_t)ci.unk_first | ((ci.unk_count < 8 ? ci.unk_count : 0u) << 29);
+                        else *(uint2 *)(mbuf + 2 * (lane * WMAXM + m)) = make_uint2((uint32_t)ci.unk_first, ci.unk_count);
+                    }
+                }
+                uspan[lane] = (uint16_t)span;
+            } else if (lane < nw) { cnt = 1; mcnt[lane] = 0; uspan[lane] = 0; }  // position C: EOS (lattice.rs:165-175)
+            if (__ballot(ovf != 0) != 0) { failed = true; why = 2; break; }
+            wave_sync();
+
+            KW_T(3);
+            // -- scan: node numbering (insertion order, lattice.rs:105-110), bucket offsets, pair offsets, far-out slots
+            uint32_t N, Nb, E, NF, maxpairs;
+            {
+                const uint32_t v = lane < nw ? cnt : 0u, fo = lane < nw ? nfar : 0u;
+                const uint32_t vs = wave_incl_scan(v, lane), fs = wave_incl_scan(fo, lane);
+                if (lane <= nw) { nb[lane] = vs - v; fbase[lane] = fs - fo; }
+                N = (uint32_t)__builtin_amdgcn_readlane((int)vs, 63); NF = (uint32_t)__builtin_amdgcn_readlane((int)fs, 63);
+                // bucket offsets over the REL relative ends (two rounds of 64)
+                uint32_t bc = 0;
+                for (uint32_t e0 = 0; e0 < REL + 1; e0 += 64) {
+                    const uint32_t e = e0 + lane;
+                    const uint32_t w = e < REL ? boff[e] : 0u;
+                    const uint32_t ws = wave_incl_scan(w, lane);
+                    if (e <= REL) boff[e] = bc + ws - w;
+                    bc += (uint32_t)__builtin_amdgcn_readlane((int)ws, 63);
+                }
+                Nb = bc;
+                wave_sync();
+                // relaxations: targets x (LDS predecessors + streamed ones)
+                const uint32_t P = lane < nw ? boff[lane + 1] - boff[lane] : 0u;
+                const uint32_t x = v * P;
+                const uint32_t xs = wave_incl_scan(x, lane);
+                if (lane <= nw) ebase[lane] = xs - x;
+                E = (uint32_t)__builtin_amdgcn_readlane((int)xs, 63);
+                wEw = (lane < nw) ? v * (P + wideN[lane]) : 0u;
+                maxpairs = x;
+#pragma unroll
+                for (int dd = 32; dd > 0; dd >>= 1) maxpairs = max(maxpairs, (uint32_t)__shfl_xor((int)maxpairs, dd, 64));
+                maxpairs = bcast32(maxpairs);
+            }
+            // -- LDS carve: node arrays, buckets (+ far-out slots + sink), far-out ends, pair table (overlays the match buffer)
+            uint32_t off = off0;
+            uint2 *bk = (uint2 *)(lds + off);            off += 8 * (Nb + NF + 1);
+            int32_t *nSid = (int32_t *)(lds + off);      off += 4 * N;
+            uint32_t *nCS = (uint32_t *)(lds + off);     off += 4 * N;
+            uint32_t *farEnd = (uint32_t *)(lds + off);  off += 4 * NF;
+            uint16_t *nLeft = (uint16_t *)(lds + off);   off += 2 * N;
+            uint16_t *nStart = (uint16_t *)(lds + off);  off += 2 * N;
+            off = align_up(off, 4);
+            uint16_t *pre = nLeft;
+            int16_t *mpair = (int16_t *)(lds + off);
+            const uint32_t pair_need = min(2 * E, max(2 * maxpairs, PAIR_MIN));
+            if (N > 0x7FFF || NF >= 0x7FFF || Nb + NF > 0xFFF0 || off + cbytes(ncarry) + mbytes + 16 > lds_bytes || off + pair_need > lds_bytes ||
+                off0 + 8 * (Nb + NF + 1) + cbytes(Nb) > moff /* the flush writes the next carry list above the buckets it reads */) {
+                if (wlim > 4 && nw > 1) { wlim = max(4u, nw >> 1); continue; }  // the same window once more, half as long
+                failed = true; why = 8;
+                break;
+            }
+            if ((uint64_t)gw + N >= ((uint64_t)NCHUNKS << NCH_LOG)) { failed = true; why = 3; break; }
+            const uint32_t mcap = (lds_bytes - off) / 2;
+            wave_sync();
+
+            KW_T(4);
+            // -- emit 3a (lane = start position, LDS only): the node list in insertion order; nLeft = relative end, or 0x8000 | far-out slot
+            if (lane < nwc) {
+                uint32_t t = nb[lane], fslot = fbase[lane];
+                const uint32_t nm = mcnt[lane], span = uspan[lane];
+                uint32_t ufirst = 0, ucnt = 0;
+                if (span) {
+                    if (nm < WMAXM) {
+                        if (MS == 4) { const uint32_t w = mbuf[lane * WMAXM + nm]; ufirst = w & 0x1FFFFFu; ucnt = w >> 29; }
+                        else { const uint2 w = *(const uint2 *)(mbuf + 2 * (lane * WMAXM + nm)); ufirst = w.x; ucnt = w.y; }
+                    }
+                    if (ucnt == 0) { const CatInfo ci = d.cinfo[catw[lane]]; ufirst = (uint32_t)ci.unk_first; ucnt = ci.unk_count; }
+                }
+                auto put = [&](int32_t sid, uint32_t rel) {
+                    nSid[t] = sid; nStart[t] = (uint16_t)lane;
+                    if (rel <= 2 * WIN) nLeft[t] = (uint16_t)rel;
+                    else { nLeft[t] = (uint16_t)(0x8000u | fslot); farEnd[fslot] = w0 + rel; ++fslot; }
+                    ++t;
+                };
+                for (uint32_t m = 0; m < nm; ++m) {
+                    uint32_t id, nch, nrec;
+                    if (MS == 4) {
+                        const uint32_t w = mbuf[lane * WMAXM + m];
+                        id = w & 0x1FFFFFu; nch = (w >> 21) & 255u; nrec = w >> 29;
+                        if (nrec == 0) nrec = 1u + d.morph[id - 1].dup;
+                    } else {
+                        const uint2 w = *(const uint2 *)(mbuf + 2 * (lane * WMAXM + m));
+                        id = w.x; nch = w.y & 255u; nrec = w.y >> 8;
+                    }
+                    for (uint32_t r = 0; r < nrec; ++r) put((int32_t)(id + r), lane + nch);
+                }
+                if (span) for (uint32_t r = 0; r < ucnt; ++r) put(-(int32_t)(ufirst + r), lane + span);
+            }
+            if (nw > nwc && lane == nwc) {  // EOS: Morph(0,0,0), its dp goes to the sink slot
+                const uint32_t t = nb[lane];
+                nSid[t] = 0; nStart[t] = (uint16_t)lane; nLeft[t] = (uint16_t)0x7FFF;
+            }
+            wave_sync();
+            // -- seeds into their buckets: carried entries, then the staged FIFO entries
+            for (uint32_t k = lane; k < ncarry; k += 64) {
+                const uint32_t rel = crel(ncarry)[k];
+                const uint32_t slot = boff[rel] + atomicAdd(&bfill[rel], 1u);
+                bk[slot] = carry8(ncarry)[k];  // (its node index is already relative to this window's base)
+            }
+            for (uint32_t f = fhead + lane; f < fhead + fin; f += 64) {
+                const Far e = *far_rec(f);
+                const uint32_t rel = e.end - w0;
+                if (wideN[rel] == 0) {
+                    const uint32_t slot = boff[rel] + atomicAdd(&bfill[rel], 1u);
+                    bk[slot] = make_uint2((uint32_t)e.dp, (e.right & 0xFFFFu) | ((e.node - rb) << 16));
+                }
+            }
+            // -- emit 3b (lane = node): morph record, bucket slot
+            for (uint32_t t0 = 0; t0 < N; t0 += 256) {
+                uint32_t tt[4], ee[4];
+                Morph8 mm[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    tt[k] = t0 + 64 * k + lane;
+                    const bool v = tt[k] < N;
+                    const int32_t sid = v ? nSid[tt[k]] : 1;
+                    ee[k] = v ? nLeft[tt[k]] : 0u;
+                    mm[k] = sid == 0 ? Morph8{(int16_t)d.eos_left, 0, 0, 0} : *(sid > 0 ? d.morph + (sid - 1) : d.unk_morph + (-sid - 1));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (tt[k] < N) {
+                        uint32_t slot;
+                        if (ee[k] == 0x7FFFu) slot = Nb + NF;                                   // EOS: the sink
+                        else if (ee[k] & 0x8000u) slot = Nb + (ee[k] & 0x7FFFu);                 // ends beyond the LDS buckets: a far-out slot
+                        else slot = boff[ee[k]] + atomicAdd(&bfill[ee[k]], 1u);
+                        nLeft[tt[k]] = (uint16_t)mm[k].left; nCS[tt[k]] = (uint32_t)(uint16_t)mm[k].cost | (slot << 16);
+                        bk[slot] = make_uint2((uint32_t)INF, rword((uint32_t)(uint16_t)mm[k].right) | ((gw + tt[k] - rb) << 16));
+                    }
+                }
+            }
+            wave_sync();
+
+            KW_T(5);
+            // -- gather + sweep, block by block (the pool kernel's step: kgpu_pool.hip)
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(KW_LDS(uint8_t) *)lds;
+            const uint32_t a_ncs = bcast32(lds0 + (uint32_t)((uint8_t *)nCS - lds)), a_bk = bcast32(lds0 + (uint32_t)((uint8_t *)bk - lds));
+            const uint32_t a_mp = bcast32(lds0 + (uint32_t)((uint8_t *)mpair - lds)), a_pre = bcast32(lds0 + (uint32_t)((uint8_t *)pre - lds));
+            uint32_t qa = 0;
+            while (qa < nw) {
+                const uint32_t ql = qa + lane;
+                const bool inq = ql < nw;
+                const uint32_t nb0 = nb[inq ? ql : nw], nb1 = nb[inq ? ql + 1 : nw], eb_l = ebase[inq ? ql : nw], eb1 = ebase[inq ? ql + 1 : nw];
+                const uint32_t tA = bcast32(nb0), eb0 = bcast32(eb_l);
+                const uint64_t fits = __ballot(inq && (lane == 0 || (nb1 - tA <= 64u && eb1 - eb0 <= mcap)));
+                const uint32_t nq = ~fits ? (uint32_t)__ffsll((unsigned long long)~fits) - 1u : 64u;
+                const uint32_t qb = qa + nq;
+                const uint32_t ta = tA, tb = bcast32(nb[qb]);
+                for (uint32_t t = ta + lane; t < tb; t += 64) {   // gather M[right(j)][left(t)] of the block's pairs (connection.rs:12-14)
+                    const uint32_t q = nStart[t];
+                    const uint32_t p0 = boff[q], P = boff[q + 1] - p0;
+                    const uint32_t ti = t - nb[q];
+                    const uint32_t base = ebase[q] - eb0 + ti * P;
+                    const uint32_t L = nLeft[t];
+                    const int16_t *col = tiled ? d.conn_tiled + ((size_t)(L >> 3) * d.conn_rt64 + (L & 7u) * 8u) : d.conn + (size_t)d.conn_rows * L;
+                    for (uint32_t j = 0; j < P; j += 8) {
+                        const uint32_t j1 = min(j + 1, P - 1), j2 = min(j + 2, P - 1), j3 = min(j + 3, P - 1);
+                        const bool more = j + 4 < P;
+                        const uint32_t j4 = j + 4, j5 = min(j + 5, P - 1), j6 = min(j + 6, P - 1), j7 = min(j + 7, P - 1);
+                        const uint32_t r0 = bk[p0 + j].y & 0xFFFFu, r1 = bk[p0 + j1].y & 0xFFFFu, r2 = bk[p0 + j2].y & 0xFFFFu, r3 = bk[p0 + j3].y & 0xFFFFu;
+                        uint32_t r4 = 0, r5 = 0, r6 = 0, r7 = 0;
+                        if (more) { r4 = bk[p0 + j4].y & 0xFFFFu; r5 = bk[p0 + j5].y & 0xFFFFu; r6 = bk[p0 + j6].y & 0xFFFFu; r7 = bk[p0 + j7].y & 0xFFFFu; }
+                        const int16_t c0 = col[r0], c1 = col[r1], c2 = col[r2], c3 = col[r3];
+                        int16_t c4 = 0, c5 = 0, c6 = 0, c7 = 0;
+                        if (more) { c4 = col[r4]; c5 = col[r5]; c6 = col[r6]; c7 = col[r7]; }
+                        mpair[base + j] = c0; mpair[base + j1] = c1; mpair[base + j2] = c2; mpair[base + j3] = c3;
+                        if (more) { mpair[base + j4] = c4; mpair[base + j5] = c5; mpair[base + j6] = c6; mpair[base + j7] = c7; }
+                    }
+                }
+                wave_sync();
+                KW_T(6);
+                {
+                    uint32_t dT = 0, dP = 0, dt0 = 0, d0 = 1u << 31, d1 = 0, d2 = 0;
+                    if (lane < nq) {
+                        dt0 = nb0;
+                        const uint32_t dp0 = boff[ql], deb = eb_l - eb0;
+                        dT = nb1 - dt0;
+                        dP = boff[ql + 1] - dp0;
+                        const bool fastq = dP <= 32 && dT - 1u < 127u && wideN[ql] == 0;
+                        d0 = (a_ncs + 4 * dt0) | (fastq ? (dT << 18) | (dP << 25) : 1u << 31);
+                        d1 = a_bk + 8 * dp0;
+                        d2 = a_mp + 2 * deb;
+                    }
+                    for (uint32_t r = 0; r < nq; ++r) {
+                        const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)r);
+                        const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)r);
+                        const uint32_t D2 = (uint32_t)__builtin_amdgcn_readlane((int)d2, (int)r);
+                        if (!(D0 >> 31)) {
+                            const uint32_t acs = D0 & 0x3FFFFu, T = (D0 >> 18) & 127u, P = D0 >> 25;
+                            const uint32_t apre = a_pre + ((acs - a_ncs) >> 1);
+                            auto pass = [&](auto LGc, uint32_t tbb) {
+                                constexpr uint32_t LG = decltype(LGc)::value, G = 1u << LG;
+                                const uint32_t j = lane & (G - 1u), ti = min(tbb + (lane >> LG), T - 1u);
+                                const bool j0v = j < P, j1v = j + G < P;
+                                const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
+                                const uint2 e0 = lds_ld2(D1 + 8 * j), e1 = lds_ld2(D1 + 8 * j + 8 * G);
+                                const uint32_t am = D2 + 2 * (__umul24(ti, P) + j);
+                                const int32_t pc0 = lds_ld<int16_t>(am), pc1 = lds_ld<int16_t>(am + 2 * G);
+                                __builtin_amdgcn_sched_barrier(0);
+                                constexpr int32_t ABSENT = 0x7FFEFFFF;
+                                const int32_t v0 = j0v ? (int32_t)e0.x + pc0 : ABSENT;
+                                const int32_t v1 = j1v ? (int32_t)e1.x + pc1 : ABSENT;
+                                const int32_t vmin = wmin_i32<LG>(min(v0, v1));
+                                const uint32_t n0 = v0 == vmin ? e0.y : 0xFFFFFFFFu, n1 = v1 == vmin ? e1.y : 0xFFFFFFFFu;
+                                const uint32_t nmin = wmin_u32<LG>(min(n0, n1));
+                                const int32_t tot = vmin + (int32_t)(int16_t)cs;
+                                const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
+                                lds_st<uint16_t>(apre + 2 * ti, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
+                                lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
+                            };
+                            auto pass1 = [&](uint32_t tbb) {  // P <= 8: one candidate per lane
+                                const uint32_t j = lane & 7u, ti = min(tbb + (lane >> 3), T - 1u);
+                                const bool j0v = j < P;
+                                const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
+                                const uint2 e0 = lds_ld2(D1 + 8 * j);
+                                const int32_t pc0 = lds_ld<int16_t>(D2 + 2 * (__umul24(ti, P) + j));
+                                __builtin_amdgcn_sched_barrier(0);
+                                const int32_t v0 = j0v ? (int32_t)e0.x + pc0 : 0x7FFEFFFF;
+                                const int32_t vmin = wmin_i32<3>(v0);
+                                const uint32_t nmin = wmin_u32<3>(v0 == vmin ? e0.y : 0xFFFFFFFFu);
+                                const int32_t tot = vmin + (int32_t)(int16_t)cs;
+                                const bool ok = tot < INF;
+                                lds_st<uint16_t>(apre + 2 * ti, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
+                                lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
+                            };
+                            if (P <= 8) {
+                                pass1(0u);
+                                if (T > 8) for (uint32_t tbb = 8; tbb < T; tbb += 8) pass1(tbb);
+                            } else if (P <= 16) {
+                                pass(std::integral_constant<uint32_t, 3>{}, 0u);
+                                if (T > 8) for (uint32_t tbb = 8; tbb < T; tbb += 8) pass(std::integral_constant<uint32_t, 3>{}, tbb);
+                            } else {
+                                for (uint32_t tbb = 0; tbb < T; tbb += 4) pass(std::integral_constant<uint32_t, 4>{}, tbb);
+                            }
+                        } else {
+                            // any shape, and the streamed (wide) positions: one target at a time, the lanes split its predecessors;
+                            // key = (total, node index) -- strict '<' over ascending insertion order (lattice.rs:125,136)
+                            const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)dT, (int)r);
+                            const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)dP, (int)r);
+                            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)dt0, (int)r);
+                            const uint32_t p0 = (D1 - a_bk) >> 3, eb = (D2 - a_mp) >> 1;
+                            const uint32_t q = qa + r;
+                            const uint32_t wn = wideN[q], wlo = fcnt[q];
+                            for (uint32_t tg = 0; tg < T; tg += 8) {  // eight targets share every load of a predecessor
+                                const uint32_t nt8 = min(8u, T - tg);
+                                uint64_t key[8];
+                                const int16_t *col[8];
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) {
+                                    key[k] = ~0ull;
+                                    const uint32_t L = nLeft[t0 + tg + min((uint32_t)k, nt8 - 1)];
+                                    col[k] = tiled ? d.conn_tiled + ((size_t)(L >> 3) * d.conn_rt64 + (L & 7u) * 8u) : d.conn + (size_t)d.conn_rows * L;
+                                }
+                                for (uint32_t jj = lane; jj < P; jj += 64) {
+                                    const uint2 e = bk[p0 + jj];
+                                    const uint32_t gi = rb + (e.y >> 16);
+#pragma unroll
+                                    for (int k = 0; k < 8; ++k)
+                                        if ((uint32_t)k < nt8) {
+                                            const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + (tg + k) * P + jj];
+                                            const uint64_t ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | gi;
+                                            key[k] = ck < key[k] ? ck : key[k];
+                                        }
+                                }
+                                for (uint32_t f = wlo + lane; f < wlo + wn; f += 64) {
+                                    const Far e = *far_rec(f);
+                                    const uint32_t r = e.right & 0xFFFFu;
+                                    int32_t cc[8];
+#pragma unroll
+                                    for (int k = 0; k < 8; ++k) cc[k] = (uint32_t)k < nt8 ? (int32_t)col[k][r] : 0;
+#pragma unroll
+                                    for (int k = 0; k < 8; ++k)
+                                        if ((uint32_t)k < nt8) {
+                                            const int32_t v = e.dp + cc[k];
+                                            const uint64_t ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | e.node;
+                                            key[k] = ck < key[k] ? ck : key[k];
+                                        }
+                                }
+#pragma unroll
+                                for (int k = 0; k < 8; ++k)
+                                    if ((uint32_t)k < nt8) {
+                                        const uint64_t kk = wmin_u64_all(key[k]);
+                                        if (lane == 0) {
+                                            const uint32_t cs = nCS[t0 + tg + k];
+                                            int32_t dpv = INF; uint32_t prv = NONE16;
+                                            if (kk != ~0ull) {
+                                                const int32_t tot = (int32_t)((uint32_t)(kk >> 32) ^ 0x80000000u) + (int32_t)(int16_t)cs;
+                                                if (tot < INF) { dpv = tot; prv = (uint32_t)kk - rb; }
+                                            }
+                                            pre[t0 + tg + k] = (uint16_t)prv;
+                                            bk[cs >> 16].x = (uint32_t)dpv;
+                                        }
+                                    }
+                                wave_sync();
+                            }
+                            wave_sync();
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                wave_sync();
+                KW_T(7);
+                qa = qb;
+            }
+
+            // -- flush: node records to HBM, far-out entries to the FIFO, the buckets beyond the window to the carry list
+            if (!chunk_get(nchunk, nchunks_have, (gw + N - 1) >> NCH_LOG, sizeof(NodeRec) << NCH_LOG)) { failed = true; why = 3; break; }
+            for (uint32_t t = lane; t < N; t += 64) {
+                const uint32_t p = pre[t], st = nStart[t];
+                NodeRec rec;
+                rec.pre = p == NONE16 ? NONE : rb + p;
+                rec.sid = nSid[t];
+                rec.start = w0 + st;
+                rec.bstart = st <= nwc ? cbw[st] : B;
+                *node_rec(gw + t) = rec;
+                if (rec.sid == 0 && w0 + st == C) eos_pre = rec.pre;  // (only EOS has sid 0: BOS is never a target)
+            }
+            if (nw > nwc) eos_pre = bcast32((uint32_t)__shfl((int)eos_pre, (int)((N - 1) & 63u), 64));  // the lane that wrote node N - 1
+            if (NF) {
+                if (NF > ((FCHUNKS - 1) << FCH_LOG) - (ftail - fhead)) { failed = true; why = 4; break; }
+                if (!chunk_get(fchunk, fchunks_have, min((ftail + NF - 1) >> FCH_LOG, FCHUNKS - 1), sizeof(Far) << FCH_LOG)) { failed = true; why = 5; break; }
+                uint32_t fbad = 0;
+                for (uint32_t k = lane; k < NF; k += 64) {
+                    const uint2 e = bk[Nb + k];
+                    const uint32_t en = farEnd[k], prev = k ? farEnd[k - 1] : last_far_end;
+                    if (en < prev) fbad = 1;  // the FIFO lives on non-decreasing ends
+                    *far_rec(ftail + k) = Far{en, (int32_t)e.x, e.y & 0xFFFFu, rb + (e.y >> 16)};
+                }
+                if (__ballot(fbad != 0) != 0) { failed = true; why = 6; break; }
+                last_far_end = bcast32(farEnd[NF - 1]);
+                ftail += NF;
+            }
+            fhead += fin;
+            {
+                const uint32_t c0 = boff[nw], nc = Nb - c0;
+                const uint32_t gnext = gw + N, rbn = gnext >= 0x8000u ? gnext - 0x8000u : 0u;  // the next window's base
+                uint2 *c8 = carry8(nc);
+                uint8_t *cr = crel(nc);
+                uint32_t cbad = 0;
+                // lanes over the relative positions nw .. 2 WIN: the carried slots of each, re-based
+                for (uint32_t rel = nw + lane; rel <= 2 * WIN; rel += 64)
+                    for (uint32_t sl = boff[rel]; sl < boff[rel + 1]; ++sl) {
+                        const uint2 e = bk[sl];
+                        const uint32_t g = rb + (e.y >> 16);
+                        if (g < rbn) cbad = 1;
+                        c8[sl - c0] = make_uint2(e.x, (e.y & 0xFFFFu) | ((g - rbn) << 16));
+                        cr[sl - c0] = (uint8_t)(rel - nw);
+                    }
+                if (__ballot(cbad != 0) != 0) { failed = true; why = 7; break; }
+                ncarry = nc;
+            }
+            wlim = min(WIN, wlim * 2);
+            wT += wTw; wE += wEw;
+            wbyte0 = wbyte_next;
+            wave_sync();  // (no wait for the stores: what a window writes to HBM is read two windows later at the earliest -- FIFO entries end beyond the next window)
+            KW_T(8);
+            gw += N;
+            w0 += nw;
+        }
+        if (failed) { fail(s); if (lane == 0 && !a.count_work) atomicAdd(&a.ctl->phase[why < 10 ? why : 9], 1ull); __syncthreads(); continue; }
+
+        // ---- backtrace (lattice.rs:144-153): chase `pre` through windows of node records staged in LDS ----
+        KW_T(8);
+        const uint32_t Ntot = gw;  // BOS + every node; EOS is node Ntot - 1
+        uint32_t K = 0;
+        {
+            uint32_t *win = (uint32_t *)(lds + off0);
+            const uint32_t Wn = (lds_bytes - off0) / 4;
+            uint32_t pos = Ntot - 1, pr_first = eos_pre;
+            bool done = pr_first == NONE;  // EOS unreachable: empty Vec (lattice.rs:144-153)
+            if (!done && lane == 0) path[0] = pos;
+            if (!done) { K = 1; pos = pr_first; }
+            while (!done) {
+                // pos: the node whose record is needed next (a predecessor always has a smaller index)
+                const uint32_t wlo = pos >= Wn - 1 ? pos - (Wn - 1) : 0;
+                for (uint32_t i = wlo + lane; i <= pos; i += 64) win[i - wlo] = i ? node_rec(i)->pre : NONE;
+                wave_sync();
+                uint32_t npos = pos, nK = K, fin2 = 0;
+                if (lane == 0) {
+                    for (;;) {
+                        const uint32_t pr = win[npos - wlo];
+                        if (pr == NONE || nK > C) { fin2 = 1; break; }  // the chain's first node (normally BOS) is dropped
+                        path[nK++] = npos;
+                        npos = pr;
+                        if (npos < wlo) break;
+                    }
+                }
+                pos = bcast32(npos); K = bcast32(nK); done = bcast32(fin2) != 0;
+                wave_sync();
+            }
+        }
+        K = bcast32(K);
+        const uint64_t ts = b0 - a.offsets[0] + s;
+        __syncthreads();
+        for (uint32_t k = lane; k < K; k += 64) {  // Node -> Token (tokenizer.rs:22-43); a word ends where its successor starts
+            const NodeRec r = *node_rec(path[K - 1 - k]);
+            kgpu_token tk;
+            if (r.sid == 0) { tk.id = 0; tk.cls = KGPU_CLASS_DUMMY; tk.position = B; tk.start = C; tk.end = C + 3; tk.byte_len = 0; }
+            else {
+                const NodeRec nx = *node_rec(path[K - 2 - k]);
+                tk.id = r.sid > 0 ? r.sid : -r.sid;
+                tk.cls = r.sid > 0 ? KGPU_CLASS_KNOWN : KGPU_CLASS_UNKNOWN;
+                tk.position = r.bstart; tk.start = r.start; tk.end = nx.start; tk.byte_len = nx.bstart - r.bstart;
+            }
+            a.stage[ts + k] = tk;
+        }
+        if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; }
+        KW_T(9);
+        if (a.count_work) {
+            wT = wave_sum(wT); wE = wave_sum(wE);
+            accW[0] += 1; accW[1] += B; accW[2] += C; accW[3] += wT; accW[4] += Ntot - 1; accW[5] += wE; accW[6] += K;
+        }
+        __syncthreads();
+    }
+    if (a.count_work && lane == 0) {
+        for (int k = 0; k < 7; ++k) atomicAdd(&a.ctl->work[k], (unsigned long long)accW[k]);
+        for (int k = 0; k < 10; ++k) atomicAdd(&a.ctl->phase[k], (unsigned long long)tph[k]);
+    }
+}
+
+int window_workgroups_per_cu(uint32_t lds_bytes) {
+    if (lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)k_tokenize_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return 0;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_window, 64, (size_t)lds_bytes) != hipSuccess) return 0;
+    return n;
+}
+
+int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, void *stream) {
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k_tokenize_window, dim3((unsigned)n_workgroups), dim3(64), lds_bytes, (hipStream_t)stream, d, a, io, lds_bytes);
+    return (int)hipGetLastError();
+}
+
+}  // namespace kgpu
