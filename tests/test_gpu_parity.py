@@ -563,3 +563,22 @@ def test_large_host_call_chunk_byte_counts(small):
         sents = body + [last] + ["い" * 30 + "b"] * 200
         assert sum(len(x.encode()) for x in sents[:2048]) == 2 * 262144 + 1 + extra
         assert_same(tok, orc, sents)
+
+
+@pytest.mark.parametrize("window_kib,pool", [("12", "40:4:48"), ("16", "40:4:48"), ("16", "0"), ("24", "16:4:8")])
+def test_windowed_long_sentence_kernel(libs, window_kib, pool, monkeypatch):
+    """The experimental windowed kernel (kgpu_window.hip, KGPU_WINDOW = KiB of LDS per workgroup; off by default): the lattice of a long
+    sentence is built and relaxed window by window, only the carry list / the far FIFO / 16 bytes per node outlive a window
+    (src/lattice.rs:101-154).  What it cannot hold is rerun through the HBM-lattice kernel -- same records either way."""
+    from kanpyo_amd import Tokenizer, synth
+
+    _, oracle = libs
+    monkeypatch.setenv("KGPU_WINDOW", window_kib)
+    monkeypatch.setenv("KGPU_POOL", pool)
+    sd = synth.build_dict(20000, seed=11)
+    tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
+    sents = (synth.make_corpus(sd, 1500, 3, "cfg2") + synth.make_corpus(sd, 1200, 4, "cfg3") + synth.make_corpus(sd, 6, 6, "cfg5")
+             + ["", "あ", "ア" * 1500, "1" * 1025, "𠮷野家" * 40, "漢" * 300, "x" * 1023 + "あ"])
+    for _ in range(2):
+        assert_same(tok, orc, sents)
+    assert_same(tok, orc, ["", "", "すもも", ""])

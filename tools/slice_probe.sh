@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the library built with other occupancy targets next to the default one:
+#   cd kanpyo_amd/csrc && for w in 5 6; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DKGPU_POOL_WPE=$w -shared -o ../libkanpyo_gpu_w$w.so kgpu_kernels.hip kgpu_pool.hip kgpu_window.hip kgpu_api.cpp kgpu_index_build.cpp; done
 # fixed LDS slices (one wavefront per workgroup, no page pool) against the shared pools; any-order launches -> gpurun_out/slice_probe.txt
 mkdir -p gpurun_out
 OUT=gpurun_out/slice_probe.txt; : > $OUT
