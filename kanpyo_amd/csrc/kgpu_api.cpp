@@ -1001,7 +1001,7 @@ static int pipe_finish(PipeJob &j, const uint8_t *utf8, const uint64_t *offsets,
     const uint32_t *first = (const uint32_t *)(ph + j.off_first);
     const uint64_t *toff = (const uint64_t *)(ph + j.off_toff);
     const uint8_t *st = ph + j.off_status;
-    constexpr uint64_t SLICE = 2048;
+    const uint64_t SLICE = std::min<uint64_t>(2048, std::max<uint64_t>(256, j.m / 8));  // (a lone 4096-sentence call: eight slices, not two)
     const int nt = (int)((j.m + SLICE - 1) / SLICE);
     if (nt == 0) { if (!overflow) tok_offsets[j.lo] = tok_base; return KGPU_OK; }
     j.tasks.store(nt, std::memory_order_release);

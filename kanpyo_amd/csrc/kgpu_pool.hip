@@ -316,7 +316,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                 lensum += l;
                 cbyte[ci] = (uint16_t)k;
                 cp16[ci] = (uint16_t)(cp < 0xFFFFu ? cp : 0xFFFFu);
-                ccat[ci] = bad ? 0 : (cp < d.cat_len ? d.cat[cp] : d.cat[0]);  // char_category_def.rs:33-38
+                // the category of a BMP character is loaded with the walk's first loads (phase 1), not here: this phase then has no
+                // exposed trip to the category table.  Only what cp16 cannot name (non-BMP -> table[0], and U+FFFF) is looked up now.
+                if (cp >= 0xFFFFu) ccat[ci] = bad ? 0 : (cp < d.cat_len ? d.cat[cp] : d.cat[0]);  // char_category_def.rs:33-38
             }
             cb += __popcll(m);
         }
@@ -340,14 +342,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             for (int ch = nchunks - 1; ch >= 0; --ch) {
                 const uint32_t i = (uint32_t)ch * 64 + lane;
                 const bool active = i < C;
-                const uint32_t cat = active ? ccat[i] : 0x1FFu;
-                const uint32_t ncat = (i + 1 < C) ? ccat[i + 1] : 0x2FFu;
-                const uint64_t bm = __ballot(active && ncat != cat);
-                const uint64_t rest = bm >> lane;
-                const uint32_t run_end = rest ? i + (uint32_t)__ffsll((unsigned long long)rest) : carry_end;
-                carry_end = bcast32(run_end);
+                // categories (char_category_def.rs:33-38) of this character and of the next: requested here, consumed after the walk
+                const uint32_t cpi = active ? cp16[i] : 0u, cpn = (i + 1 < C) ? cp16[i + 1] : 0u;
+                uint32_t cat = 0x1FFu, ncat = 0x2FFu;
+                if (active) cat = cpi != 0xFFFFu ? (cpi < d.cat_len ? d.cat[cpi] : d.cat[0]) : ccat[i];
+                if (i + 1 < C) ncat = cpn != 0xFFFFu ? (cpn < d.cat_len ? d.cat[cpn] : d.cat[0]) : ccat[i + 1];
+                uint32_t cnt = 0, m = 0;
                 if (active) {
-                    uint32_t cnt = 0, m = 0;
                     auto on_match = [&](uint32_t id, uint32_t nch, uint32_t dup) {
                         const uint32_t nrec = 1u + (dup != NONE ? dup : (uint32_t)d.morph[id - 1].dup);  // index.rs:46-51
                         if (m < MAXM && nch < 256) {
@@ -358,8 +359,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                         cnt += nrec;
                         atomicAdd(&boff[i + nch], nrec);
                     };
-                    wT += da_walk_first(d, text, cp16[i], cbyte[i], cbyte[i + 1], B, base_root, on_match);
+                    wT += da_walk_first(d, text, cpi, cbyte[i], cbyte[i + 1], B, base_root, on_match);
                     mcnt[i] = (uint8_t)(m < MAXM ? m : MAXM);
+                    ccat[i] = (uint8_t)cat;  // (the emit phase's fallback reads it)
+                }
+                const uint64_t bm = __ballot(active && ncat != cat);
+                const uint64_t rest = bm >> lane;
+                const uint32_t run_end = rest ? i + (uint32_t)__ffsll((unsigned long long)rest) : carry_end;
+                carry_end = bcast32(run_end);
+                if (active) {
                     const CatInfo ci = d.cinfo[cat];
                     uint32_t span = 0;
                     if ((cnt == 0 || (ci.flags & CAT_INVOKE)) && (ci.flags & CAT_HAS_UNK) && ci.unk_count) {  // lattice.rs:54,87-92
