@@ -613,8 +613,6 @@ def main():
         per_rank = [{"rank": r, "sentences": int(x[0].item()), "seconds": float(x[1].item()),
                      "sentences_per_s": float(x[0].item()) / max(float(x[1].item()), 1e-9)} for r, x in enumerate(allr)]
 
-    if extras_dir:
-        open(os.path.join(extras_dir, "go"), "w").close()  # the corpus generator may have its core now
     prof = {"launches": 0, "tokenize_ms": 0.0, "first_ms": 0.0, "aux_ms": 0.0, "batches": 0, "sentences": 0, "deferred": [0] * 4, "redone": [0] * 4,
             "long_launches": 0, "arena_regrows": 0}
     for c in eng.ctxs:
@@ -839,6 +837,9 @@ def main():
             result["value_end_to_end"] = {"value": max(result["pcie_inclusive"]["large_call_pageable"], result["pcie_inclusive"]["large_call_pinned"]),
                                           "unit": "sentences/s", "what": "SURVEY 8(d) end-to-end incl. H2D / D2H: the better of pcie_inclusive.large_call_{pageable,pinned}; "
                                                                          "`value` is the device-resident rate"}
+
+    if extras_dir:  # the corpus generator (a pure-Python loop on one core) starts only now: the host-side legs above share the box's CPU quota with nothing
+        open(os.path.join(extras_dir, "go"), "w").close()
 
     # ---- CPU baseline (rank 0, N==1 only): the oracle restatement on the host cores, every sentence tokenized once
     if world == 1 and not args.no_cpu:
