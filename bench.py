@@ -143,8 +143,12 @@ class GpuEngine:
                       torch.empty(wl.batch, dtype=torch.uint8, device=dev)) for b in range(nbmax)] for r in range(ring)]
         # compact: the firsts of a step's batches, rows of one tensor like the offsets ([batch, sentence, (position, start)])
         self.first3d = [torch.zeros((nbmax, wl.batch, 2), dtype=torch.int32, device=dev) for _ in range(ring)] if compact else None
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, min(streams, self.Q)))]
-        self.ctxs = [DeviceContext(tok, self.streams[i % len(self.streams)].cuda_stream) for i in range(self.Q)]
+        # streams = 0: the contexts share the dictionary's own streams (kgpu_ctx_create with a NULL stream: four with GPU_MAX_HW_QUEUES >= 5,
+        # else three) -- what a single-GPU caller should do: every further stream in the process competes for the hardware queues (four idle
+        # torch streams next to the library's cost a large host call 61 -> 50 M sentences/s, tools/e2e_probe.py PROBE_ENG).  The multi-rank path
+        # needs torch streams: it orders them behind the gather's events.
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, min(streams, self.Q)))] if streams > 0 else []
+        self.ctxs = [DeviceContext(tok, self.streams[i % len(self.streams)].cuda_stream if self.streams else None) for i in range(self.Q)]
         self.seq, self.occupant, self.where, self.ntok = 0, [None] * self.Q, {}, {}
 
     def nb(self, step):
@@ -492,7 +496,7 @@ def main():
     tok = Tokenizer(sd.dict, device=local_rank)
     cs = chunk_steps_for(wl.nb(0))
     compact = multi and args.gather_records == 8
-    eng = GpuEngine(tok, dev, wl, queue=args.queue, streams=args.streams, ring=3 * cs if multi else 1, compact=compact)
+    eng = GpuEngine(tok, dev, wl, queue=args.queue, streams=args.streams if multi else 0, ring=3 * cs if multi else 1, compact=compact)
     Q = eng.Q
 
     # ---- untimed: device-side work counters of every distinct batch of corpus 0 (algorithmic bytes)
@@ -539,7 +543,7 @@ def main():
                 n0 = len(corpora[0])
                 tok_np, cnt_np = expand_gathered(tok_np, cnt_np, sizes_all, [[(n0 - r + world - 1) // world] for r in range(world)])
             g_tok, g_off = reassemble(tok_np, cnt_np, len(corpora[0]), world)
-            full = GpuEngine(tok, dev, Workload(corpora[:1], 0, 1), queue=2, streams=1, ring=1)
+            full = GpuEngine(tok, dev, Workload(corpora[:1], 0, 1), queue=2, streams=0, ring=1)
             for b in range(full.nb(0)):
                 full.enqueue(0, b)
             fv, fc = full.results(0)
@@ -557,7 +561,7 @@ def main():
     one_gpu = None
     if world > 1 and not args.no_one_gpu_leg:
         if rank == 0:
-            eng1 = GpuEngine(tok, dev, Workload(corpora, 0, 1), queue=args.queue, streams=args.streams, ring=1)
+            eng1 = GpuEngine(tok, dev, Workload(corpora, 0, 1), queue=args.queue, streams=0, ring=1)
             run_job(eng1, max(2, min(W, 5)))
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -916,7 +920,7 @@ def main():
                 # cfg 3 names no batch size (BASELINE configs[2]): batches of 16384 -- a launch lasts as long as its longest sentence, and with one
                 # sentence per wavefront slot (4096) a few 500-char sentences decide a launch whose average is 120 (12.8 vs 15.6 M sentences/s)
                 wl_x = PackedWorkload(u, o, batch=16384 if kind == "cfg3" else BATCH)
-                extra.append(measure_config(tok, dev, wl_x, n_chars, passes, args.queue, args.streams, lab, orc=extras_orc))
+                extra.append(measure_config(tok, dev, wl_x, n_chars, passes, args.queue, 0, lab, orc=extras_orc))
             except Exception as e:
                 print(f"{kind} leg failed: {e}", file=sys.stderr)
         result["extra"] = extra

@@ -10,6 +10,15 @@ reps_c = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 pinned = len(sys.argv) > 2 and sys.argv[2] == "pinned"
 sd = synth.build_dict(); corpus = synth.make_corpus(sd, 100_000, 1, "cfg2")
 tok = Tokenizer(sd.dict)
+keep = []
+if os.environ.get("PROBE_ENG"):  # what bench.py has alive when it times its large calls: eight device contexts on four torch streams (+ a 4 GiB tensor)
+    from kanpyo_amd.device import DeviceContext
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    keep = [streams, [DeviceContext(tok, streams[i % 4].cuda_stream) for i in range(8)]]
+    if os.environ["PROBE_ENG"] == "2":
+        for c in keep[1]: c.close()
+        keep = [streams]
 u1, o1 = pack_sentences(corpus)
 n = reps_c * len(corpus)
 ua = np.tile(u1, reps_c)
