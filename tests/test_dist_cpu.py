@@ -251,3 +251,85 @@ def test_bench_chunking_rule():
     import bench
 
     assert [bench.chunk_steps_for(nb) for nb in (25, 13, 7, 4, 1)] == [1, 1, 2, 3, 12]
+
+
+class _CompactOracleEngine(_OracleEngine):
+    """The same stand-in with bench.GpuEngine(compact=True)'s protocol: 8-byte kgpu_token8 rows [k, 2] and, behind the counts,
+    the first token's (position, start) of every sentence as one int64 each (include/kanpyo_gpu.h: kgpu_token8)."""
+
+    def results(self, step):
+        import torch
+
+        views, counts, firsts = [], [], []
+        for b in range(self.nb(step)):
+            r = self.done.pop((step, b))
+            t = r.tokens
+            packed = (t["cls"] | ((t["end"] - t["start"]) << 2) | (t["byte_len"] << 14)).astype(np.uint32)
+            t8 = np.stack([t["id"].astype(np.int32).view(np.uint32), packed], axis=1).view(np.int32)
+            cnt = (r.offsets[1:] - r.offsets[:-1]).astype(np.int64)
+            first = np.full((len(cnt), 2), 0xFFFFFFFF, dtype=np.uint32)
+            has = cnt > 0
+            at = r.offsets[:-1][has].astype(np.int64)
+            first[has, 0], first[has, 1] = t["position"][at], t["start"][at]
+            views.append(torch.from_numpy(np.ascontiguousarray(t8)))
+            counts.append(torch.from_numpy(cnt))
+            firsts.append(torch.from_numpy(first.view(np.int64).reshape(-1).copy()))
+        return views, torch.cat(counts + firsts) if counts else torch.zeros(0, dtype=torch.int64)
+
+
+def _worker_compact_job(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import bench
+    from kanpyo_amd import synth
+    from kanpyo_amd.dist import ChunkedGather, reassemble
+    from kanpyo_amd.tokenizer import pack_sentences
+    from oracle import oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sd = synth.build_dict(6000, seed=5)
+    corpora = [synth.make_corpus(sd, 300 + 11 * k, 100 + k, "cfg2") + (["", "あ"] if k == 0 else []) for k in range(2)]
+    orc = oracle.OracleTokenizer.from_dict(sd.dict)
+    # one batch per step: the engine's layout [counts of the step | firsts of the step] is what bench.expand_gathered slices
+    wl = bench.Workload(corpora, rank, world, batch=4096)
+    ok = True
+    for chunk_steps, nsteps in ((1, 2), (2, 4)):
+        chunks = {}
+        bench.run_job(_CompactOracleEngine(orc, wl), nsteps, ChunkedGather(dst=0), chunk_steps, lambda c0, r: chunks.__setitem__(c0, r))
+        if rank != 0:
+            continue
+        for c0, (tok8_all, cnt2_all, sizes) in chunks.items():
+            steps = list(range(c0, min(c0 + chunk_steps, nsteps)))
+            per_rank = [[(len(corpora[s % 2]) - r + world - 1) // world for s in steps] for r in range(world)]
+            tok, cnt = bench.expand_gathered(tok8_all.numpy(), cnt2_all.numpy(), sizes, per_rank)
+            exp_t, exp_c = [], []
+            for r in range(world):
+                for s in steps:
+                    c = corpora[s % 2]
+                    e = orc.tokenize_batch(*pack_sentences([c[i] for i in range(r, len(c), world)]), 1)
+                    exp_t.append(e.tokens.view(np.int32).reshape(-1, 6))
+                    exp_c.append((e.offsets[1:] - e.offsets[:-1]).astype(np.int64))
+            ok = ok and np.array_equal(tok, np.concatenate(exp_t)) and np.array_equal(cnt, np.concatenate(exp_c))
+            if chunk_steps == 1:
+                n = len(corpora[c0 % 2])
+                got_t, got_off = reassemble(tok, cnt, n, world)
+                full = orc.tokenize_batch(*pack_sentences(corpora[c0 % 2]), 1)
+                ok = ok and np.array_equal(got_off.astype(np.uint64), full.offsets) and np.array_equal(got_t.reshape(-1), full.tokens.view(np.int32).reshape(-1))
+    if rank == 0:
+        open(os.path.join(tmpdir, "compactjob"), "w").write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_job_gathers_compact_records_gloo(tmp_path):
+    """bench.py's default wire format for N > 1: 8-byte kgpu_token8 records + firsts behind the counts, gathered chunk by chunk with
+    world size 2 over gloo, expanded on the root by bench.expand_gathered (kgpu_expand_tokens: a host function of the library, no GPU
+    needed) -- the expanded stream equals the oracle's 24-byte records, rank-major, and reassembles to the unsharded corpus's stream."""
+    import torch.multiprocessing as mp
+
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_worker_compact_job, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "compactjob").read() == "ok"
