@@ -473,7 +473,27 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                             *(tv ? &dpT[t0 + ti] : &sink[2]) = dpn;
                             *((tv && sl != 0xFFFFu) ? &dpL[sl] : &sink[0]) = dpn;
                         };
-                        if (Pq <= 16) {
+                        auto pass1 = [&](uint32_t tb) {  // P <= 8 (most positions): one candidate per lane, as in kgpu_pool.hip
+                            const uint32_t j = lane & 7u, ti = tb + (lane >> 3);
+                            const bool tv = ti < Tq, j0v = j < Pq;
+                            const uint32_t cs = csL[t0 + ti];
+                            const uint32_t dp0 = dpL[p0 + j], nd0 = ndL[p0 + j];
+                            const int32_t pc0 = prL[eb + __umul24(ti, Pq) + j];
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int32_t v0 = (tv && j0v) ? (int32_t)dp0 + pc0 : 0x7FFEFFFF;
+                            const int32_t vmin = gmin_i32(v0, 3);
+                            const uint32_t nmin = gmin_u32(v0 == vmin ? nd0 : 0xFFFFFFFFu, 3);
+                            const int32_t tot = vmin + (int32_t)(int16_t)cs;
+                            const bool ok = tot < INF;
+                            const uint32_t dpn = (uint32_t)(ok ? tot : INF), sl = cs >> 16;
+                            *(tv ? &preL[t0 + ti] : &sink[1]) = ok ? nmin : NONE;
+                            *(tv ? &dpT[t0 + ti] : &sink[2]) = dpn;
+                            *((tv && sl != 0xFFFFu) ? &dpL[sl] : &sink[0]) = dpn;
+                        };
+                        if (Pq <= 8) {
+                            pass1(0u);
+                            if (Tq > 8) for (uint32_t tb = 8; tb < Tq; tb += 8) pass1(tb);
+                        } else if (Pq <= 16) {
                             pass(std::integral_constant<uint32_t, 3>{}, 0u);
                             if (Tq > 8) for (uint32_t tb = 8; tb < Tq; tb += 8) pass(std::integral_constant<uint32_t, 3>{}, tb);
                         } else {
