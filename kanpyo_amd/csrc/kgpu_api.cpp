@@ -96,7 +96,7 @@ struct PinBuf {
 // Test-only environment hooks.  getenv is not thread-safe against setenv, and kgpu_tokenize_batch may be called from many
 // threads: the hooks are read under a mutex, ONCE per process -- unless KGPU_TEST_HOOKS_REREAD is set (tests/conftest.py sets
 // it: the tests flip the hooks between calls).
-struct TestHooks { bool no_small_calls = false, legacy_host_path = false; uint64_t chunk_bytes = 4ull << 20, chunk_sents = 16384, depth = 12; };
+struct TestHooks { bool no_small_calls = false, legacy_host_path = false, plain_leaves = false; uint64_t chunk_bytes = 4ull << 20, chunk_sents = 16384, depth = 12; };
 static bool env_flag_now(const char *name) { const char *e = getenv(name); return e && *e && *e != '0'; }
 static TestHooks test_hooks() {
     static std::mutex mu;
@@ -108,6 +108,7 @@ static TestHooks test_hooks() {
         cur = TestHooks{};
         cur.no_small_calls = env_flag_now("KGPU_NO_SMALL_CALLS");
         cur.legacy_host_path = env_flag_now("KGPU_HOST_LEGACY");
+        cur.plain_leaves = env_flag_now("KGPU_PLAIN_LEAVES");
         if (const char *e = getenv("KGPU_HOST_DEPTH")) cur.depth = strtoull(e, nullptr, 10);
         if (const char *e = getenv("KGPU_HOST_CHUNK_BYTES")) cur.chunk_bytes = strtoull(e, nullptr, 10);
         if (const char *e = getenv("KGPU_HOST_CHUNK_SENTS")) cur.chunk_sents = strtoull(e, nullptr, 10);
@@ -395,7 +396,7 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
     // anyway, and the record count of the surface (index.rs:46-51) is the next thing it needs: with ids below 2^21 the spare
     // bits hold it (1023 = larger, look it up), and one dependent load per match disappears from the walk.
     uint32_t leaf_dup = 0;
-    if (morphs.size() < (1u << 21) && !env_flag_now("KGPU_PLAIN_LEAVES") /* tests: the layout of a dictionary with 2^21 morphs or more */) {
+    if (morphs.size() < (1u << 21) && !test_hooks().plain_leaves /* tests: the layout of a dictionary with 2^21 morphs or more */) {
         leaf_dup = 1;
         for (size_t a2 = 0; a2 < da.size(); ++a2) {
             DaNode &nd = da[a2];
