@@ -14,6 +14,7 @@
 #include <deque>
 #include <functional>
 #include <thread>
+#include <unistd.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -890,9 +891,16 @@ static int host_job_finish(HostJob &j, kgpu_token *tokens, uint64_t token_capaci
 // a pageable destination costs anyway) while the next chunks compute.
 struct WorkerPool {
     std::mutex mu; std::condition_variable cv; std::deque<std::function<void()>> q; std::vector<std::thread> th; bool stop = false;
+    pid_t owner = 0;
     void start() {
         std::lock_guard<std::mutex> g(mu);
-        if (!th.empty()) return;
+        if (!th.empty() && owner == getpid()) return;
+        if (!th.empty()) {  // a fork()ed child: the parent's threads do not exist here; forget them (never joined) and start afresh
+            auto *leaked = new std::vector<std::thread>(std::move(th));  // (std::thread objects of threads that do not exist: neither joined nor destroyed)
+            (void)leaked;
+            th.clear(); q.clear();
+        }
+        owner = getpid();
         unsigned n = 0;
         if (const char *e = getenv("KGPU_HOST_THREADS")) n = (unsigned)atoi(e);
         if (n == 0) n = std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 8));
