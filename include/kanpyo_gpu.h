@@ -153,7 +153,10 @@ typedef struct kgpu_plan_info {
     uint32_t long_lds_bytes;          /* long-sentence kernel: LDS per single-wavefront workgroup (sweep blocks)    */
     uint32_t long_workgroups_per_cu;  /* ... resident per CU (occupancy API)                                       */
     uint32_t long_workgroups;         /* ... grid of one launch                                                    */
-    uint32_t reserved[8];
+    uint32_t window_lds_bytes;        /* windowed kernel (very long sentences): LDS per single-wavefront workgroup, 0 = off */
+    uint32_t window_workgroups_per_cu;/* ... resident per CU (occupancy API)                                       */
+    uint32_t window_min_bytes;        /* ... sentences at least this long take it                                  */
+    uint32_t reserved[5];
 } kgpu_plan_info;
 int kgpu_ctx_get_plan(kgpu_ctx *c, kgpu_plan_info *out, size_t out_size);
 

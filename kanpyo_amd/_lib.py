@@ -73,7 +73,7 @@ class Routing(C.Structure):  # kgpu_routing: read with its size, fields are only
 
 class PlanInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("compute_units", "pool_lds_bytes", "pool_wavefronts", "pool_workgroups_per_cu", "pool_max_pages",
-                                          "long_lds_bytes", "long_workgroups_per_cu", "long_workgroups")] + [("reserved", C.c_uint32 * 8)]
+                                          "long_lds_bytes", "long_workgroups_per_cu", "long_workgroups", "window_lds_bytes", "window_workgroups_per_cu", "window_min_bytes")] + [("reserved", C.c_uint32 * 5)]
 
 
 class LatticeNode(C.Structure):

@@ -135,6 +135,7 @@ struct kgpu_dict {
     std::atomic<int> big_pool_batches{0};
     // Same for the long-sentence kernel (its workgroups hold 32 KB of LDS each): issued while recent
     // batches still had sentences left after the pools.
+    std::atomic<int> window_batches{64};  // same for the windowed kernel: armed while recent batches held sentences of WINDOW_MIN_BYTES or more (Control::very_long)
     std::atomic<int> long_batches{64};  // starts armed: a corpus of long sentences does not spend its first batches in the last-resort kernel (3.8 ms per batch on cfg 3)
     // Streams handed round-robin to contexts created without one.  HIP multiplexes streams onto three
     // hardware queues: a 4th stream queues behind the 1st and unbalances them (measured -25 %), so any
@@ -166,6 +167,7 @@ struct kgpu_ctx {
     uint32_t launch_seq = 0;
     int last_pools = 0;        // pool launches issued for the pending batch
     bool last_long = false;    // ... and whether the long-sentence kernel was
+    bool last_window = false;  // ... and whether the windowed kernel was
     bool force_legacy_long = false;  // the pending batch is a rerun: the windowed kernel handed a sentence back
     uint32_t event_every = 1;  // KGPU_PROFILE_SAMPLED: HIP events on every 4th launch only
     DevBuf arena, stage, tok_count;
@@ -573,8 +575,11 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
         const int pools_now = c->dict->big_pool_batches.load(std::memory_order_relaxed) > 0 ? c->plan.n_pools : std::min(c->plan.n_pools, 1);
         c->last_pools = pools_now;
         c->last_long = c->plan.long_lds_bytes && (c->plan.n_pools == 0 || c->dict->long_batches.load(std::memory_order_relaxed) > 0);
-        const bool window_now = c->plan.window_lds_bytes && !c->force_legacy_long && !a.dump_lattice;
-        if (window_now) c->last_long = true;  // (the windowed kernel is always in the chain: it costs an empty launch nothing to find its list empty... and its list is all it serves)
+        // the windowed kernel (very long sentences) is in the chain while recent batches held such sentences -- an empty launch of a few
+        // thousand workgroups behind a chip full of long-running wavefronts is not free -- or always, without a pool kernel to count them
+        const bool window_now = c->plan.window_lds_bytes && !c->force_legacy_long && !a.dump_lattice && c->stop_after == 0 &&
+                                (c->plan.n_pools == 0 || c->dict->window_batches.load(std::memory_order_relaxed) > 0);
+        c->last_window = window_now;
         hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->last_long, c->stop_after, c->stream, ef, window_now);
         if (e != hipSuccess) { set_error("k_tokenize launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     } else if (timed) HIPCHECK(hipEventRecord(ef, c->stream));
@@ -709,9 +714,14 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
         // too small costs a redo (late_count), one that is too large only idles pages until the
         // lattice is known -- steer for a redo rate of 1-3 %.  Applied to the value the batch ran with; races between
         // contexts only lose an adjustment.
-        if (c->last_pools > 0 && c->plan.long_lds_bytes) {  // sentences that no pool could take
-            if (c->h_ctl->ovf_count[c->last_pools - 1] > 0) c->dict->long_batches.store(64, std::memory_order_relaxed);
-            else if (c->last_long) c->dict->long_batches.fetch_sub(1, std::memory_order_relaxed);
+        if (c->last_pools > 0 && c->plan.long_lds_bytes) {  // sentences that neither a pool nor the windowed kernel took
+            const int left = c->last_pools - 1 + (c->last_window ? 1 : 0);
+            if (c->h_ctl->ovf_count[left] > 0) c->dict->long_batches.store(64, std::memory_order_relaxed);
+            else if (c->last_long) c->dict->long_batches.fetch_sub(8, std::memory_order_relaxed);  // (eight clean batches disarm it: a wrong guess costs one batch in the last-resort kernel)
+        }
+        if (c->plan.window_lds_bytes) {
+            if (c->h_ctl->very_long > 0) c->dict->window_batches.store(64, std::memory_order_relaxed);
+            else if (c->last_window) c->dict->window_batches.fetch_sub(8, std::memory_order_relaxed);
         }
         if (c->plan.n_pools > 1) {
             if (c->h_ctl->ovf_count[0] > 0) c->dict->big_pool_batches.store(64, std::memory_order_relaxed);
@@ -815,6 +825,8 @@ extern "C" int kgpu_ctx_get_plan(kgpu_ctx *c, kgpu_plan_info *out, size_t out_si
     }
     p.long_lds_bytes = c->plan.long_lds_bytes; p.long_workgroups = (uint32_t)c->plan.long_workgroups;
     p.long_workgroups_per_cu = c->plan.long_lds_bytes ? (uint32_t)long_workgroups_per_cu(c->plan.long_lds_bytes) : 0u;
+    p.window_lds_bytes = c->plan.window_lds_bytes; p.window_min_bytes = WINDOW_MIN_BYTES;
+    p.window_workgroups_per_cu = c->plan.window_lds_bytes ? (uint32_t)window_workgroups_per_cu(c->plan.window_lds_bytes) : 0u;
     std::memcpy(out, &p, std::min(out_size, sizeof p));
     return KGPU_OK;
 }

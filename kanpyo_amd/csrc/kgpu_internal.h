@@ -63,8 +63,10 @@ struct Control {
     unsigned int waves_copied;        // ... and through with moving its tokens to the caller's (pinned) buffers
     unsigned int small_flag;          // the call's sequence number, stored LAST into the host copy: the host polls it
     unsigned int pack_overflow;       // compact records: a token did not fit kgpu_token8 (chars > 4095 or bytes > 262143): the host falls back to 24-byte records
-    unsigned int window_fail;         // the windowed long-sentence kernel met a sentence it cannot hold: the host reruns the batch with the HBM-lattice kernel
+    unsigned int window_fail;         // the windowed long-sentence kernel met a sentence it cannot hold AND had no list to hand it on to: the host reruns the batch with the HBM-lattice kernel
     unsigned int small_abort;         // ... a wavefront gave up waiting at the rendezvous: the host redoes the call on the general path
+    unsigned int very_long;           // sentences of WINDOW_MIN_BYTES or more seen by the pool kernel (arms the windowed kernel for the following batches)
+    unsigned int pad3;
     unsigned long long dump[8];       // kgpu_lattice_dump: arena offsets of the sentence's two slabs, B, C, N, 1 = valid, dp of EOS
 };
 
@@ -94,6 +96,7 @@ struct BatchArgs {
     uint8_t *status8;                // optional (host path): the compaction kernel mirrors status[] there (mapped host memory)
     uint64_t *toff8;                 // optional (host path): ... and tok_offsets[] (n + 1), so that it reads its offsets from HBM, not back over PCIe
 };                                   // (added to by its owner, summed on the host: hot atomics on a few words would distort the run)
+constexpr uint32_t WINDOW_MIN_BYTES = 3072;  // sentences at least this long (~1000 characters) take the windowed kernel; shorter long ones the HBM-lattice kernel
 constexpr uint32_t STAT_SLOTS = 16384, STAT_WORDS = 32;  // words 0..6: Control::work, 16..25: Control::phase
 
 // Launch plan of one batch: the LDS page-pool kernel (kgpu_pool.hip) once or twice -- W independent

@@ -735,7 +735,7 @@ int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
 
 // Launch chain: pool kernel(s), then the general (HBM scratch) kernel.  Every launch is a
 // persistent grid over its work list (the first one: the identity over [0, n)).
-int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, void *stream);  // kgpu_window.hip
+int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, uint32_t min_bytes, int n_workgroups, void *stream);  // kgpu_window.hip
 
 int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now, uint32_t stop_after, void *stream,
                     void *event_after_first, bool window_now) {
@@ -755,11 +755,18 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
         in_count = &ctl->ovf_count[li];
     }
     if (event_after_first && (plan.n_pools == 0 || n_pools_now == 0) && hipEventRecord((hipEvent_t)event_after_first, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
-    if (long_now && window_now && plan.window_lds_bytes && stop_after == 0) {  // windowed lattice in LDS; what it cannot hold it flags (Control::window_fail)
-        WorkIO io{in_list, in_count, nullptr, nullptr, nullptr};
+    if (window_now && plan.window_lds_bytes && stop_after == 0) {
+        // windowed lattice in LDS for the very long sentences (WINDOW_MIN_BYTES and more); the shorter ones of its list, and what it cannot
+        // hold, go on to the next launch (the HBM-lattice kernel, or the last resort)
+        WorkIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], nullptr};
         uint64_t wg = plan.window_workgroups;
         if (!in_list && a.n < wg) wg = a.n;
-        return launch_tokenize_window(d, a, io, plan.window_lds_bytes, (int)(wg ? wg : 1), stream);
+        int e = launch_tokenize_window(d, a, io, plan.window_lds_bytes, in_list ? WINDOW_MIN_BYTES : 0u /* no pool kernel in front: everything is its to serve */,
+                                       (int)(wg ? wg : 1), stream);
+        if (e) return e;
+        in_list = a.ovf[li];
+        in_count = &ctl->ovf_count[li];
+        ++li;
     }
     if (long_now && plan.long_lds_bytes) {  // HBM lattice + LDS-blocked sweep; takes its whole list, leaves none
         WorkIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], nullptr};
@@ -869,10 +876,10 @@ LaunchPlan default_launch_plan(int device) {
             if (*q == ',') ++q;
         }
     }
-    // windowed long-sentence kernel: KGPU_WINDOW="<KiB>" of LDS per single-wavefront workgroup, "0" = off (the HBM-lattice kernel serves the long sentences)
+    // windowed long-sentence kernel: KGPU_WINDOW="<KiB>" of LDS per single-wavefront workgroup, "0" = off (the HBM-lattice kernel serves every long sentence)
     {
         const char *e = getenv("KGPU_WINDOW");
-        int kib = e ? atoi(e) : 0;
+        int kib = e ? atoi(e) : 12;   // 12 KB: 13 workgroups per CU (cfg 5: 1.08 M documents/s; 16 KB: 0.76; 10 KB: windows outgrow the LDS too often)
         if (kib < 8 || kib > 160) kib = 0;
         t.window_lds_bytes = (uint32_t)kib * 1024;
         const int per_cu = kib ? window_workgroups_per_cu(t.window_lds_bytes) : 0;

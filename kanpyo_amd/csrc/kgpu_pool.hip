@@ -222,6 +222,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         const uint64_t b0 = a.offsets[s];
         const uint64_t Bl = a.offsets[s + 1] - b0;
         const uint32_t pool_cap = page * POOL_PAGES;
+        if (Bl >= WINDOW_MIN_BYTES && lane == 0) atomicAdd(&a.ctl->very_long, 1u);  // (always beyond the routing limits below: max_pages <= 64 pages of <= 2.5 KB... of lattice, not text)
         if (Bl + 64 > pool_cap || Bl > 0xFFF0) { work_defer(io, lane, s); continue; }
         const uint32_t B = (uint32_t)Bl;
         const uint8_t *gtext = a.utf8 + b0;

@@ -17,9 +17,11 @@
 // sentences (LDS x time grows with the square of the length: DESIGN.md section 8).  This kernel's LDS is independent of the
 // length and its HBM traffic is one write per node.
 //
-// What it cannot hold (more than 8 dictionary prefixes at one position, a window whose lattice outgrows the LDS budget, a
-// dictionary word that ends more than 2 WIN positions ahead after an even farther one, node indices beyond the 16-bit
-// window of the tie-break) it reports through Control::window_fail: the host reruns the batch with the HBM-lattice kernel.
+// What it cannot hold (more than 8 dictionary prefixes at one position, a window whose lattice outgrows the LDS budget even four
+// positions long, a FIFO-order violation by a dictionary word longer than a window, node indices beyond the 16-bit window of the tie-break)
+// it pushes onto the next launch's work list (the HBM-lattice kernel, or the last resort), like the sentences of its list that are shorter
+// than `min_bytes`: the HBM-lattice kernel serves those better.  Without a list to hand on to (not in the chain as built) it
+// flags Control::window_fail and the host reruns the batch.
 #include <type_traits>
 
 #include "kgpu_device.h"
@@ -32,6 +34,7 @@ namespace {
 
 constexpr uint32_t WIN = 32;               // start positions per window
 constexpr uint32_t REL = 2 * WIN + 1;      // bucket positions a window holds: relative ends 0 .. 2 WIN
+constexpr uint32_t NEARLEN = WIN;           // a node up to this many characters long keeps its bucket entry in LDS (relative end <= 2 WIN - 1); longer ones go to the FIFO
 constexpr uint32_t WMAXM = 8;              // trie matches parked per start position
 constexpr uint32_t LOOKB = 192;            // text bytes staged beyond the window's own characters (a walk that runs past them reads HBM)
 constexpr uint32_t TEXTB = 4 * WIN + LOOKB;
@@ -117,8 +120,22 @@ __device__ __forceinline__ uint32_t win_walk(const DictView &d, BY &&byte, uint3
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a, WorkIO io, uint32_t lds_bytes) {
+// PROF: device-side work counters + per-phase shader clocks (KGPU_PROFILE_WORK) -- a separate instantiation: the accumulators cost ~40 SGPRs
+struct WinArgs { DictView d; BatchArgs a; WorkIO io; uint32_t lds_bytes, min_bytes; };
+template <bool PROF>
+__global__ __launch_bounds__(64) void k_tokenize_window(WinArgs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    // The arguments stay in the kernarg segment; every phase reads the fields it uses from there (KW_ARGS(): scalar loads behind a pointer
+    // made opaque by an empty asm) -- as by-value parameters the ~90 dwords are live from entry to exit and spill (kgpu_pool.hip does the same).
+    typedef const __attribute__((address_space(4))) WinArgs *KArgs;
+    const KArgs kargs = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    DictView d; BatchArgs a; WorkIO io;
+#define KW_ARGS() do { KArgs kq_ = kargs; asm volatile("" : "+s"(kq_)); \
+        d.da = kq_->d.da; d.da_len = kq_->d.da_len; d.leaf_dup = kq_->d.leaf_dup; d.first = kq_->d.first; d.morph = kq_->d.morph; d.n_morph = kq_->d.n_morph; d.unk_morph = kq_->d.unk_morph; d.n_unk_morph = kq_->d.n_unk_morph; d.conn = kq_->d.conn; d.conn_rows = kq_->d.conn_rows; d.bos_right = kq_->d.bos_right; d.eos_left = kq_->d.eos_left; d.cat = kq_->d.cat; d.cat_len = kq_->d.cat_len; d.cinfo = kq_->d.cinfo; d.conn_tiled = kq_->d.conn_tiled; d.conn_rt64 = kq_->d.conn_rt64; \
+        a.utf8 = kq_->a.utf8; a.offsets = kq_->a.offsets; a.n = kq_->a.n; a.ctl = kq_->a.ctl; a.arena = kq_->a.arena; a.arena_bytes = kq_->a.arena_bytes; a.stage = kq_->a.stage; a.tok_count = kq_->a.tok_count; a.status = kq_->a.status; \
+        io.in_list = kq_->io.in_list; io.in_count = kq_->io.in_count; io.out_list = kq_->io.out_list; io.out_count = kq_->io.out_count; } while (0)
+    KW_ARGS();
+    const uint32_t lds_bytes = kargs->lds_bytes, min_bytes = kargs->min_bytes;
     const uint32_t lane = threadIdx.x;
     const int32_t base_root = d.da[1].base;
     const bool tiled = d.conn_tiled != nullptr;
@@ -126,7 +143,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
     Slab sa{nullptr, 0};
     uint64_t accW[7] = {0, 0, 0, 0, 0, 0, 0};
     uint64_t tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // shader clocks per phase (only summed when a.count_work): prepass, stage, seeds, walk, scan, emit, gather, sweep, flush, backtrace+tokens
-#define KW_T(k) do { if (a.count_work) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); tph[k] += t_ - tlast; tlast = t_; } } while (0)
+#define KW_T(k) do { if constexpr (PROF) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); tph[k] += t_ - tlast; tlast = t_; } } while (0)
 
     // ---- LDS, fixed part (persists across the windows of a sentence; the chunk tables across sentences) ----
     uint32_t off0 = 0;
@@ -159,8 +176,9 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
     auto crel = [&](uint32_t n) { return lds + moff - align_up(8 * n, 16) - align_up(n, 16); };
     auto cbytes = [&](uint32_t n) { return align_up(8 * n, 16) + align_up(n, 16); };
 
-    auto fail = [&](uint64_t s) {  // this sentence needs the HBM-lattice kernel: the host reruns the batch with it
-        if (lane == 0) { a.status[s] = KGPU_SENT_NO_SCRATCH; a.tok_count[s] = 0; atomicExch(&a.ctl->window_fail, 1u); }
+    auto fail = [&](uint64_t s) {  // this sentence needs the HBM-lattice kernel: on to the next launch's list, or (no list) the host reruns the batch
+        if (io.out_list) work_defer(io, lane, s);
+        else if (lane == 0) { a.status[s] = KGPU_SENT_NO_SCRATCH; a.tok_count[s] = 0; atomicExch(&a.ctl->window_fail, 1u); }
     };
     auto chunk_get = [&](uint32_t *table, uint32_t &have, uint32_t idx, uint32_t bytes) -> bool {  // make chunk idx exist (bytes: a multiple of 256)
         while (have <= idx) {
@@ -178,13 +196,14 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
     auto far_rec = [&](uint32_t f) { return (Far *)(a.arena + ((uint64_t)fchunk[(f >> FCH_LOG) % FCHUNKS] << 8)) + (f & ((1u << FCH_LOG) - 1)); };
 
     for (uint32_t iter = 0;; ++iter) {
+        KW_ARGS();
         uint64_t s = 0;
         if (!work_next(io, a, iter, s)) break;
         const uint64_t b0 = a.offsets[s];
         const uint32_t B = (uint32_t)(a.offsets[s + 1] - b0);
         const uint8_t *text = a.utf8 + b0;
-        uint64_t tlast = a.count_work ? __builtin_amdgcn_s_memtime() : 0;
-        if (cfg_bad) { if (lane == 0) { a.status[s] = KGPU_SENT_NO_SCRATCH; a.tok_count[s] = 0; atomicExch(&a.ctl->window_fail, 1u); } continue; }
+        uint64_t tlast = PROF ? __builtin_amdgcn_s_memtime() : 0;
+        if (cfg_bad || (io.out_list && B < min_bytes)) { fail(s); continue; }  // short long sentences: the HBM-lattice kernel serves them better
 
         // ---- slab: per-character arrays in HBM (written once by the decode pass, read once per window) ----
         const uint64_t na = (uint64_t)B + 4;
@@ -235,6 +254,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
         }
         if (lane == 0) cbyte[C] = B;
         __syncthreads();
+        KW_ARGS();
         // ---- pass 1 (descending): length of the same-category run that starts at each character, capped at 1024 ----
         {
             uint32_t carry_end = C;
@@ -281,6 +301,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
             auto byte = [&](uint32_t k) -> uint32_t { const uint32_t r = k - tb0; return r < tlen ? ltext[r] : text[k]; };
 
             KW_T(1);
+            KW_ARGS();
             // -- seeds: carried entries per relative end; FIFO entries that end inside this window
             uint32_t seed_bad = 0;
             for (uint32_t k = lane; k < ncarry; k += 64) atomicAdd(&boff[crel(ncarry)[k]], 1u);
@@ -309,6 +330,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
             wave_sync();
 
             KW_T(2);
+            KW_ARGS();
             // -- walk: one double-array walk per start position; count, park the matches (lattice.rs:24-38, 42-99)
             uint32_t *mbuf = (uint32_t *)(lds + moff);
             uint32_t ovf = 0, cnt = 0, nfar = 0, wTw = 0, wEw = 0;  // (work of this window: added to the sentence's only when the window goes through)
@@ -322,8 +344,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
                     } else ovf = 1;
                     ++m;
                     cnt += nrec;
-                    const uint32_t rel = lane + nch;
-                    if (rel <= 2 * WIN) atomicAdd(&boff[rel], nrec); else nfar += nrec;
+                    if (nch <= NEARLEN) atomicAdd(&boff[lane + nch], nrec); else nfar += nrec;
                 };
                 wTw += win_walk(d, byte, cp16w[lane], cbw[lane], cbw[lane + 1], B, base_root, on_match);
                 mcnt[lane] = (uint8_t)(m < WMAXM ? m : WMAXM);
@@ -332,8 +353,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
                 if ((cnt == 0 || (ci.flags & CAT_INVOKE)) && (ci.flags & CAT_HAS_UNK) && ci.unk_count) {  // lattice.rs:54,87-92
                     span = (ci.flags & CAT_GROUP) ? (uint32_t)rlenw[lane] : 1u;                             // lattice.rs:66-84
                     cnt += ci.unk_count;
-                    const uint32_t rel = lane + span;
-                    if (rel <= 2 * WIN) atomicAdd(&boff[rel], ci.unk_count); else nfar += ci.unk_count;
+                    if (span <= NEARLEN) atomicAdd(&boff[lane + span], ci.unk_count); else nfar += ci.unk_count;
                     if (m < WMAXM) {
                         if (MS == 4) mbuf[lane * WMAXM + m] = (uint32_t)ci.unk_first | ((ci.unk_count < 8 ? ci.unk_count : 0u) << 29);
                         else *(uint2 *)(mbuf + 2 * (lane * WMAXM + m)) = make_uint2((uint32_t)ci.unk_first, ci.unk_count);
@@ -345,6 +365,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
             wave_sync();
 
             KW_T(3);
+            KW_ARGS();
             // -- scan: node numbering (insertion order, lattice.rs:105-110), bucket offsets, pair offsets, far-out slots
             uint32_t N, Nb, E, NF, maxpairs;
             {
@@ -378,6 +399,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
             // -- LDS carve: node arrays, buckets (+ far-out slots + sink), far-out ends, pair table (overlays the match buffer)
             uint32_t off = off0;
             uint2 *bk = (uint2 *)(lds + off);            off += 8 * (Nb + NF + 1);
+            uint8_t *brel = lds + off;                   off += align_up(Nb, 4);   // relative end position of every bucket slot (the flush carries slot by slot)
             int32_t *nSid = (int32_t *)(lds + off);      off += 4 * N;
             uint32_t *nCS = (uint32_t *)(lds + off);     off += 4 * N;
             uint32_t *farEnd = (uint32_t *)(lds + off);  off += 4 * NF;
@@ -388,7 +410,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
             int16_t *mpair = (int16_t *)(lds + off);
             const uint32_t pair_need = min(2 * E, max(2 * maxpairs, PAIR_MIN));
             if (N > 0x7FFF || NF >= 0x7FFF || Nb + NF > 0xFFF0 || off + cbytes(ncarry) + mbytes + 16 > lds_bytes || off + pair_need > lds_bytes ||
-                off0 + 8 * (Nb + NF + 1) + cbytes(Nb) > moff /* the flush writes the next carry list above the buckets it reads */) {
+                off0 + 8 * (Nb + NF + 1) + align_up(Nb, 4) + cbytes(Nb - boff[nw]) > moff /* the flush writes the next carry list above the buckets it reads */) {
                 if (wlim > 4 && nw > 1) { wlim = max(4u, nw >> 1); continue; }  // the same window once more, half as long
                 failed = true; why = 8;
                 break;
@@ -398,6 +420,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
             wave_sync();
 
             KW_T(4);
+            KW_ARGS();
             // -- emit 3a (lane = start position, LDS only): the node list in insertion order; nLeft = relative end, or 0x8000 | far-out slot
             if (lane < nwc) {
                 uint32_t t = nb[lane], fslot = fbase[lane];
@@ -412,7 +435,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
                 }
                 auto put = [&](int32_t sid, uint32_t rel) {
                     nSid[t] = sid; nStart[t] = (uint16_t)lane;
-                    if (rel <= 2 * WIN) nLeft[t] = (uint16_t)rel;
+                    if (rel - lane <= NEARLEN) nLeft[t] = (uint16_t)rel;
                     else { nLeft[t] = (uint16_t)(0x8000u | fslot); farEnd[fslot] = w0 + rel; ++fslot; }
                     ++t;
                 };
@@ -440,6 +463,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
                 const uint32_t rel = crel(ncarry)[k];
                 const uint32_t slot = boff[rel] + atomicAdd(&bfill[rel], 1u);
                 bk[slot] = carry8(ncarry)[k];  // (its node index is already relative to this window's base)
+                brel[slot] = (uint8_t)rel;
             }
             for (uint32_t f = fhead + lane; f < fhead + fin; f += 64) {
                 const Far e = *far_rec(f);
@@ -447,6 +471,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
                 if (wideN[rel] == 0) {
                     const uint32_t slot = boff[rel] + atomicAdd(&bfill[rel], 1u);
                     bk[slot] = make_uint2((uint32_t)e.dp, (e.right & 0xFFFFu) | ((e.node - rb) << 16));
+                    brel[slot] = (uint8_t)rel;
                 }
             }
             // -- emit 3b (lane = node): morph record, bucket slot
@@ -467,7 +492,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
                         uint32_t slot;
                         if (ee[k] == 0x7FFFu) slot = Nb + NF;                                   // EOS: the sink
                         else if (ee[k] & 0x8000u) slot = Nb + (ee[k] & 0x7FFFu);                 // ends beyond the LDS buckets: a far-out slot
-                        else slot = boff[ee[k]] + atomicAdd(&bfill[ee[k]], 1u);
+                        else { slot = boff[ee[k]] + atomicAdd(&bfill[ee[k]], 1u); brel[slot] = (uint8_t)ee[k]; }
                         nLeft[tt[k]] = (uint16_t)mm[k].left; nCS[tt[k]] = (uint32_t)(uint16_t)mm[k].cost | (slot << 16);
                         bk[slot] = make_uint2((uint32_t)INF, rword((uint32_t)(uint16_t)mm[k].right) | ((gw + tt[k] - rb) << 16));
                     }
@@ -476,6 +501,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
             wave_sync();
 
             KW_T(5);
+            KW_ARGS();
             // -- gather + sweep, block by block (the pool kernel's step: kgpu_pool.hip)
             const uint32_t lds0 = (uint32_t)(uintptr_t)(KW_LDS(uint8_t) *)lds;
             const uint32_t a_ncs = bcast32(lds0 + (uint32_t)((uint8_t *)nCS - lds)), a_bk = bcast32(lds0 + (uint32_t)((uint8_t *)bk - lds));
@@ -647,6 +673,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
                 qa = qb;
             }
 
+            KW_ARGS();
             // -- flush: node records to HBM, far-out entries to the FIFO, the buckets beyond the window to the carry list
             if (!chunk_get(nchunk, nchunks_have, (gw + N - 1) >> NCH_LOG, sizeof(NodeRec) << NCH_LOG)) { failed = true; why = 3; break; }
             for (uint32_t t = lane; t < N; t += 64) {
@@ -673,6 +700,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
                 if (__ballot(fbad != 0) != 0) { failed = true; why = 6; break; }
                 last_far_end = bcast32(farEnd[NF - 1]);
                 ftail += NF;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the next window may already take some of these from the FIFO
             }
             fhead += fin;
             {
@@ -681,28 +709,34 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
                 uint2 *c8 = carry8(nc);
                 uint8_t *cr = crel(nc);
                 uint32_t cbad = 0;
-                // lanes over the relative positions nw .. 2 WIN: the carried slots of each, re-based
-                for (uint32_t rel = nw + lane; rel <= 2 * WIN; rel += 64)
-                    for (uint32_t sl = boff[rel]; sl < boff[rel + 1]; ++sl) {
-                        const uint2 e = bk[sl];
-                        const uint32_t g = rb + (e.y >> 16);
-                        if (g < rbn) cbad = 1;
-                        c8[sl - c0] = make_uint2(e.x, (e.y & 0xFFFFu) | ((g - rbn) << 16));
-                        cr[sl - c0] = (uint8_t)(rel - nw);
-                    }
+                for (uint32_t sl = c0 + lane; sl < Nb; sl += 64) {  // lane = carried slot, re-based
+                    const uint2 e = bk[sl];
+                    const uint32_t g = rb + (e.y >> 16);
+                    if (g < rbn) cbad = 1;
+                    c8[sl - c0] = make_uint2(e.x, (e.y & 0xFFFFu) | ((g - rbn) << 16));
+                    cr[sl - c0] = (uint8_t)(brel[sl] - nw);
+                }
                 if (__ballot(cbad != 0) != 0) { failed = true; why = 7; break; }
                 ncarry = nc;
             }
             wlim = min(WIN, wlim * 2);
             wT += wTw; wE += wEw;
             wbyte0 = wbyte_next;
-            wave_sync();  // (no wait for the stores: what a window writes to HBM is read two windows later at the earliest -- FIFO entries end beyond the next window)
+            wave_sync();  // (no workgroup barrier: the FIFO entries just written are read back by this same wavefront, in program order)
             KW_T(8);
             gw += N;
             w0 += nw;
         }
-        if (failed) { fail(s); if (lane == 0 && !a.count_work) atomicAdd(&a.ctl->phase[why < 10 ? why : 9], 1ull); __syncthreads(); continue; }
+        if (failed) {
+            if ((why == 3 || why == 5) && __hip_atomic_load(&a.ctl->arena_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (lane == 0) { a.status[s] = KGPU_SENT_NO_SCRATCH; a.tok_count[s] = 0; }  // the scratch arena was too small: the host grows it and reruns the batch
+            } else fail(s);
+            if (lane == 0 && !PROF) atomicAdd(&a.ctl->phase[why < 10 ? why : 9], 1ull);
+            __syncthreads();
+            continue;
+        }
 
+        KW_ARGS();
         // ---- backtrace (lattice.rs:144-153): chase `pre` through windows of node records staged in LDS ----
         KW_T(8);
         const uint32_t Ntot = gw;  // BOS + every node; EOS is node Ntot - 1
@@ -750,13 +784,13 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
         }
         if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; }
         KW_T(9);
-        if (a.count_work) {
+        if constexpr (PROF) {
             wT = wave_sum(wT); wE = wave_sum(wE);
             accW[0] += 1; accW[1] += B; accW[2] += C; accW[3] += wT; accW[4] += Ntot - 1; accW[5] += wE; accW[6] += K;
         }
         __syncthreads();
     }
-    if (a.count_work && lane == 0) {
+    if (PROF && lane == 0) {
         for (int k = 0; k < 7; ++k) atomicAdd(&a.ctl->work[k], (unsigned long long)accW[k]);
         for (int k = 0; k < 10; ++k) atomicAdd(&a.ctl->phase[k], (unsigned long long)tph[k]);
     }
@@ -764,18 +798,20 @@ __global__ __launch_bounds__(64) void k_tokenize_window(DictView d, BatchArgs a,
 
 int window_workgroups_per_cu(uint32_t lds_bytes) {
     if (lds_bytes > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)k_tokenize_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return 0;
+        hipFuncSetAttribute((const void *)k_tokenize_window<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return 0;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_window, 64, (size_t)lds_bytes) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_window<false>, 64, (size_t)lds_bytes) != hipSuccess) return 0;
     return n;
 }
 
-int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, void *stream) {
+int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, uint32_t min_bytes, int n_workgroups, void *stream) {
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_window<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_tokenize_window<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k_tokenize_window, dim3((unsigned)n_workgroups), dim3(64), lds_bytes, (hipStream_t)stream, d, a, io, lds_bytes);
+    if (a.count_work) hipLaunchKernelGGL(k_tokenize_window<true>, dim3((unsigned)n_workgroups), dim3(64), lds_bytes, (hipStream_t)stream, WinArgs{d, a, io, lds_bytes, min_bytes});
+    else hipLaunchKernelGGL(k_tokenize_window<false>, dim3((unsigned)n_workgroups), dim3(64), lds_bytes, (hipStream_t)stream, WinArgs{d, a, io, lds_bytes, min_bytes});
     return (int)hipGetLastError();
 }
 

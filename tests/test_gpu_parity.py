@@ -567,9 +567,10 @@ def test_large_host_call_chunk_byte_counts(small):
 
 @pytest.mark.parametrize("window_kib,pool", [("12", "40:4:48"), ("16", "40:4:48"), ("16", "0"), ("24", "16:4:8")])
 def test_windowed_long_sentence_kernel(libs, window_kib, pool, monkeypatch):
-    """The experimental windowed kernel (kgpu_window.hip, KGPU_WINDOW = KiB of LDS per workgroup; off by default): the lattice of a long
-    sentence is built and relaxed window by window, only the carry list / the far FIFO / 16 bytes per node outlive a window
-    (src/lattice.rs:101-154).  What it cannot hold is rerun through the HBM-lattice kernel -- same records either way."""
+    """The windowed kernel (kgpu_window.hip, KGPU_WINDOW = KiB of LDS per workgroup; in the chain for sentences of 3072 bytes and more, for
+    everything when there is no pool kernel): the lattice is built and relaxed window by window, only the carry list / the far FIFO /
+    16 bytes per node outlive a window (src/lattice.rs:101-154).  What it cannot hold travels on to the HBM-lattice kernel -- same
+    records either way."""
     from kanpyo_amd import Tokenizer, synth
 
     _, oracle = libs
