@@ -32,7 +32,11 @@ using namespace dev;
 
 namespace {
 
-constexpr uint32_t WIN = 32;               // start positions per window
+#ifndef KGPU_WIN
+#define KGPU_WIN 32
+#endif
+constexpr uint32_t WIN = KGPU_WIN;         // start positions per window
+static_assert(WIN >= 8 && WIN <= 63, "lane = position, and lane WIN holds the totals of the scans");
 constexpr uint32_t REL = 2 * WIN + 1;      // bucket positions a window holds: relative ends 0 .. 2 WIN
 constexpr uint32_t NEARLEN = WIN;           // a node up to this many characters long keeps its bucket entry in LDS (relative end <= 2 WIN - 1); longer ones go to the FIFO
 constexpr uint32_t WMAXM = 8;              // trie matches parked per start position
