@@ -906,7 +906,7 @@ def main():
             from oracle import oracle as _orc
 
             extras_orc = _orc.OracleTokenizer.from_dict(sd.dict)
-        for kind, passes, lab in (("cfg5", 5, "BASELINE configs[4] (cfg 5): 1k sentences of 2048 chars, each with a same-category run > 1024 chars"),
+        for kind, passes, lab in (("cfg5", 40, "BASELINE configs[4] (cfg 5): 1k sentences of 2048 chars, each with a same-category run > 1024 chars"),
                                   ("cfg3", 2, f"BASELINE configs[2] (cfg 3): {args.cfg3_sentences} mixed-length (8-512 char) sentences incl. unknown-word path, batches of 16384")):
             flag = os.path.join(extras_dir, kind + "_done.npy")
             t_wait = time.perf_counter()

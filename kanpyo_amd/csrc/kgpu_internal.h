@@ -96,7 +96,10 @@ struct BatchArgs {
     uint8_t *status8;                // optional (host path): the compaction kernel mirrors status[] there (mapped host memory)
     uint64_t *toff8;                 // optional (host path): ... and tok_offsets[] (n + 1), so that it reads its offsets from HBM, not back over PCIe
 };                                   // (added to by its owner, summed on the host: hot atomics on a few words would distort the run)
-constexpr uint32_t WINDOW_MIN_BYTES = 3072;  // sentences at least this long (~1000 characters) take the windowed kernel; shorter long ones the HBM-lattice kernel
+#ifndef KGPU_WINDOW_MIN_BYTES
+#define KGPU_WINDOW_MIN_BYTES 3072
+#endif
+constexpr uint32_t WINDOW_MIN_BYTES = KGPU_WINDOW_MIN_BYTES;  // sentences at least this long (~1000 characters) take the windowed kernel; shorter long ones the HBM-lattice kernel
 constexpr uint32_t STAT_SLOTS = 16384, STAT_WORDS = 32;  // words 0..6: Control::work, 16..25: Control::phase
 
 // Launch plan of one batch: the LDS page-pool kernel (kgpu_pool.hip) once or twice -- W independent

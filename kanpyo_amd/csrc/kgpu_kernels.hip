@@ -125,10 +125,74 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         uint32_t toff = 0;
         if constexpr (LDS_SWEEP) { const uint32_t tb = (B + 4 + 15) & ~15u; if (2 * tb <= lds_bytes) toff = tb; }
         uint32_t C = 0, bad = 0, lensum = 0;
+        if constexpr (LDS_SWEEP) {
+            // 256 bytes a round, through LDS (in place when the text stays there, else a scratch block at its start): the continuation bytes are
+            // LDS reads, the next round's text is in flight while this one is decoded, and the round's four category loads are issued together
+            // (unconditional, clamped addresses: a load under a lane mask is waited for on the spot) -- one memory round trip per 256 bytes
+            // instead of up to five per 64 (this pass was the largest part of "decode + count", itself 28 % of a 325-character sentence).
+            uint32_t pf[5];
+            auto fetch = [&](uint32_t k0) {
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const uint32_t k = k0 + 64u * (uint32_t)u + (u < 4 ? lane : (lane & 3u));
+                    pf[u] = text[min(k, B - 1u)];
+                }
+            };
+            if (B) fetch(0);
+            for (uint32_t k0 = 0; k0 < B; k0 += 256) {
+                uint8_t *blk = lds + (toff ? k0 : 0u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) blk[64 * u + lane] = (uint8_t)(k0 + 64u * (uint32_t)u + lane < B ? pf[u] : 0x80u);
+                if (lane < 3) blk[256 + lane] = (uint8_t)(k0 + 256u + lane < B ? pf[4] : 0x80u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                fetch(k0 + 256);
+                uint32_t ci[4], kk[4], cpx[4];
+                bool st[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t r = 64u * (uint32_t)u + lane, k = k0 + r;
+                    const uint32_t b = blk[r];
+                    const bool start = k < B && (b & 0xC0) != 0x80;
+                    const uint64_t m = __ballot(start);
+                    ci[u] = C + __popcll(m & ((1ull << lane) - 1));
+                    st[u] = start; kk[u] = k; cpx[u] = 0;
+                    if (start) {
+                        uint32_t l, cp;
+                        if (b < 0x80) { l = 1; cp = b; }
+                        else if (b >= 0xC2 && b <= 0xDF) { l = 2; cp = b & 0x1F; }
+                        else if ((b & 0xF0) == 0xE0) { l = 3; cp = b & 0x0F; }
+                        else if (b >= 0xF0 && b <= 0xF4) { l = 4; cp = b & 0x07; }
+                        else { l = 1; cp = 0; bad = 1; }
+                        if (k + l > B) { bad = 1; l = 1; }
+                        for (uint32_t j = 1; j < l; ++j) {
+                            const uint32_t bb = blk[r + j];
+                            if ((bb & 0xC0) != 0x80) bad = 1;
+                            cp = (cp << 6) | (bb & 0x3F);
+                        }
+                        if (l == 3 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) bad = 1;
+                        if (l == 4 && (cp < 0x10000 || cp > 0x10FFFF)) bad = 1;
+                        lensum += l;
+                        cpx[u] = cp;
+                    }
+                    C += __popcll(m);
+                }
+                uint32_t cv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cv[u] = d.cat[cpx[u] < d.cat_len ? cpx[u] : 0u];  // char_category_def.rs:33-38: table[ch] if in range else table[0]
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (st[u]) {
+                        cbyte[ci[u]] = kk[u];
+                        cp16[ci[u]] = (uint16_t)(cpx[u] < 0xFFFFu ? cpx[u] : 0xFFFFu);
+                        ccat[ci[u]] = (uint8_t)(bad ? 0u : cv[u]);
+                    }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        } else
         for (uint32_t k0 = 0; k0 < B; k0 += 64) {
             uint32_t k = k0 + lane;
             uint32_t b = k < B ? text[k] : 0x80u;
-            if (toff && k < B) lds[k] = (uint8_t)b;
             bool start = k < B && (b & 0xC0) != 0x80;
             uint64_t m = __ballot(start);
             uint32_t ci = C + __popcll(m & ((1ull << lane) - 1));

@@ -42,6 +42,8 @@ constexpr uint32_t NEARLEN = WIN;           // a node up to this many characters
 constexpr uint32_t WMAXM = 8;              // trie matches parked per start position
 constexpr uint32_t LOOKB = 192;            // text bytes staged beyond the window's own characters (a walk that runs past them reads HBM)
 constexpr uint32_t TEXTB = 4 * WIN + LOOKB;
+constexpr uint32_t LTEXT = ((TEXTB + 4 > 260 ? TEXTB + 4 : 260) + 15) & ~15u;   // the staged block as aligned dwords (up to 3 bytes of misalignment in front); the decode pass's 256 + 3 bytes
+static_assert(LTEXT / 4 <= 128, "two dwords per lane");
 constexpr uint32_t NCH_LOG = 13, NCHUNKS = 32;   // node records: chunks of 8192 (128 KB), at most 262144 nodes per sentence
 constexpr uint32_t FCH_LOG = 12, FCHUNKS = 16;   // far entries: chunks of 4096 (64 KB), at most 65536 waiting at once
 constexpr uint32_t WIDE_MIN = 96;          // FIFO entries at one end position from which they are streamed instead of staged in LDS
@@ -127,7 +129,7 @@ __device__ __forceinline__ uint32_t win_walk(const DictView &d, BY &&byte, uint3
 // PROF: device-side work counters + per-phase shader clocks (KGPU_PROFILE_WORK) -- a separate instantiation: the accumulators cost ~40 SGPRs
 struct WinArgs { DictView d; BatchArgs a; WorkIO io; uint32_t lds_bytes, min_bytes; };
 template <bool PROF>
-__global__ __launch_bounds__(64) void k_tokenize_window(WinArgs) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_tokenize_window(WinArgs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     // The arguments stay in the kernarg segment; every phase reads the fields it uses from there (KW_ARGS(): scalar loads behind a pointer
     // made opaque by an empty asm) -- as by-value parameters the ~90 dwords are live from entry to exit and spill (kgpu_pool.hip does the same).
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(WinArgs) {
     uint32_t off0 = 0;
     uint32_t *nchunk = (uint32_t *)(lds + off0); off0 += 4 * NCHUNKS;   // node-record chunks this workgroup owns (arena offsets / 256)
     uint32_t *fchunk = (uint32_t *)(lds + off0); off0 += 4 * FCHUNKS;   // far-entry chunks
-    uint8_t *ltext = lds + off0;                 off0 += align_up(TEXTB, 16);
+    uint8_t *ltext = lds + off0;                 off0 += LTEXT;
     uint32_t *cbw = (uint32_t *)(lds + off0);    off0 += 4 * (WIN + 2);   // byte offset of the window's characters (and one past)
     uint32_t *nb = (uint32_t *)(lds + off0);     off0 += 4 * (WIN + 2);   // nodes starting at position q -> first local node index
     uint32_t *ebase = (uint32_t *)(lds + off0);  off0 += 4 * (WIN + 2);   // first pair index per position
@@ -209,74 +211,123 @@ __global__ __launch_bounds__(64) void k_tokenize_window(WinArgs) {
         uint64_t tlast = PROF ? __builtin_amdgcn_s_memtime() : 0;
         if (cfg_bad || (io.out_list && B < min_bytes)) { fail(s); continue; }  // short long sentences: the HBM-lattice kernel serves them better
 
-        // ---- slab: per-character arrays in HBM (written once by the decode pass, read once per window) ----
+        // ---- slab: one 8-byte record per character in HBM (written by the two prepasses, read once per window), then the backtrace's path ----
+        //   .x = byte offset (24 bits) | category << 24     .y = BMP code point (0xFFFF: not BMP) | same-category run length from here << 16
+        if (B >= (1u << 24)) { fail(s); continue; }
         const uint64_t na = (uint64_t)B + 4;
-        if (!slab_ensure(sa, na * 13 + 64, a, lane)) {
+        if (!slab_ensure(sa, na * 12 + 64, a, lane)) {
             if (lane == 0) { a.status[s] = KGPU_SENT_NO_SCRATCH; a.tok_count[s] = 0; }
             continue;
         }
-        uint32_t *cbyte = (uint32_t *)sa.ptr;       // char -> byte offset, [C] = B
-        uint32_t *path = cbyte + na;                // backtrace
-        uint16_t *cp16 = (uint16_t *)(path + na);   // BMP code point (0xFFFF: not BMP)
-        uint16_t *rlen = cp16 + na;                 // same-category run length from here, capped at 1024 (lattice.rs:66-84)
-        uint8_t *ccat = (uint8_t *)(rlen + na);
+        uint2 *crec = (uint2 *)sa.ptr;              // [C]: {B, 0}
+        uint32_t *path = (uint32_t *)(crec + na);   // backtrace
 
-        // ---- pass 0: decode + validate + category (char_category_def.rs:33-38) ----
+        // ---- pass 0: decode + validate + category (char_category_def.rs:33-38), 256 bytes a round: the round's text goes through LDS (the
+        // continuation bytes are read there), the next round's is in flight meanwhile, and the four category loads of a round are issued together --
+        // one memory round trip per 256 bytes (a 64-byte round with its dependent category load made this pass 13 % of a 2048-character document)
+#ifdef KGPU_WIN_SPLIT  // measurement build: slot 0 = sentence set-up, 1 (+ stage) = decode pass, 2 (+ seeds) = run-length pass
+        KW_T(0);
+#endif
         uint32_t C = 0, bad = 0, lensum = 0;
-        for (uint32_t k0 = 0; k0 < B; k0 += 64) {
-            const uint32_t k = k0 + lane;
-            const uint32_t b = k < B ? text[k] : 0x80u;
-            const bool start = k < B && (b & 0xC0) != 0x80;
-            const uint64_t m = __ballot(start);
-            const uint32_t ci = C + __popcll(m & ((1ull << lane) - 1));
-            if (start) {
-                uint32_t l, cp;
-                if (b < 0x80) { l = 1; cp = b; }
-                else if (b >= 0xC2 && b <= 0xDF) { l = 2; cp = b & 0x1F; }
-                else if ((b & 0xF0) == 0xE0) { l = 3; cp = b & 0x0F; }
-                else if (b >= 0xF0 && b <= 0xF4) { l = 4; cp = b & 0x07; }
-                else { l = 1; cp = 0; bad = 1; }
-                if (k + l > B) { bad = 1; l = 1; }
-                for (uint32_t j = 1; j < l; ++j) {
-                    const uint32_t bb = text[k + j];
-                    if ((bb & 0xC0) != 0x80) bad = 1;
-                    cp = (cp << 6) | (bb & 0x3F);
+        {
+            uint32_t pf[5];
+            auto fetch = [&](uint32_t k0) {  // (unconditional loads at clamped addresses: a load under a lane mask is waited for on the spot)
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const uint32_t k = k0 + 64u * (uint32_t)u + (u < 4 ? lane : (lane & 3u));
+                    pf[u] = text[min(k, B - 1u)];
                 }
-                if (l == 3 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) bad = 1;
-                if (l == 4 && (cp < 0x10000 || cp > 0x10FFFF)) bad = 1;
-                lensum += l;
-                cbyte[ci] = k;
-                cp16[ci] = (uint16_t)(cp < 0xFFFFu ? cp : 0xFFFFu);
-                ccat[ci] = bad ? 0 : (cp < d.cat_len ? d.cat[cp] : d.cat[0]);
+            };
+            if (B) fetch(0);
+            for (uint32_t k0 = 0; k0 < B; k0 += 256) {
+                wave_sync();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ltext[64 * u + lane] = (uint8_t)(k0 + 64u * (uint32_t)u + lane < B ? pf[u] : 0x80u);
+                if (lane < 3) ltext[256 + lane] = (uint8_t)(k0 + 256u + lane < B ? pf[4] : 0x80u);
+                wave_sync();
+                fetch(k0 + 256);  // (clamped addresses: harmless past the end)
+                uint32_t ci[4], kk[4], cpx[4];
+                bool st[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t r = 64u * (uint32_t)u + lane, k = k0 + r;
+                    const uint32_t b = ltext[r];
+                    const bool start = k < B && (b & 0xC0) != 0x80;
+                    const uint64_t m = __ballot(start);
+                    ci[u] = C + __popcll(m & ((1ull << lane) - 1));
+                    st[u] = start; kk[u] = k; cpx[u] = 0;
+                    if (start) {
+                        uint32_t l, cp;
+                        if (b < 0x80) { l = 1; cp = b; }
+                        else if (b >= 0xC2 && b <= 0xDF) { l = 2; cp = b & 0x1F; }
+                        else if ((b & 0xF0) == 0xE0) { l = 3; cp = b & 0x0F; }
+                        else if (b >= 0xF0 && b <= 0xF4) { l = 4; cp = b & 0x07; }
+                        else { l = 1; cp = 0; bad = 1; }
+                        if (k + l > B) { bad = 1; l = 1; }
+                        for (uint32_t j = 1; j < l; ++j) {
+                            const uint32_t bb = ltext[r + j];
+                            if ((bb & 0xC0) != 0x80) bad = 1;
+                            cp = (cp << 6) | (bb & 0x3F);
+                        }
+                        if (l == 3 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) bad = 1;
+                        if (l == 4 && (cp < 0x10000 || cp > 0x10FFFF)) bad = 1;
+                        lensum += l;
+                        cpx[u] = cp;
+                    }
+                    C += __popcll(m);
+                }
+                uint32_t cv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cv[u] = d.cat[cpx[u] < d.cat_len ? cpx[u] : 0u];  // (cpx = 0 where no character starts: four loads, one wait)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (st[u]) {
+                        crec[ci[u]].x = kk[u] | ((bad ? 0u : cv[u]) << 24);
+                        *(uint16_t *)&crec[ci[u]].y = (uint16_t)(cpx[u] < 0xFFFFu ? cpx[u] : 0xFFFFu);
+                    }
             }
-            C += __popcll(m);
         }
         lensum = bcast32(wave_sum(lensum));
         if (__ballot(bad != 0) != 0 || lensum != B) {
             if (lane == 0) { a.status[s] = KGPU_SENT_INVALID_UTF8; a.tok_count[s] = 0; }
             continue;
         }
-        if (lane == 0) cbyte[C] = B;
+        if (lane == 0) crec[C] = make_uint2(B, 0u);
         __syncthreads();
+#ifdef KGPU_WIN_SPLIT
+        KW_T(1);
+#endif
         KW_ARGS();
-        // ---- pass 1 (descending): length of the same-category run that starts at each character, capped at 1024 ----
+        // ---- pass 1 (descending): length of the same-category run that starts at each character, capped at 1024; 256 characters a round ----
         {
             uint32_t carry_end = C;
-            for (int ch = (int)((C + 63) / 64) - 1; ch >= 0; --ch) {
-                const uint32_t i = (uint32_t)ch * 64 + lane;
-                const bool active = i < C;
-                const uint32_t cat = active ? ccat[i] : 0x1FFu;
-                const uint32_t ncat = (i + 1 < C) ? ccat[i + 1] : 0x2FFu;
-                const uint64_t bm = __ballot(active && ncat != cat);
-                const uint64_t rest = bm >> lane;
-                const uint32_t run_end = rest ? i + (uint32_t)__ffsll((unsigned long long)rest) : carry_end;
-                carry_end = bcast32(run_end);
-                if (active) { const uint32_t r = run_end - i; rlen[i] = (uint16_t)(r < MAX_UNKNOWN_LEN ? r : MAX_UNKNOWN_LEN); }
+            for (int ch = (int)((C + 255) / 256) - 1; ch >= 0; --ch) {
+                uint32_t cat[4], ncat[4];
+#pragma unroll
+                for (int u = 3; u >= 0; --u) {
+                    const uint32_t i = (uint32_t)ch * 256 + 64u * (uint32_t)u + lane;
+                    cat[u] = crec[min(i, C)].x >> 24;   // ([C] exists: loads without a lane mask, eight in flight)
+                    ncat[u] = crec[min(i + 1, C)].x >> 24;
+                }
+#pragma unroll
+                for (int u = 3; u >= 0; --u) {
+                    const uint32_t i = (uint32_t)ch * 256 + 64u * (uint32_t)u + lane;
+                    const bool active = i < C;
+                    const uint64_t bm = __ballot(active && (i + 1 >= C || ncat[u] != cat[u]));
+                    const uint64_t rest = bm >> lane;
+                    const uint32_t run_end = rest ? i + (uint32_t)__ffsll((unsigned long long)rest) : carry_end;
+                    carry_end = bcast32(run_end);
+                    if (active) { const uint32_t r = run_end - i; ((uint16_t *)&crec[i].y)[1] = (uint16_t)(r < MAX_UNKNOWN_LEN ? r : MAX_UNKNOWN_LEN); }
+                }
             }
         }
         __syncthreads();
 
+#ifdef KGPU_WIN_SPLIT
+        KW_T(2);
+#else
         KW_T(0);
+#endif
         // ---- the windows ----
         uint32_t w0 = 0, gw = 1 /* global index of the window's first node: BOS is node 0 */, ncarry = 1, fhead = 0, ftail = 0, last_far_end = 0;
         uint32_t wT = 0, wE = 0;
@@ -284,6 +335,18 @@ __global__ __launch_bounds__(64) void k_tokenize_window(WinArgs) {
         uint32_t why = 0;  // which limit a failed sentence ran into (Control::phase[why] counts them: KGPU_WINDOW_TRACE)
         if (lane == 0) { carry8(1)[0] = make_uint2(0u, rword(d.bos_right)); crel(1)[0] = 0; }  // BOS: node 0, ends at 0, dp None -> 0 (lattice.rs:127,156-164)
         uint32_t wbyte0 = 0;  // first byte of the next window's characters
+        uint2 pf_rec = make_uint2(0u, 0u);
+        uint32_t pf_t0 = 0, pf_t1 = 0;
+        bool staged = false;
+        auto prefetch = [&](uint32_t w0n, uint32_t tbn) {  // the records of positions w0n .. w0n + WIN and the text block from byte tbn, as aligned dwords
+            if (lane <= WIN && w0n + lane <= C) pf_rec = crec[w0n + lane];
+            const uintptr_t g = (uintptr_t)(text + tbn);
+            const uint32_t mis = (uint32_t)(g & 3u), tl = min(B - tbn, TEXTB) + mis;
+            const uint32_t *g32 = (const uint32_t *)(g - mis);
+            if (4 * lane < tl) pf_t0 = g32[lane];
+            if (4 * (64 + lane) < tl) pf_t1 = g32[64 + lane];
+        };
+        prefetch(0, 0);
         uint32_t wlim = WIN;  // positions per window: halved when a window's lattice outgrows the LDS, doubled back afterwards
         wave_sync();
         uint32_t eos_pre = NONE;
@@ -291,18 +354,24 @@ __global__ __launch_bounds__(64) void k_tokenize_window(WinArgs) {
             const uint32_t nw = min(wlim, C + 1 - w0);         // positions of this window; position C (if in it) holds only EOS
             const uint32_t nwc = min(nw, C - w0);              // ... of which characters
             const uint32_t rb = gw >= 0x8000u ? gw - 0x8000u : 0u;   // node indices inside the window's LDS are 16-bit offsets from here
-            // -- stage: the window's per-character records and its text (+ LOOKB bytes) into LDS
-            if (lane <= nwc) cbw[lane] = cbyte[w0 + lane];
-            if (lane < nwc) { cp16w[lane] = cp16[w0 + lane]; catw[lane] = ccat[w0 + lane]; rlenw[lane] = rlen[w0 + lane]; }
+            // -- stage: the window's per-character records and its text (+ LOOKB bytes) into LDS -- from the registers they were prefetched into
+            // while the previous window was relaxed (the text block starts at the byte the previous window's characters ended at and has a
+            // fixed length).  A window that is redone half as long finds everything still in place.
+            const uint32_t tb0 = wbyte0, tlen = min(B - tb0, TEXTB);
+            const uint32_t tmis = (uint32_t)((uintptr_t)(text + tb0) & 3u);
+            if (!staged) {
+                const uint32_t nfull = min(WIN, C - w0);
+                if (lane <= nfull) cbw[lane] = pf_rec.x & 0xFFFFFFu;
+                if (lane < nfull) { cp16w[lane] = (uint16_t)pf_rec.y; catw[lane] = (uint8_t)(pf_rec.x >> 24); rlenw[lane] = (uint16_t)(pf_rec.y >> 16); }
+                ((uint32_t *)ltext)[lane] = pf_t0;
+                if (lane < LTEXT / 4 - 64) ((uint32_t *)ltext)[64 + lane] = pf_t1;
+                staged = true;
+            }
             for (uint32_t e = lane; e < REL + 2; e += 64) { boff[e] = 0; bfill[e] = 0; }
             if (lane < WIN + 2) { fcnt[lane] = 0; wideN[lane] = 0; }
-            // (the text block starts at the byte the previous window's characters ended at -- known without waiting for cbw -- and
-            // has a fixed length: one round trip for the whole stage)
-            const uint32_t tb0 = wbyte0, tlen = min(B - tb0, TEXTB);
-            for (uint32_t k = lane; k < tlen; k += 64) ltext[k] = text[tb0 + k];
             wave_sync();
             const uint32_t wbyte_next = cbw[nwc];
-            auto byte = [&](uint32_t k) -> uint32_t { const uint32_t r = k - tb0; return r < tlen ? ltext[r] : text[k]; };
+            auto byte = [&](uint32_t k) -> uint32_t { const uint32_t r = k - tb0; return r < tlen ? ltext[r + tmis] : text[k]; };
 
             KW_T(1);
             KW_ARGS();
@@ -421,6 +490,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(WinArgs) {
             }
             if ((uint64_t)gw + N >= ((uint64_t)NCHUNKS << NCH_LOG)) { failed = true; why = 3; break; }
             const uint32_t mcap = (lds_bytes - off) / 2;
+            if (w0 + nw <= C) prefetch(w0 + nw, wbyte_next);  // the next window's stage: in flight while this one is emitted and relaxed
             wave_sync();
 
             KW_T(4);
@@ -726,6 +796,7 @@ __global__ __launch_bounds__(64) void k_tokenize_window(WinArgs) {
             wlim = min(WIN, wlim * 2);
             wT += wTw; wE += wEw;
             wbyte0 = wbyte_next;
+            staged = false;
             wave_sync();  // (no workgroup barrier: the FIFO entries just written are read back by this same wavefront, in program order)
             KW_T(8);
             gw += N;
