@@ -97,7 +97,7 @@ struct PinBuf {
 // Test-only environment hooks.  getenv is not thread-safe against setenv, and kgpu_tokenize_batch may be called from many
 // threads: the hooks are read under a mutex, ONCE per process -- unless KGPU_TEST_HOOKS_REREAD is set (tests/conftest.py sets
 // it: the tests flip the hooks between calls).
-struct TestHooks { bool no_small_calls = false, legacy_host_path = false, plain_leaves = false; uint64_t chunk_bytes = 4ull << 20, chunk_sents = 16384, depth = 12; };
+struct TestHooks { bool no_small_calls = false, legacy_host_path = false, plain_leaves = false, byte_trie = false; uint64_t chunk_bytes = 4ull << 20, chunk_sents = 16384, depth = 12; };
 static bool env_flag_now(const char *name) { const char *e = getenv(name); return e && *e && *e != '0'; }
 static TestHooks test_hooks() {
     static std::mutex mu;
@@ -110,6 +110,7 @@ static TestHooks test_hooks() {
         cur.no_small_calls = env_flag_now("KGPU_NO_SMALL_CALLS");
         cur.legacy_host_path = env_flag_now("KGPU_HOST_LEGACY");
         cur.plain_leaves = env_flag_now("KGPU_PLAIN_LEAVES");
+        cur.byte_trie = env_flag_now("KGPU_BYTE_TRIE");  // no character-level copy of the trie: every kernel walks the bytes
         if (const char *e = getenv("KGPU_HOST_DEPTH")) cur.depth = strtoull(e, nullptr, 10);
         if (const char *e = getenv("KGPU_HOST_CHUNK_BYTES")) cur.chunk_bytes = strtoull(e, nullptr, 10);
         if (const char *e = getenv("KGPU_HOST_CHUNK_SENTS")) cur.chunk_sents = strtoull(e, nullptr, 10);
@@ -444,6 +445,18 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
             pp = (int32_t)q;
         }
         first[cp] = ok ? DaNode{pp, da[(size_t)pp].base} : DaNode{0, steps};
+    }
+    // Character-level copy of the trie (kgpu_chartrie.cpp): one dependent load per character instead of one per byte.
+    CharTrie ct;
+    const bool have_ct = !test_hooks().byte_trie && build_char_trie(da, cat.data(), cat.size(), ct);
+    if (have_ct) {
+        if ((rc = upload(d, ct.da, &d->view.da2)) || (rc = upload(d, ct.rec, &d->view.crec)) ||
+            (rc = upload(d, ct.nb_cp, &d->view.nb_cp)) || (rc = upload(d, ct.nb_code, &d->view.nb_code))) {
+            kgpu_dict_destroy(d);
+            return rc;
+        }
+        d->view.da2_len = (uint32_t)ct.da.size();
+        d->view.n_nb = (uint32_t)ct.nb_cp.size();
     }
     if ((rc = upload(d, first, &d->view.first)) ||
         (rc = upload(d, da, &d->view.da)) || (rc = upload(d, morphs, &d->view.morph)) ||

@@ -187,6 +187,43 @@ __device__ __forceinline__ uint32_t da_walk_first2(const DictView &d, const uint
     return steps;
 }
 
+// The walk over the character-level array (kgpu_chartrie.cpp): the lane sits on node p (base bp) `depth` characters into the sentence
+// from its start position; every round issues the terminator probe of p and the child for the next character's code together -- one
+// memory latency per CHARACTER.  code_at(depth): the code of the character `depth` positions after the start, 0xFFFF = none (end of the
+// sentence, or a character no key contains).  Loads are unconditional: a lane with nothing to ask reads slot 0, which matches nothing.
+// (p, bp) come from CharRec (the root's child for the first character); p == 0: no key starts with it.
+template <class CODE, class F>
+__device__ __forceinline__ void ct_walk(const DictView &d, int32_t p, int32_t bp, CODE &&code_at, F &&on_match) {
+    if (p == 0) return;
+    uint32_t depth = 1;
+    for (;;) {
+        const uint32_t c = code_at(depth);
+        const uint32_t q = (uint32_t)bp + c;
+        const bool doprobe = (uint32_t)bp < d.da2_len;
+        const bool donext = c != 0xFFFFu && q < d.da2_len;
+        const DaNode t = d.da2[doprobe ? (uint32_t)bp : 0u];   // + TERMINATOR (da.rs:166)
+        const DaNode nx = d.da2[donext ? q : 0u];
+        if (t.check == p && t.base < 0) { uint32_t id, dup; leaf_decode(d, t.base, id, dup); on_match(id, depth, dup); }
+        if (nx.check != p) break;  // da.rs:162-165 (slot 0 has check 0, nodes start at 1)
+        p = (int32_t)q;
+        bp = nx.base;
+        ++depth;
+    }
+}
+// Code of a character >= U+FFFF (the BMP table cannot name it): binary search in the dictionary's short list.
+__device__ __forceinline__ uint32_t ct_code_nonbmp(const DictView &d, uint32_t cp) {
+    uint32_t lo = 0, hi = d.n_nb;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (d.nb_cp[mid] < cp) lo = mid + 1; else hi = mid; }
+    return (lo < d.n_nb && d.nb_cp[lo] == cp) ? d.nb_code[lo] : 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t utf8_cp_at(const uint8_t *t) {  // valid UTF-8 (already checked)
+    const uint32_t b = t[0];
+    if (b < 0x80) return b;
+    if (b < 0xE0) return ((b & 0x1Fu) << 6) | (t[1] & 0x3Fu);
+    if (b < 0xF0) return ((b & 0x0Fu) << 12) | ((t[1] & 0x3Fu) << 6) | (t[2] & 0x3Fu);
+    return ((b & 0x07u) << 18) | ((t[1] & 0x3Fu) << 12) | ((t[2] & 0x3Fu) << 6) | (t[3] & 0x3Fu);
+}
+
 // Work-list plumbing shared by the kernels of a launch chain: launch k takes its sentence ids
 // from list `in_list` (nullptr = identity over [0, n)) and pushes the ones it does not
 // serve (LDS budget, routing) onto the next launch's list.  Work is a

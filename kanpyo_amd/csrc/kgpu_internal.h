@@ -5,6 +5,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 #include "../../include/kanpyo_gpu.h"
 
@@ -28,6 +29,20 @@ struct alignas(16) CatInfo {  // one per category byte value
     uint32_t pad;
 };
 enum : uint32_t { CAT_INVOKE = 1u, CAT_GROUP = 2u, CAT_HAS_UNK = 4u };
+// The character-level copy of the trie (kgpu_chartrie.cpp): what a walk needs to know about the character it starts with, in one 16-byte load.
+struct alignas(16) CharRec {
+    int32_t base, slot;   // the root's child for this character in the char-level array: its base and its slot (0: no key starts with it)
+    uint16_t code;        // the character's code in the char-level array (0xFFFF: in no key)
+    uint8_t cat, pad;     // char_category_def.rs:33-38, resolved (table[cp] if in range else table[0])
+    uint32_t pad2;
+};
+struct CharTrie {         // host side, before the upload
+    std::vector<DaNode> da;
+    std::vector<CharRec> rec;                // [65536]
+    std::vector<uint32_t> nb_cp, nb_code;    // characters >= U+FFFF that occur in keys, ascending, and their codes
+    uint32_t n_codes = 0;
+};
+bool build_char_trie(const std::vector<DaNode> &da, const uint8_t *cat, size_t cat_len, CharTrie &out);  // false: walk the bytes
 
 struct DictView {
     const DaNode *da;        uint32_t da_len;
@@ -47,6 +62,11 @@ struct DictView {
     // frequency-ranked ids the pairs a position needs fall into a few tiles, and the lanes of one gather instruction that
     // hit the same line share one request.  nullptr: ids not ranked or >= 8192 rows -- the pool kernel then uses `conn`.
     const int16_t *conn_tiled; uint32_t conn_rt64; uint32_t pad_;
+    // Character-level double array (kgpu_chartrie.cpp; nullptr: the dictionary is walked byte by byte): one dependent load per character
+    // instead of one per byte.  crec: per BMP code point; nb_cp / nb_code: the few characters >= U+FFFF that occur in keys.
+    const DaNode *da2;       uint32_t da2_len; uint32_t n_nb;
+    const CharRec *crec;
+    const uint32_t *nb_cp;   const uint32_t *nb_code;
 };
 
 // ---- per-ctx control block in device memory (zeroed before every batch) ---

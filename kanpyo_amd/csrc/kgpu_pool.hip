@@ -184,7 +184,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
     uint32_t stop_after;
     // (the empty asm makes the pointer opaque: what was read before it is dead, what is not used before the next one is never loaded)
 #define KGPU_ARGS() do { KArgs kq_ = kargs; asm volatile("" : "+s"(kq_)); \
-        d.da = kq_->d.da; d.da_len = kq_->d.da_len; d.leaf_dup = kq_->d.leaf_dup; d.first = kq_->d.first; d.morph = kq_->d.morph; d.n_morph = kq_->d.n_morph; d.unk_morph = kq_->d.unk_morph; d.n_unk_morph = kq_->d.n_unk_morph; d.conn = kq_->d.conn; d.conn_rows = kq_->d.conn_rows; d.bos_right = kq_->d.bos_right; d.eos_left = kq_->d.eos_left; d.cat = kq_->d.cat; d.cat_len = kq_->d.cat_len; d.cinfo = kq_->d.cinfo; d.conn_tiled = kq_->d.conn_tiled; d.conn_rt64 = kq_->d.conn_rt64; \
+        d.da = kq_->d.da; d.da_len = kq_->d.da_len; d.leaf_dup = kq_->d.leaf_dup; d.first = kq_->d.first; d.morph = kq_->d.morph; d.n_morph = kq_->d.n_morph; d.unk_morph = kq_->d.unk_morph; d.n_unk_morph = kq_->d.n_unk_morph; d.conn = kq_->d.conn; d.conn_rows = kq_->d.conn_rows; d.bos_right = kq_->d.bos_right; d.eos_left = kq_->d.eos_left; d.cat = kq_->d.cat; d.cat_len = kq_->d.cat_len; d.cinfo = kq_->d.cinfo; d.conn_tiled = kq_->d.conn_tiled; d.conn_rt64 = kq_->d.conn_rt64; d.da2 = kq_->d.da2; d.da2_len = kq_->d.da2_len; d.n_nb = kq_->d.n_nb; d.crec = kq_->d.crec; d.nb_cp = kq_->d.nb_cp; d.nb_code = kq_->d.nb_code; \
         a.utf8 = kq_->a.utf8; a.offsets = kq_->a.offsets; a.n = kq_->a.n; a.ctl = kq_->a.ctl; a.arena = kq_->a.arena; a.arena_bytes = kq_->a.arena_bytes; a.stage = kq_->a.stage; a.tok_count = kq_->a.tok_count; a.status = kq_->a.status; a.out = kq_->a.out; a.out_cap = kq_->a.out_cap; a.tok_offsets = kq_->a.tok_offsets; a.count_work = kq_->a.count_work; a.ovf[0] = kq_->a.ovf[0]; a.ovf[1] = kq_->a.ovf[1]; a.ovf[2] = kq_->a.ovf[2]; a.ovf[3] = kq_->a.ovf[3]; a.est_q8 = kq_->a.est_q8; a.dump_lattice = kq_->a.dump_lattice; a.fused_host = kq_->a.fused_host; a.fused_seq = kq_->a.fused_seq; a.stat_slots = kq_->a.stat_slots; \
         io.in_list = kq_->io.in_list; io.in_count = kq_->io.in_count; io.out_list = kq_->io.out_list; io.out_count = kq_->io.out_count; io.late_count = kq_->io.late_count; stop_after = kq_->stop_after; } while (0)
     KGPU_ARGS();
@@ -343,26 +343,56 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             for (int ch = nchunks - 1; ch >= 0; --ch) {
                 const uint32_t i = (uint32_t)ch * 64 + lane;
                 const bool active = i < C;
-                // categories (char_category_def.rs:33-38) of this character and of the next: requested here, consumed after the walk
-                const uint32_t cpi = active ? cp16[i] : 0u, cpn = (i + 1 < C) ? cp16[i + 1] : 0u;
+                const uint32_t cpi = active ? cp16[i] : 0xFFFFu;
                 uint32_t cat = 0x1FFu, ncat = 0x2FFu;
+                uint32_t cnt = 0, m = 0;
+                auto on_match = [&](uint32_t id, uint32_t nch, uint32_t dup) {
+                    const uint32_t nrec = 1u + (dup != NONE ? dup : (uint32_t)d.morph[id - 1].dup);  // index.rs:46-51
+                    if (m < MAXM && nch < 256) {
+                        if (MS == 4) mbuf[i * MAXM + m] = id | (nch << 21) | ((nrec < 8 ? nrec : 0u) << 29);
+                        else *(uint2 *)(mbuf + 2 * (i * MAXM + m)) = make_uint2(id, nch | (nrec << 8));
+                    } else ovf = 1;
+                    ++m;
+                    cnt += nrec;
+                    atomicAdd(&boff[i + nch], nrec);
+                };
+                if (d.da2) {
+                    // Character-level array (kgpu_chartrie.cpp): ONE 16-byte record per character gives its category, its code and the
+                    // root's child for it; the codes replace the code points in LDS (the chunks are walked last to first, so the
+                    // characters a walk runs into already have theirs), then every further character costs one dependent load.
+                    const CharRec r = d.crec[cpi != 0xFFFFu ? cpi : 0u];
+                    uint32_t code = 0xFFFFu;
+                    int32_t p0 = 0, bp0 = 0;
+                    if (active) {
+                        if (cpi != 0xFFFFu) { cat = r.cat; code = r.code; p0 = r.slot; bp0 = r.base; }
+                        else {  // not in the table (>= U+FFFF): category from the decode phase, code from the dictionary's short list
+                            cat = ccat[i];
+                            code = d.n_nb ? ct_code_nonbmp(d, utf8_cp_at(text + cbyte[i])) : 0xFFFFu;
+                            if (code != 0xFFFFu) {
+                                const uint32_t q = (uint32_t)d.da2[1].base + code;
+                                if (q < d.da2_len) { const DaNode nd = d.da2[q]; if (nd.check == 1) { p0 = (int32_t)q; bp0 = nd.base; } }
+                            }
+                        }
+                        cp16[i] = (uint16_t)code;
+                        ccat[i] = (uint8_t)cat;  // (the next position's run test and the emit phase's fallback read it)
+                    }
+                    wave_sync();
+                    if (i + 1 < C) ncat = ccat[i + 1];
+                    if (active) {
+                        ct_walk(d, p0, bp0, [&](uint32_t dep) -> uint32_t { return i + dep < C ? (uint32_t)cp16[i + dep] : 0xFFFFu; }, on_match);
+                        if (prof) wT += da_walk_first(d, text, cpi, cbyte[i], cbyte[i + 1], B, base_root, [](uint32_t, uint32_t, uint32_t) {});  // the reference's byte steps (work counters)
+                        mcnt[i] = (uint8_t)(m < MAXM ? m : MAXM);
+                    }
+                } else {
+                // categories (char_category_def.rs:33-38) of this character and of the next: requested here, consumed after the walk
+                const uint32_t cpn = (i + 1 < C) ? cp16[i + 1] : 0u;
                 if (active) cat = cpi != 0xFFFFu ? (cpi < d.cat_len ? d.cat[cpi] : d.cat[0]) : ccat[i];
                 if (i + 1 < C) ncat = cpn != 0xFFFFu ? (cpn < d.cat_len ? d.cat[cpn] : d.cat[0]) : ccat[i + 1];
-                uint32_t cnt = 0, m = 0;
                 if (active) {
-                    auto on_match = [&](uint32_t id, uint32_t nch, uint32_t dup) {
-                        const uint32_t nrec = 1u + (dup != NONE ? dup : (uint32_t)d.morph[id - 1].dup);  // index.rs:46-51
-                        if (m < MAXM && nch < 256) {
-                            if (MS == 4) mbuf[i * MAXM + m] = id | (nch << 21) | ((nrec < 8 ? nrec : 0u) << 29);
-                            else *(uint2 *)(mbuf + 2 * (i * MAXM + m)) = make_uint2(id, nch | (nrec << 8));
-                        } else ovf = 1;
-                        ++m;
-                        cnt += nrec;
-                        atomicAdd(&boff[i + nch], nrec);
-                    };
                     wT += da_walk_first(d, text, cpi, cbyte[i], cbyte[i + 1], B, base_root, on_match);
                     mcnt[i] = (uint8_t)(m < MAXM ? m : MAXM);
                     ccat[i] = (uint8_t)cat;  // (the emit phase's fallback reads it)
+                }
                 }
                 const uint64_t bm = __ballot(active && ncat != cat);
                 const uint64_t rest = bm >> lane;
