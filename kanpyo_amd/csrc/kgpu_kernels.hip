@@ -123,7 +123,8 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         // LDS): every step of a double-array walk reads one text byte and then the node that byte selects -- two dependent loads; from
         // LDS the first one costs an LDS access instead of a trip through the vector memory path.
         uint32_t toff = 0;
-        if constexpr (LDS_SWEEP) { const uint32_t tb = (B + 4 + 15) & ~15u; if (2 * tb <= lds_bytes) toff = tb; }
+        const bool ct = d.da2 != nullptr;  // character-level trie (kgpu_chartrie.cpp): the walks read character codes, not bytes; cp16[] then holds the codes
+        if constexpr (LDS_SWEEP) { const uint32_t tb = (B + 4 + 15) & ~15u; if (!ct && 2 * tb <= lds_bytes) toff = tb; }
         uint32_t C = 0, bad = 0, lensum = 0;
         if constexpr (LDS_SWEEP) {
             // 256 bytes a round, through LDS (in place when the text stays there, else a scratch block at its start): the continuation bytes are
@@ -177,14 +178,25 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                     }
                     C += __popcll(m);
                 }
-                uint32_t cv[4];
+                uint32_t cv[4], cd[4];
+                if (ct) {   // category and code from the character's record; what the table cannot name (>= U+FFFF): the slow way
+                    CharRec rr[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) cv[u] = d.cat[cpx[u] < d.cat_len ? cpx[u] : 0u];  // char_category_def.rs:33-38: table[ch] if in range else table[0]
+                    for (int u = 0; u < 4; ++u) rr[u] = d.crec[cpx[u] < 0xFFFFu ? cpx[u] : 0u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        cv[u] = rr[u].cat; cd[u] = rr[u].code;
+                        if (st[u] && cpx[u] >= 0xFFFFu) { cv[u] = d.cat[cpx[u] < d.cat_len ? cpx[u] : 0u]; cd[u] = d.n_nb ? ct_code_nonbmp(d, cpx[u]) : 0xFFFFu; }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { cv[u] = d.cat[cpx[u] < d.cat_len ? cpx[u] : 0u]; cd[u] = cpx[u] < 0xFFFFu ? cpx[u] : 0xFFFFu; }  // char_category_def.rs:33-38: table[ch] if in range else table[0]
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (st[u]) {
                         cbyte[ci[u]] = kk[u];
-                        cp16[ci[u]] = (uint16_t)(cpx[u] < 0xFFFFu ? cpx[u] : 0xFFFFu);
+                        cp16[ci[u]] = (uint16_t)cd[u];
                         ccat[ci[u]] = (uint8_t)(bad ? 0u : cv[u]);
                     }
             }
@@ -213,7 +225,9 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                 if (l == 4 && (cp < 0x10000 || cp > 0x10FFFF)) bad = 1;
                 lensum += l;
                 cbyte[ci] = k;
-                cp16[ci] = (uint16_t)(cp < 0xFFFFu ? cp : 0xFFFFu);
+                uint32_t code = cp < 0xFFFFu ? cp : 0xFFFFu;
+                if (ct) code = cp < 0xFFFFu ? (uint32_t)d.crec[cp].code : (d.n_nb ? ct_code_nonbmp(d, cp) : 0xFFFFu);
+                cp16[ci] = (uint16_t)code;
                 // char_category_def.rs:33-38: table[ch] if in range else table[0]
                 ccat[ci] = bad ? 0 : (cp < d.cat_len ? d.cat[cp] : d.cat[0]);
             }
@@ -224,7 +238,17 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             if (lane == 0) { a.status[s] = KGPU_SENT_INVALID_UTF8; a.tok_count[s] = 0; }
             continue;
         }
-        if (lane == 0) cbyte[C] = B;
+        if (lane == 0) { cbyte[C] = B; if (ct) cp16[C] = 0xFFFFu; }
+        if constexpr (LDS_SWEEP) {
+            if (ct) {   // the codes into LDS (2 bytes per character, when they take at most half of it): every walk step reads one, then the node it selects
+                const uint32_t tc = (2 * (C + 1) + 15) & ~15u;
+                if (2 * tc <= lds_bytes) {
+                    toff = tc;
+                    __syncthreads();
+                    for (uint32_t e = lane; e <= C; e += 64) ((uint16_t *)lds)[e] = cp16[e];
+                }
+            }
+        }
         // Per-end-position counters / fill cursors: in LDS when the sentence's C + 3 words fit (LDS atomics
         // instead of one global round trip per node), else in the HBM slab.
         uint32_t *cnt_e = boff, *fill_e = bfill;
@@ -234,7 +258,9 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             lds_cursors = toff + (uint64_t)(C + 3) * 4 <= lds_bytes;
             if (lds_cursors) { cnt_e = (uint32_t *)(lds + toff); fill_e = (uint32_t *)(lds + toff); }
         }
-        const uint8_t *wtext = toff ? (const uint8_t *)lds : text;  // what the walks read (count phase, and the emit phase's re-walks)
+        const uint8_t *wtext = (toff && !ct) ? (const uint8_t *)lds : text;  // what the walks read (count phase, and the emit phase's re-walks)
+        const uint16_t *wcode = (toff && ct) ? (const uint16_t *)lds : cp16;  // ... with the character-level trie
+        auto code_at = [&](uint32_t j) -> uint32_t { return (uint32_t)wcode[min(j, C)]; };  // ([C]: none)
         for (uint32_t e = lane; e < C + 3; e += 64) { cnt_e[e] = 0; if (!lds_cursors) bfill[e] = 0; }
         __syncthreads();
 
@@ -275,13 +301,20 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             uint32_t cpX[2], kbX[2], knX[2];
 #pragma unroll
             for (int x = 0; x < 2; ++x) { cpX[x] = actX[x] ? cp16[iX[x]] : 0xFFFFu; kbX[x] = actX[x] ? cbyte[iX[x]] : 0u; knX[x] = actX[x] ? cbyte[iX[x] + 1] : 0u; }
+            if (ct) {
+                ct_walk2(d, actX[0], [&](uint32_t dep) { return code_at(iX[0] + dep); }, on_match(0), actX[1], [&](uint32_t dep) { return code_at(iX[1] + dep); }, on_match(1));
+                if (a.count_work) {  // the reference's byte steps (work counters)
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) if (actX[x]) wT += da_walk(d, text, kbX[x], B, base_root, [](uint32_t, uint32_t, uint32_t) {});
+                }
+            } else
             wT += da_walk_first2(d, wtext, B, actX[0] && cpX[0] != 0xFFFFu, cpX[0], kbX[0], knX[0], on_match(0),
                                  actX[1] && cpX[1] != 0xFFFFu, cpX[1], kbX[1], knX[1], on_match(1));
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 if (!actX[x]) continue;
                 const uint32_t i = iX[x];
-                if (cpX[x] == 0xFFFFu) wT += da_walk(d, wtext, kbX[x], B, base_root, on_match(x));  // first character outside the BMP: no table entry
+                if (!ct && cpX[x] == 0xFFFFu) wT += da_walk(d, wtext, kbX[x], B, base_root, on_match(x));  // first character outside the BMP: no table entry
                 uint32_t cnt = cntX[x];
                 const uint32_t m = mX[x];
                 mcnt[i] = (uint8_t)(m > GMAXM ? 0xFFu : m);
@@ -354,7 +387,10 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                 }
             };
             const uint32_t nm = mcnt[i];
-            if (nm == 0xFFu) da_walk(d, wtext, cbyte[i], B, base_root, emit_match);
+            if (nm == 0xFFu) {
+                if (ct) ct_walk(d, 1, d.da2[1].base, [&](uint32_t dep) { return code_at(i + dep); }, emit_match, 0u);
+                else da_walk(d, wtext, cbyte[i], B, base_root, emit_match);
+            }
             else for (uint32_t m = 0; m < nm; ++m) emit_match(mid[(size_t)i * GMAXM + m], mnch[(size_t)i * GMAXM + m]);
             const uint32_t span = uspan[i];
             if (span) {  // lattice.rs:87-97,190-201

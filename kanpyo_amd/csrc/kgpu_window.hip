@@ -42,8 +42,10 @@ constexpr uint32_t NEARLEN = WIN;           // a node up to this many characters
 constexpr uint32_t WMAXM = 8;              // trie matches parked per start position
 constexpr uint32_t LOOKB = 192;            // text bytes staged beyond the window's own characters (a walk that runs past them reads HBM)
 constexpr uint32_t TEXTB = 4 * WIN + LOOKB;
+constexpr uint32_t LCODE = 96;            // character codes staged per window (char-level trie): the window's own and what the walks run into; beyond, the slab
 constexpr uint32_t LTEXT = ((TEXTB + 4 > 260 ? TEXTB + 4 : 260) + 15) & ~15u;   // the staged block as aligned dwords (up to 3 bytes of misalignment in front); the decode pass's 256 + 3 bytes
 static_assert(LTEXT / 4 <= 128, "two dwords per lane");
+static_assert(2 * LCODE <= LTEXT && LCODE >= WIN && LCODE <= 128, "the codes share the text block's place");
 constexpr uint32_t NCH_LOG = 13, NCHUNKS = 32;   // node records: chunks of 8192 (128 KB), at most 262144 nodes per sentence
 constexpr uint32_t FCH_LOG = 12, FCHUNKS = 16;   // far entries: chunks of 4096 (64 KB), at most 65536 waiting at once
 constexpr uint32_t WIDE_MIN = 96;          // FIFO entries at one end position from which they are streamed instead of staged in LDS
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
     const KArgs kargs = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
     DictView d; BatchArgs a; WorkIO io;
 #define KW_ARGS() do { KArgs kq_ = kargs; asm volatile("" : "+s"(kq_)); \
-        d.da = kq_->d.da; d.da_len = kq_->d.da_len; d.leaf_dup = kq_->d.leaf_dup; d.first = kq_->d.first; d.morph = kq_->d.morph; d.n_morph = kq_->d.n_morph; d.unk_morph = kq_->d.unk_morph; d.n_unk_morph = kq_->d.n_unk_morph; d.conn = kq_->d.conn; d.conn_rows = kq_->d.conn_rows; d.bos_right = kq_->d.bos_right; d.eos_left = kq_->d.eos_left; d.cat = kq_->d.cat; d.cat_len = kq_->d.cat_len; d.cinfo = kq_->d.cinfo; d.conn_tiled = kq_->d.conn_tiled; d.conn_rt64 = kq_->d.conn_rt64; \
+        d.da = kq_->d.da; d.da_len = kq_->d.da_len; d.leaf_dup = kq_->d.leaf_dup; d.first = kq_->d.first; d.morph = kq_->d.morph; d.n_morph = kq_->d.n_morph; d.unk_morph = kq_->d.unk_morph; d.n_unk_morph = kq_->d.n_unk_morph; d.conn = kq_->d.conn; d.conn_rows = kq_->d.conn_rows; d.bos_right = kq_->d.bos_right; d.eos_left = kq_->d.eos_left; d.cat = kq_->d.cat; d.cat_len = kq_->d.cat_len; d.cinfo = kq_->d.cinfo; d.conn_tiled = kq_->d.conn_tiled; d.conn_rt64 = kq_->d.conn_rt64; d.da2 = kq_->d.da2; d.da2_len = kq_->d.da2_len; d.n_nb = kq_->d.n_nb; d.crec = kq_->d.crec; d.nb_cp = kq_->d.nb_cp; d.nb_code = kq_->d.nb_code; \
         a.utf8 = kq_->a.utf8; a.offsets = kq_->a.offsets; a.n = kq_->a.n; a.ctl = kq_->a.ctl; a.arena = kq_->a.arena; a.arena_bytes = kq_->a.arena_bytes; a.stage = kq_->a.stage; a.tok_count = kq_->a.tok_count; a.status = kq_->a.status; \
         io.in_list = kq_->io.in_list; io.in_count = kq_->io.in_count; io.out_list = kq_->io.out_list; io.out_count = kq_->io.out_count; } while (0)
     KW_ARGS();
@@ -215,12 +217,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
         //   .x = byte offset (24 bits) | category << 24     .y = BMP code point (0xFFFF: not BMP) | same-category run length from here << 16
         if (B >= (1u << 24)) { fail(s); continue; }
         const uint64_t na = (uint64_t)B + 4;
-        if (!slab_ensure(sa, na * 12 + 64, a, lane)) {
+        if (!slab_ensure(sa, na * 14 + 64, a, lane)) {
             if (lane == 0) { a.status[s] = KGPU_SENT_NO_SCRATCH; a.tok_count[s] = 0; }
             continue;
         }
         uint2 *crec = (uint2 *)sa.ptr;              // [C]: {B, 0}
         uint32_t *path = (uint32_t *)(crec + na);   // backtrace
+        uint16_t *code16 = (uint16_t *)(path + na); // char-level trie: the characters' codes (0xFFFF: in no key), [C] = 0xFFFF
+        const bool ct = d.da2 != nullptr;
 
         // ---- pass 0: decode + validate + category (char_category_def.rs:33-38), 256 bytes a round: the round's text goes through LDS (the
         // continuation bytes are read there), the next round's is in flight meanwhile, and the four category loads of a round are issued together --
@@ -276,14 +280,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     }
                     C += __popcll(m);
                 }
-                uint32_t cv[4];
+                uint32_t cv[4], cd[4];
+                if (ct) {   // category and code from the character's record (kgpu_chartrie.cpp); what the table cannot name: the slow way
+                    CharRec rr[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) cv[u] = d.cat[cpx[u] < d.cat_len ? cpx[u] : 0u];  // (cpx = 0 where no character starts: four loads, one wait)
+                    for (int u = 0; u < 4; ++u) rr[u] = d.crec[cpx[u] < 0xFFFFu ? cpx[u] : 0u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        cv[u] = rr[u].cat; cd[u] = rr[u].code;
+                        if (st[u] && cpx[u] >= 0xFFFFu) { cv[u] = d.cat[cpx[u] < d.cat_len ? cpx[u] : 0u]; cd[u] = d.n_nb ? ct_code_nonbmp(d, cpx[u]) : 0xFFFFu; }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { cv[u] = d.cat[cpx[u] < d.cat_len ? cpx[u] : 0u]; cd[u] = cpx[u] < 0xFFFFu ? cpx[u] : 0xFFFFu; }  // (cpx = 0 where no character starts: four loads, one wait)
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (st[u]) {
                         crec[ci[u]].x = kk[u] | ((bad ? 0u : cv[u]) << 24);
-                        *(uint16_t *)&crec[ci[u]].y = (uint16_t)(cpx[u] < 0xFFFFu ? cpx[u] : 0xFFFFu);
+                        *(uint16_t *)&crec[ci[u]].y = (uint16_t)cd[u];   // the code point (byte-level walk), or the code
+                        if (ct) code16[ci[u]] = (uint16_t)cd[u];
                     }
             }
         }
@@ -292,7 +308,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             if (lane == 0) { a.status[s] = KGPU_SENT_INVALID_UTF8; a.tok_count[s] = 0; }
             continue;
         }
-        if (lane == 0) crec[C] = make_uint2(B, 0u);
+        if (lane == 0) { crec[C] = make_uint2(B, 0u); if (ct) code16[C] = 0xFFFFu; }
         __syncthreads();
 #ifdef KGPU_WIN_SPLIT
         KW_T(1);
@@ -340,6 +356,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
         bool staged = false;
         auto prefetch = [&](uint32_t w0n, uint32_t tbn) {  // the records of positions w0n .. w0n + WIN and the text block from byte tbn, as aligned dwords
             if (lane <= WIN && w0n + lane <= C) pf_rec = crec[w0n + lane];
+            if (ct) {   // the codes of positions w0n .. w0n + LCODE - 1 (past the end: [C], "none")
+                pf_t0 = code16[min(w0n + lane, C)];
+                if (lane < LCODE - 64) pf_t1 = code16[min(w0n + 64 + lane, C)];
+                return;
+            }
             const uintptr_t g = (uintptr_t)(text + tbn);
             const uint32_t mis = (uint32_t)(g & 3u), tl = min(B - tbn, TEXTB) + mis;
             const uint32_t *g32 = (const uint32_t *)(g - mis);
@@ -363,8 +384,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 const uint32_t nfull = min(WIN, C - w0);
                 if (lane <= nfull) cbw[lane] = pf_rec.x & 0xFFFFFFu;
                 if (lane < nfull) { cp16w[lane] = (uint16_t)pf_rec.y; catw[lane] = (uint8_t)(pf_rec.x >> 24); rlenw[lane] = (uint16_t)(pf_rec.y >> 16); }
-                ((uint32_t *)ltext)[lane] = pf_t0;
-                if (lane < LTEXT / 4 - 64) ((uint32_t *)ltext)[64 + lane] = pf_t1;
+                if (ct) {
+                    ((uint16_t *)ltext)[lane] = (uint16_t)pf_t0;
+                    if (lane < LCODE - 64) ((uint16_t *)ltext)[64 + lane] = (uint16_t)pf_t1;
+                } else {
+                    ((uint32_t *)ltext)[lane] = pf_t0;
+                    if (lane < LTEXT / 4 - 64) ((uint32_t *)ltext)[64 + lane] = pf_t1;
+                }
                 staged = true;
             }
             for (uint32_t e = lane; e < REL + 2; e += 64) { boff[e] = 0; bfill[e] = 0; }
@@ -419,6 +445,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     cnt += nrec;
                     if (nch <= NEARLEN) atomicAdd(&boff[lane + nch], nrec); else nfar += nrec;
                 };
+                if (ct) {
+                    const uint16_t *lcode = (const uint16_t *)ltext;
+                    ct_walk(d, 1, d.da2[1].base, [&](uint32_t dep) -> uint32_t { const uint32_t j = lane + dep; return j < LCODE ? (uint32_t)lcode[j] : (uint32_t)code16[min(w0 + j, C)]; }, on_match, 0u);
+                    if constexpr (PROF) wTw += da_walk(d, text, cbw[lane], B, base_root, [](uint32_t, uint32_t, uint32_t) {});  // the reference's byte steps (work counters)
+                } else
                 wTw += win_walk(d, byte, cp16w[lane], cbw[lane], cbw[lane + 1], B, base_root, on_match);
                 mcnt[lane] = (uint8_t)(m < WMAXM ? m : WMAXM);
                 const CatInfo ci = d.cinfo[catw[lane]];
