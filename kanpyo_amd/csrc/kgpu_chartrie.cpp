@@ -4,9 +4,10 @@
 // node load per byte, three per Japanese character.  Every walk of the tokenizer starts at a character boundary of valid UTF-8 text
 // and keys are UTF-8 strings (Rust `String`s: no key ends inside a character), so the same key set can be walked one CHARACTER at a
 // time: this file re-indexes the byte-level trie as a double array over character codes -- one dependent load per character.
-//   * codes: 0 = the terminator edge (da.rs:118-123, 166), 1..n = the distinct characters that occur in keys, ascending by code point;
-//   * nodes: {base, check} exactly as in the byte-level array (child of slot p by code c: slot base[p] + c with check == p; a key's
-//     value: the terminator child, base = the byte-level leaf's (re-encoded) base, i.e. -(id | dup << 21) or -id);
+//   * codes: 1..n = the distinct characters that occur in keys, ascending by code point;
+//   * nodes: {base, check} as in the byte-level array (child of slot p by code c: slot base[p] + c with check == p) plus, in the same
+//     16-byte record, the key that ends on the node: leaf = the byte-level terminator child's (re-encoded) base, -(id | dup << 21) or
+//     -id (da.rs:118-123, 166) -- the walk learns it from the load that took it there, there is no terminator probe;
 //   * slot 0 is never used (a clamped load of it matches nothing), slot 1 is the root.
 // The result is an acceleration structure, not a format: it is derived from the caller's double array whatever built that, and the
 // byte-level array stays on the device (work counters count the reference's byte steps; dictionaries this file cannot represent --
@@ -117,12 +118,12 @@ bool build_char_trie(const std::vector<DaNode> &da, const uint8_t *cat, size_t c
     out.n_codes = (uint32_t)cps.size();
 
     // ---- placement: first fit over a free-slot chain (next free slot >= q, path-compressed), children of a node at base + code ----
-    std::vector<DaNode> &d2 = out.da;
+    std::vector<CtNode> &d2 = out.da;
     std::vector<uint32_t> nf;   // nf[q] = q if free, else a later slot to look at
     auto grow = [&](size_t need) {   // nf has one entry more than the array: nf[size] == size, "free, but not there yet"
         if (need <= d2.size()) return;
         const size_t n = std::max<size_t>(need, d2.size() * 2 + 1024), old = d2.size();
-        d2.resize(n, DaNode{0, 0});
+        d2.resize(n, CtNode{0, 0, 0, 0});
         nf.resize(n + 1);
         for (size_t q = old + 1; q <= n; ++q) nf[q] = (uint32_t)q;
     };
@@ -140,16 +141,16 @@ bool build_char_trie(const std::vector<DaNode> &da, const uint8_t *cat, size_t c
     take(0); take(1);  // slot 0: never used; slot 1: the root
     std::vector<uint32_t> slot_of(n_nodes, 0);
     slot_of[0] = 1;
-    d2[1] = DaNode{0, 0};
+    d2[1] = CtNode{0, 0, 0, 0};
     uint32_t cursor = 2;  // multi-child nodes start their search here; it moves on when a region has become too dense to be worth scanning
     std::vector<uint32_t> codes;
     for (uint32_t cn = 0; cn < n_nodes; ++cn) {
         const uint32_t e0 = first_edge[cn], e1 = first_edge[cn + 1];
         codes.clear();
-        if (leaf_of[cn] < 0) codes.push_back(0);
         for (uint32_t e = e0; e < e1; ++e) codes.push_back(code_of(edges[e].cp));
         const uint32_t ps = slot_of[cn];
-        if (codes.empty()) { d2[ps].base = 1; continue; }  // (a node without key and children: only in a corrupt array)
+        d2[ps].leaf = leaf_of[cn];
+        if (codes.empty()) continue;  // a key's last character: no children, base stays 0 (slot 0 + code: nothing there has this parent)
         const uint32_t c0 = codes.front(), cmax = codes.back();
         uint32_t q = next_free(std::max(codes.size() > 1 ? cursor : 2u, c0 + 1));
         uint32_t tries = 0;
@@ -161,10 +162,9 @@ bool build_char_trie(const std::vector<DaNode> &da, const uint8_t *cat, size_t c
             if (ok) {
                 d2[ps].base = (int32_t)b;
                 size_t k = 0;
-                if (leaf_of[cn] < 0) { d2[b] = DaNode{leaf_of[cn], (int32_t)ps}; take(b); k = 1; }
                 for (uint32_t e = e0; e < e1; ++e, ++k) {
                     const uint32_t t = b + codes[k];
-                    d2[t] = DaNode{0, (int32_t)ps};
+                    d2[t] = CtNode{0, (int32_t)ps, 0, 0};
                     take(t);
                     slot_of[edges[e].child] = t;
                 }
@@ -177,7 +177,7 @@ bool build_char_trie(const std::vector<DaNode> &da, const uint8_t *cat, size_t c
     }
     // trim, keeping room for base + any code (the kernels bound-check against the length anyway)
     size_t last = d2.size();
-    while (last > 2 && d2[last - 1].check == 0 && d2[last - 1].base == 0) --last;
+    while (last > 2 && d2[last - 1].check == 0) --last;
     d2.resize(last);
 
     // ---- per BMP code point: category, code, the root's child ----
@@ -190,7 +190,7 @@ bool build_char_trie(const std::vector<DaNode> &da, const uint8_t *cat, size_t c
         r.code = (uint16_t)code;
         if (code != 0xFFFFu) {
             const uint64_t q = (uint64_t)(int64_t)rb + code;
-            if (q < d2.size() && d2[(size_t)q].check == 1) { r.base = d2[(size_t)q].base; r.slot = (int32_t)q; }
+            if (q < d2.size() && d2[(size_t)q].check == 1) { r.base = d2[(size_t)q].base; r.slot = (int32_t)q; r.leaf = d2[(size_t)q].leaf; }
         }
     }
     for (uint32_t cp : cps)
@@ -249,16 +249,13 @@ extern "C" int kgpu_debug_chartrie_search(const uint8_t *index_blob, size_t blob
             if (q >= ct.da.size() || ct.da[(size_t)q].check != 1) continue;
             p = (int32_t)q; bp = ct.da[(size_t)q].base;
         }
-        for (;;) {
-            const uint64_t kb = k;  // bytes consumed up to and including node p's character
-            uint32_t c = 0xFFFFu;
-            const bool more = next_code(c);
-            const DaNode tn = (uint32_t)bp < ct.da.size() ? ct.da[(size_t)(uint32_t)bp] : DaNode{0, 0};
-            if (tn.check == p && tn.base < 0) {
-                if (np < cap_pairs) { out[2 * np] = (uint32_t)(-(int64_t)tn.base); out[2 * np + 1] = (uint32_t)kb; }
+        for (;;) {  // (ct_walk, kgpu_device.h)
+            if (ct.da[(size_t)p].leaf < 0) {
+                if (np < cap_pairs) { out[2 * np] = (uint32_t)(-(int64_t)ct.da[(size_t)p].leaf); out[2 * np + 1] = (uint32_t)k; }
                 ++np;
             }
-            if (!more || c == 0xFFFFu) break;
+            uint32_t c = 0xFFFFu;
+            if (!next_code(c) || c == 0xFFFFu) break;
             const uint64_t q = (uint64_t)(uint32_t)bp + c;
             if (q >= ct.da.size() || ct.da[(size_t)q].check != p) break;
             p = (int32_t)q; bp = ct.da[(size_t)q].base;

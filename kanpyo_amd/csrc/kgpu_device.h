@@ -188,25 +188,23 @@ __device__ __forceinline__ uint32_t da_walk_first2(const DictView &d, const uint
 }
 
 // The walk over the character-level array (kgpu_chartrie.cpp): the lane sits on node p (base bp) `depth` characters into the sentence
-// from its start position; every round issues the terminator probe of p and the child for the next character's code together -- one
-// memory latency per CHARACTER.  code_at(depth): the code of the character `depth` positions after the start, 0xFFFF = none (end of the
-// sentence, or a character no key contains).  Loads are unconditional: a lane with nothing to ask reads slot 0, which matches nothing.
-// (p, bp) come from CharRec (the root's child for the first character); p == 0: no key starts with it.
-// depth = 0, p = 1, bp = the root's base: the walk starts at the root (no CharRec at hand); the root itself is never probed for a key.
+// from its start position; every round loads the child for the next character's code -- ONE 16-byte load per character tells whether
+// the child exists, where its children are and which key ends on it.  code_at(depth): the code of the character `depth` positions after
+// the start, 0xFFFF = none (end of the sentence, or a character no key contains).  The load is unconditional: a lane with nothing to
+// ask reads slot 0, which has no parent.  (p, bp, leaf) come from CharRec (the root's child for the first character; p == 0: no key
+// starts with it), or -- depth = 0, p = 1, bp = the root's base, leaf = 0 -- the walk starts at the root.
 template <class CODE, class F>
-__device__ __forceinline__ void ct_walk(const DictView &d, int32_t p, int32_t bp, CODE &&code_at, F &&on_match, uint32_t depth = 1) {
+__device__ __forceinline__ void ct_walk(const DictView &d, int32_t p, int32_t bp, int32_t leaf, CODE &&code_at, F &&on_match, uint32_t depth = 1) {
     if (p == 0) return;
     for (;;) {
+        if (leaf < 0) { uint32_t id, dup; leaf_decode(d, leaf, id, dup); on_match(id, depth, dup); }
         const uint32_t c = code_at(depth);
         const uint32_t q = (uint32_t)bp + c;
-        const bool doprobe = depth > 0 && (uint32_t)bp < d.da2_len;
-        const bool donext = c != 0xFFFFu && q < d.da2_len;
-        const DaNode t = d.da2[doprobe ? (uint32_t)bp : 0u];   // + TERMINATOR (da.rs:166)
-        const DaNode nx = d.da2[donext ? q : 0u];
-        if (t.check == p && t.base < 0) { uint32_t id, dup; leaf_decode(d, t.base, id, dup); on_match(id, depth, dup); }
+        const CtNode nx = d.da2[(c != 0xFFFFu && q < d.da2_len) ? q : 0u];
         if (nx.check != p) break;  // da.rs:162-165 (slot 0 has check 0, nodes start at 1)
         p = (int32_t)q;
         bp = nx.base;
+        leaf = nx.leaf;
         ++depth;
     }
 }
@@ -220,19 +218,21 @@ __device__ __forceinline__ void ct_walk2(const DictView &d, bool onA, CA &&codeA
     while (a.live || b.live) {
         const uint32_t cA = a.live ? codeA(a.depth) : 0xFFFFu, cB = b.live ? codeB(b.depth) : 0xFFFFu;
         const uint32_t qA = (uint32_t)a.bp + cA, qB = (uint32_t)b.bp + cB;
-        const bool prA = a.live && a.depth > 0 && (uint32_t)a.bp < d.da2_len, prB = b.live && b.depth > 0 && (uint32_t)b.bp < d.da2_len;
-        const bool nxA = a.live && cA != 0xFFFFu && qA < d.da2_len, nxB = b.live && cB != 0xFFFFu && qB < d.da2_len;
-        const DaNode tA = d.da2[prA ? (uint32_t)a.bp : 0u], nA = d.da2[nxA ? qA : 0u];
-        const DaNode tB = d.da2[prB ? (uint32_t)b.bp : 0u], nB = d.da2[nxB ? qB : 0u];
+        const CtNode nA = d.da2[(cA != 0xFFFFu && qA < d.da2_len) ? qA : 0u];
+        const CtNode nB = d.da2[(cB != 0xFFFFu && qB < d.da2_len) ? qB : 0u];
         if (a.live) {
-            if (tA.check == a.p && tA.base < 0) { uint32_t id, dup; leaf_decode(d, tA.base, id, dup); matchA(id, a.depth, dup); }
             if (nA.check != a.p) a.live = false;
-            else { a.p = (int32_t)qA; a.bp = nA.base; ++a.depth; }
+            else {
+                a.p = (int32_t)qA; a.bp = nA.base; ++a.depth;
+                if (nA.leaf < 0) { uint32_t id, dup; leaf_decode(d, nA.leaf, id, dup); matchA(id, a.depth, dup); }
+            }
         }
         if (b.live) {
-            if (tB.check == b.p && tB.base < 0) { uint32_t id, dup; leaf_decode(d, tB.base, id, dup); matchB(id, b.depth, dup); }
             if (nB.check != b.p) b.live = false;
-            else { b.p = (int32_t)qB; b.bp = nB.base; ++b.depth; }
+            else {
+                b.p = (int32_t)qB; b.bp = nB.base; ++b.depth;
+                if (nB.leaf < 0) { uint32_t id, dup; leaf_decode(d, nB.leaf, id, dup); matchB(id, b.depth, dup); }
+            }
         }
     }
 }

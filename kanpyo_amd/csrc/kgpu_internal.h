@@ -29,15 +29,18 @@ struct alignas(16) CatInfo {  // one per category byte value
     uint32_t pad;
 };
 enum : uint32_t { CAT_INVOKE = 1u, CAT_GROUP = 2u, CAT_HAS_UNK = 4u };
-// The character-level copy of the trie (kgpu_chartrie.cpp): what a walk needs to know about the character it starts with, in one 16-byte load.
+// The character-level copy of the trie (kgpu_chartrie.cpp).  A node: one 16-byte load tells a walk whether the child exists (check), where its
+// children are (base) and whether a key ends on it (leaf < 0: the byte-level leaf's base, i.e. -(id | dup << 21) or -id) -- no terminator probe.
+struct alignas(16) CtNode { int32_t base, check, leaf, pad; };
+// ... and what a walk needs to know about the character it starts with, in one 16-byte load.
 struct alignas(16) CharRec {
     int32_t base, slot;   // the root's child for this character in the char-level array: its base and its slot (0: no key starts with it)
     uint16_t code;        // the character's code in the char-level array (0xFFFF: in no key)
     uint8_t cat, pad;     // char_category_def.rs:33-38, resolved (table[cp] if in range else table[0])
-    uint32_t pad2;
+    int32_t leaf;         // < 0: this character alone is a key (CtNode::leaf of the root's child)
 };
 struct CharTrie {         // host side, before the upload
-    std::vector<DaNode> da;
+    std::vector<CtNode> da;
     std::vector<CharRec> rec;                // [65536]
     std::vector<uint32_t> nb_cp, nb_code;    // characters >= U+FFFF that occur in keys, ascending, and their codes
     uint32_t n_codes = 0;
@@ -64,7 +67,7 @@ struct DictView {
     const int16_t *conn_tiled; uint32_t conn_rt64; uint32_t pad_;
     // Character-level double array (kgpu_chartrie.cpp; nullptr: the dictionary is walked byte by byte): one dependent load per character
     // instead of one per byte.  crec: per BMP code point; nb_cp / nb_code: the few characters >= U+FFFF that occur in keys.
-    const DaNode *da2;       uint32_t da2_len; uint32_t n_nb;
+    const CtNode *da2;       uint32_t da2_len; uint32_t n_nb;
     const CharRec *crec;
     const uint32_t *nb_cp;   const uint32_t *nb_code;
 };

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             };
             const uint32_t nm = mcnt[i];
             if (nm == 0xFFu) {
-                if (ct) ct_walk(d, 1, d.da2[1].base, [&](uint32_t dep) { return code_at(i + dep); }, emit_match, 0u);
+                if (ct) ct_walk(d, 1, d.da2[1].base, 0, [&](uint32_t dep) { return code_at(i + dep); }, emit_match, 0u);
                 else da_walk(d, wtext, cbyte[i], B, base_root, emit_match);
             }
             else for (uint32_t m = 0; m < nm; ++m) emit_match(mid[(size_t)i * GMAXM + m], mnch[(size_t)i * GMAXM + m]);

@@ -362,15 +362,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                     // characters a walk runs into already have theirs), then every further character costs one dependent load.
                     const CharRec r = d.crec[cpi != 0xFFFFu ? cpi : 0u];
                     uint32_t code = 0xFFFFu;
-                    int32_t p0 = 0, bp0 = 0;
+                    int32_t p0 = 0, bp0 = 0, lf0 = 0;
                     if (active) {
-                        if (cpi != 0xFFFFu) { cat = r.cat; code = r.code; p0 = r.slot; bp0 = r.base; }
+                        if (cpi != 0xFFFFu) { cat = r.cat; code = r.code; p0 = r.slot; bp0 = r.base; lf0 = r.leaf; }
                         else {  // not in the table (>= U+FFFF): category from the decode phase, code from the dictionary's short list
                             cat = ccat[i];
                             code = d.n_nb ? ct_code_nonbmp(d, utf8_cp_at(text + cbyte[i])) : 0xFFFFu;
                             if (code != 0xFFFFu) {
                                 const uint32_t q = (uint32_t)d.da2[1].base + code;
-                                if (q < d.da2_len) { const DaNode nd = d.da2[q]; if (nd.check == 1) { p0 = (int32_t)q; bp0 = nd.base; } }
+                                if (q < d.da2_len) { const CtNode nd = d.da2[q]; if (nd.check == 1) { p0 = (int32_t)q; bp0 = nd.base; lf0 = nd.leaf; } }
                             }
                         }
                         cp16[i] = (uint16_t)code;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                     wave_sync();
                     if (i + 1 < C) ncat = ccat[i + 1];
                     if (active) {
-                        ct_walk(d, p0, bp0, [&](uint32_t dep) -> uint32_t { return i + dep < C ? (uint32_t)cp16[i + dep] : 0xFFFFu; }, on_match);
+                        ct_walk(d, p0, bp0, lf0, [&](uint32_t dep) -> uint32_t { return i + dep < C ? (uint32_t)cp16[i + dep] : 0xFFFFu; }, on_match);
                         if (prof) wT += da_walk_first(d, text, cpi, cbyte[i], cbyte[i + 1], B, base_root, [](uint32_t, uint32_t, uint32_t) {});  // the reference's byte steps (work counters)
                         mcnt[i] = (uint8_t)(m < MAXM ? m : MAXM);
                     }

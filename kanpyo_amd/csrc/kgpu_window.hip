@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 };
                 if (ct) {
                     const uint16_t *lcode = (const uint16_t *)ltext;
-                    ct_walk(d, 1, d.da2[1].base, [&](uint32_t dep) -> uint32_t { const uint32_t j = lane + dep; return j < LCODE ? (uint32_t)lcode[j] : (uint32_t)code16[min(w0 + j, C)]; }, on_match, 0u);
+                    ct_walk(d, 1, d.da2[1].base, 0, [&](uint32_t dep) -> uint32_t { const uint32_t j = lane + dep; return j < LCODE ? (uint32_t)lcode[j] : (uint32_t)code16[min(w0 + j, C)]; }, on_match, 0u);
                     if constexpr (PROF) wTw += da_walk(d, text, cbw[lane], B, base_root, [](uint32_t, uint32_t, uint32_t) {});  // the reference's byte steps (work counters)
                 } else
                 wTw += win_walk(d, byte, cp16w[lane], cbw[lane], cbw[lane + 1], B, base_root, on_match);
