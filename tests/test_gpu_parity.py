@@ -583,3 +583,46 @@ def test_windowed_long_sentence_kernel(libs, window_kib, pool, monkeypatch):
     for _ in range(2):
         assert_same(tok, orc, sents)
     assert_same(tok, orc, ["", "", "すもも", ""])
+
+
+@pytest.mark.parametrize("pool,window_kib", [("40:4:48", "12"), ("0", "12"), ("0", "0")])
+def test_dictionary_keys_of_every_utf8_width(libs, pool, window_kib, monkeypatch):
+    """The device walks a character-level copy of the trie (kgpu_chartrie.cpp; reference walk: trie/da.rs:155-182, byte by byte).  Keys of 1-,
+    2-, 3- and 4-byte characters, keys that are prefixes of each other across widths, characters beyond the kernels' BMP table (non-BMP, and
+    U+FFFF, which shares the table's "not here" value) at the start, in the middle and at the end of keys -- through the pool kernel, the
+    windowed kernel and the HBM-lattice kernel (pool off / window off), short and very long sentences, the single-launch small-call path."""
+    from kanpyo_amd import Dict, Tokenizer
+
+    _, oracle = libs
+    monkeypatch.setenv("KGPU_POOL", pool)
+    monkeypatch.setenv("KGPU_WINDOW", window_kib)
+    rng = np.random.default_rng(17)
+    words = ["a", "ab", "abc", "é", "éa", "aé", "あ", "あい", "あ𠮷", "𠮷", "𠮷野", "𠮷野家", "野家", "😀", "😀😀", "a😀b", "￿", "￿x", "x￿y",
+             "い￿", "東京", "東京都", "京都", "都", "xyz𩸽", "𩸽", "λ", "λμ", "μあλ"]
+    kws = []
+    for w in sorted(set(words), key=lambda s: s.encode()):
+        kws += [w] * int(rng.integers(1, 4))
+    morphs = np.stack([rng.integers(0, 6, len(kws)), rng.integers(0, 6, len(kws)), rng.integers(-300, 6000, len(kws))], axis=1)
+    p = fixture_dict_parts()
+    d = Dict.from_parts(kws, morphs, 6, 6, rng.integers(-900, 900, 36), p["char_class"], p["char_category"],
+                        p["invoke_list"], p["group_list"], {0: (1, 1), 1: (1, 2), 2: (2, 1)}, [[0, 0, 4000], [1, 1, 3500]])
+    tok, orc = Tokenizer(d), oracle.OracleTokenizer.from_dict(d)
+    alphabet = list("abcéあい𠮷野家😀￿xy東京都𩸽λμz ")
+    sents = ["".join(rng.choice(alphabet, size=int(n))) for n in rng.integers(1, 60, 400)]
+    sents += ["".join(rng.choice(alphabet, size=int(n))) for n in (700, 1500, 2500)]  # the long-sentence kernels (>= 3072 bytes: the windowed one)
+    sents += ["", "𠮷", "￿", "😀" * 300, "𠮷野家" * 500, "a￿x￿y" * 200] + words
+    assert_same(tok, orc, sents)
+    assert_same(tok, orc, sents[:5])  # small call
+
+
+def test_byte_level_walk_is_kept_and_agrees(small, monkeypatch):
+    """KGPU_BYTE_TRIE=1: no character-level copy of the trie, every kernel walks the reference's byte-level double array as in rounds 1-2 (the
+    path a dictionary with 65535 or more distinct characters takes, and the one the work counters' byte steps come from)."""
+    from kanpyo_amd import Tokenizer, synth
+
+    sd, _, orc = small
+    monkeypatch.setenv("KGPU_BYTE_TRIE", "1")
+    tok = Tokenizer(sd.dict)
+    monkeypatch.delenv("KGPU_BYTE_TRIE")
+    assert_same(tok, orc, synth.make_corpus(sd, 3000, 41, "cfg2") + synth.make_corpus(sd, 300, 42, "cfg3") + synth.make_corpus(sd, 3, 43, "cfg5"))
+    assert_same(tok, orc, synth.make_corpus(sd, 5, 44, "cfg2"))
