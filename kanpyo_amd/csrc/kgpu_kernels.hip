@@ -942,15 +942,16 @@ LaunchPlan default_launch_plan(int device) {
     // start only then: four-wavefront workgroups drain sooner at the tail of a 4096-sentence batch than eight-
     // or sixteen-wavefront ones (80:8 66.3, 160:16 63.9, 40:4 68.6 M sentences/s; two-wavefront pools lose to
     // fragmentation, and any shape that is not 16 wavefronts per CU loses to the batch size: 4096 = 256 x 16).
-    // A sentence expected to need more than 48 of a pool's 64 pages (30 KB, ~185 chars) goes to the
+    // A sentence expected to need more than 40 of a pool's 64 pages (25 KB, ~155 chars) goes to the
     // long-sentence kernel instead: LDS x time grows with the square of the length, and a few long sentences
-    // would otherwise hold the pools while the short ones wait (cfg 3, M sentences/s by this limit: 32 pages 12.0,
-    // 40 12.2, 48 12.3, 56 11.6, 64 10.7; cfg 2 never gets there).
+    // would otherwise hold the pools while the short ones wait (cfg 3 in batches of 16384, M sentences/s by this limit:
+    // 16 pages 16.3, 24 16.8, 32 17.6-18.4, 40 17.8-18.8, 48 17.1-18.4; round 2, batches of 4096: 56 11.6, 64 10.7 against 12.3; cfg 2 is
+    // indifferent: 96.8-97.2 at 40, 96.4-97.0 at 48).
     // KGPU_POOL="<KiB>:<wavefronts>[:<max pages>][,...]", "0" = none.
     t.n_pools = 0;
     {
         const char *e = getenv("KGPU_POOL");
-        const char *q = e ? e : "40:4:48";
+        const char *q = e ? e : "40:4:40";
         while (*q && t.n_pools < 2) {
             int kib = atoi(q), w = 8, mp = 64;
             const char *c = q;

@@ -10,7 +10,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-POOLS = ["0", "8:2:64", "16:4:32", "40:4:32", "40:4:48", "40:8:20", "80:8:20", "80:10:64", "160:16:64", "80:8:20,160:4:64", "24:3:48"]
+POOLS = ["0", "8:2:64", "16:4:32", "40:4:32", "40:4:40", "40:4:48", "40:8:20", "80:8:20", "80:10:64", "160:16:64", "80:8:20,160:4:64", "24:3:48"]
 LONGS = ["0", "4", "12", "32", "160"]
 
 

@@ -565,7 +565,7 @@ def test_large_host_call_chunk_byte_counts(small):
         assert_same(tok, orc, sents)
 
 
-@pytest.mark.parametrize("window_kib,pool", [("12", "40:4:48"), ("16", "40:4:48"), ("16", "0"), ("24", "16:4:8")])
+@pytest.mark.parametrize("window_kib,pool", [("12", "40:4:40"), ("16", "40:4:48"), ("16", "0"), ("24", "16:4:8")])
 def test_windowed_long_sentence_kernel(libs, window_kib, pool, monkeypatch):
     """The windowed kernel (kgpu_window.hip, KGPU_WINDOW = KiB of LDS per workgroup; in the chain for sentences of 3072 bytes and more, for
     everything when there is no pool kernel): the lattice is built and relaxed window by window, only the carry list / the far FIFO /
@@ -585,7 +585,7 @@ def test_windowed_long_sentence_kernel(libs, window_kib, pool, monkeypatch):
     assert_same(tok, orc, ["", "", "すもも", ""])
 
 
-@pytest.mark.parametrize("pool,window_kib", [("40:4:48", "12"), ("0", "12"), ("0", "0")])
+@pytest.mark.parametrize("pool,window_kib", [("40:4:40", "12"), ("0", "12"), ("0", "0")])
 def test_dictionary_keys_of_every_utf8_width(libs, pool, window_kib, monkeypatch):
     """The device walks a character-level copy of the trie (kgpu_chartrie.cpp; reference walk: trie/da.rs:155-182, byte by byte).  Keys of 1-,
     2-, 3- and 4-byte characters, keys that are prefixes of each other across widths, characters beyond the kernels' BMP table (non-BMP, and
