@@ -141,6 +141,8 @@ typedef struct kgpu_routing {
                                  in-kernel rendezvous timed out)                                                     */
     uint64_t window_reruns;   /* batches rerun with the HBM-lattice kernel because the windowed long-sentence kernel
                                  handed a sentence back                                                              */
+    uint64_t tail_reruns;     /* batches rerun with the long-sentence kernel because the tail of the launch chain had been
+                                 left out (no recent batch needed it) and a sentence did need it                     */
 } kgpu_routing;
 
 /* The launch plan a context runs with (SURVEY.md 8d cfg 5: "LDS bytes / workgroup and achieved occupancy" as data). */

@@ -34,7 +34,7 @@ def kernel_source_hash() -> str:
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("kgpu_pool.hip", "kgpu_kernels.hip", "kgpu_device.h", "kgpu_internal.h"):
+    for name in ("kgpu_pool.hip", "kgpu_kernels.hip", "kgpu_device.h", "kgpu_internal.h", "kgpu_chartrie.cpp"):
         with open(os.path.join(_HERE, "csrc", name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
@@ -68,7 +68,7 @@ class Profile(C.Structure):  # kgpu_profile: 24 bytes, frozen
 class Routing(C.Structure):  # kgpu_routing: read with its size, fields are only ever appended
     _fields_ = [("batches", C.c_uint64), ("sentences", C.c_uint64), ("deferred", C.c_uint64 * 4), ("redone", C.c_uint64 * 4),
                 ("long_launches", C.c_uint64), ("arena_regrows", C.c_uint64), ("first_ms", C.c_double),
-                ("small_calls", C.c_uint64), ("small_fallbacks", C.c_uint64), ("window_reruns", C.c_uint64)]
+                ("small_calls", C.c_uint64), ("small_fallbacks", C.c_uint64), ("window_reruns", C.c_uint64), ("tail_reruns", C.c_uint64)]
 
 
 class PlanInfo(C.Structure):

@@ -170,6 +170,7 @@ struct kgpu_ctx {
     bool last_long = false;    // ... and whether the long-sentence kernel was
     bool last_window = false;  // ... and whether the windowed kernel was
     bool force_legacy_long = false;  // the pending batch is a rerun: the windowed kernel handed a sentence back
+    bool last_tail = true;     // ... whether the last-resort launch closed the chain (left out while no recent batch needed the tail)
     uint32_t event_every = 1;  // KGPU_PROFILE_SAMPLED: HIP events on every 4th launch only
     DevBuf arena, stage, tok_count;
     // host-buffer path staging
@@ -593,7 +594,11 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
         const bool window_now = c->plan.window_lds_bytes && !c->force_legacy_long && !a.dump_lattice && c->stop_after == 0 &&
                                 (c->plan.n_pools == 0 || c->dict->window_batches.load(std::memory_order_relaxed) > 0);
         c->last_window = window_now;
-        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->last_long, c->stop_after, c->stream, ef, window_now);
+        // The tail of the chain: the HBM-lattice kernel while recent batches left it sentences (last_long); otherwise nothing -- a sentence that
+        // does need it shows in the last work list's count, and kgpu_ctx_sync runs the batch again with the kernel armed.  (Without a
+        // long-sentence kernel in the plan, in ablation and dump runs the last-resort kernel closes every chain as before.)
+        c->last_tail = !(c->plan.n_pools > 0 && c->plan.long_lds_bytes && c->stop_after == 0 && !a.dump_lattice && !c->last_long);
+        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->last_long, c->stop_after, c->stream, ef, window_now, c->last_tail);
         if (e != hipSuccess) { set_error("k_tokenize launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     } else if (timed) HIPCHECK(hipEventRecord(ef, c->stream));
     if (timed) HIPCHECK(hipEventRecord(e1, c->stream));
@@ -699,6 +704,16 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
             if (c->last.stat_slots) HIPCHECK(hipMemsetAsync(c->last.stat_slots, 0, (size_t)STAT_SLOTS * STAT_WORDS * 8, c->stream));
             int rc = enqueue(c, c->last);
             c->force_legacy_long = false;
+            if (rc) { c->pending = false; return rc; }
+            continue;
+        }
+        if (!c->last_tail && !c->last_long && c->last.n && !c->h_ctl->arena_overflow &&
+            c->h_ctl->ovf_count[c->last_pools - 1 + (c->last_window ? 1 : 0)] > 0) {
+            // the chain ended without its tail and a sentence needed it: the batch once more, the long-sentence kernel armed
+            c->dict->long_batches.store(64, std::memory_order_relaxed);
+            c->rt.tail_reruns++;
+            if (c->last.stat_slots) HIPCHECK(hipMemsetAsync(c->last.stat_slots, 0, (size_t)STAT_SLOTS * STAT_WORDS * 8, c->stream));
+            int rc = enqueue(c, c->last);
             if (rc) { c->pending = false; return rc; }
             continue;
         }

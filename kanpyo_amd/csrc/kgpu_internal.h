@@ -148,7 +148,8 @@ struct LaunchPlan {
 int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now,
                     uint32_t stop_after /* kgpu_ctx_set_ablation; 0 = run everything */, void *stream,
                     void *event_after_first /* hipEvent_t recorded behind the first (dominant) launch, or null */,
-                    bool window_now = false /* the windowed kernel instead of the HBM-lattice one (plan.window_lds_bytes) */);
+                    bool window_now = false /* the windowed kernel in front of the HBM-lattice one (plan.window_lds_bytes) */,
+                    bool tail_now = true /* false: no last-resort launch behind a chain that has a work list (the host reruns the batch if one was needed) */);
 int window_workgroups_per_cu(uint32_t lds_bytes);
 int launch_general_only(const DictView &d, const BatchArgs &a, void *stream);
 int launch_small_call(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, void *stream);  // pool kernel alone, one sentence per wavefront  // kgpu_lattice_dump: HBM-scratch kernel alone

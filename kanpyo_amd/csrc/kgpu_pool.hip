@@ -191,6 +191,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
     const uint32_t pool_bytes = kargs->pool_bytes, max_pages = kargs->max_pages;
     const uint32_t lane = threadIdx.x & 63u, wave = bcast32(threadIdx.x >> 6) /* SGPR: everything per-sentence is wave-uniform */, W = blockDim.x >> 6;
     const int32_t base_root = d.da[1].base;
+    // a sentence this kernel does not serve: onto the next launch's list; its token count reads 0 until a later kernel has served it (when the
+    // host left the tail of the chain out -- no recent batch needed it -- the batch is run again with it: kgpu_api.cpp)
+    auto defer_s = [&](uint64_t s_) { work_defer(io, lane, s_); if (lane == 0) a.tok_count[s_] = 0; };
     uint64_t *bm = (uint64_t *)pool;
     // W == 1: the workgroup is one wavefront with a pool of its own -- a fixed LDS slice.  Nothing to share, nothing to wait for:
     // every sentence gets the whole slice (no estimate, no redo), what does not fit goes to the next launch.
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         const uint64_t Bl = a.offsets[s + 1] - b0;
         const uint32_t pool_cap = page * POOL_PAGES;
         if (Bl >= WINDOW_MIN_BYTES && lane == 0) atomicAdd(&a.ctl->very_long, 1u);  // (always beyond the routing limits below: max_pages <= 64 pages of <= 2.5 KB... of lattice, not text)
-        if (Bl + 64 > pool_cap || Bl > 0xFFF0) { work_defer(io, lane, s); continue; }
+        if (Bl + 64 > pool_cap || Bl > 0xFFF0) { defer_s(s); continue; }
         const uint32_t B = (uint32_t)Bl;
         const uint8_t *gtext = a.utf8 + b0;
         // chars of the sentence (sizes the per-position arrays); the bytes are re-read from L1 below
@@ -244,11 +247,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         uint32_t npg = own_slice ? POOL_PAGES : pages_for(est);
         // routing: a sentence expected to need more than max_pages would hold a large part of the pool for a long
         // time (LDS x time grows with the square of the length); it is better served by the long-sentence kernel
-        if (own_slice ? need1 > pool_cap : npg > max_pages) { work_defer(io, lane, s); continue; }
+        if (own_slice ? need1 > pool_cap : npg > max_pages) { defer_s(s); continue; }
         KGPU_TM(const uint64_t tm_p0 = __builtin_amdgcn_s_memtime();)
         uint32_t pg = pool_wait_alloc(bm, npg, lane);
         KGPU_TM(const uint64_t tm_p1 = __builtin_amdgcn_s_memtime(); tmPool += tm_p1 - tm_p0;)
-        if (pg == NONE) { work_defer(io, lane, s); continue; }
+        if (pg == NONE) { defer_s(s); continue; }
         for (uint32_t attempt = 0;; ++attempt) {  // at most one redo, with the exact size
         uint8_t *smem = pool + POOL_HDR + pg * page;
         const uint32_t lds_bytes = npg * page;
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                 }
             }
         }
-        if (__ballot(ovf != 0) != 0) { work_defer(io, lane, s); break; }
+        if (__ballot(ovf != 0) != 0) { defer_s(s); break; }
         if (lane == 0) {
             nb[C] = 1;       // EOS starts at C (lattice.rs:165-175)
             nb[C + 1] = 0;
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         const uint32_t off_emit_end = off;                          // everything above is written by emit
         uint16_t *pre = nLeft;                                      // (a block's sweep writes pre[t] after its gather has read nLeft[t])
         int16_t *mpair = (int16_t *)(smem + off);                   // pair table of one block; overlays the match buffer
-        if (N > 0xFFFF) { work_defer(io, lane, s); break; }
+        if (N > 0xFFFF) { defer_s(s); break; }
         // exact requirement: emit-written arrays stay below the match buffer; afterwards the pair table overlays it
         const uint32_t need_emit = off_emit_end + mbytes + 16, need_full = off + min(2 * E, max(2 * maxpairs, PAIR_CAP));
         if (need_emit > lds_bytes || off + 2 * maxpairs > lds_bytes) {
@@ -469,10 +472,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             pool_free(bm, pg, 0, npg, lane);
             if (lane == 0) atomicAdd(io.late_count, 1u);
             pg = NONE;
-            if (pages_for(max(need_emit, off + 2 * maxpairs)) > max_pages || attempt != 0) { work_defer(io, lane, s); break; }
+            if (pages_for(max(need_emit, off + 2 * maxpairs)) > max_pages || attempt != 0) { defer_s(s); break; }
             npg = min(max_pages, pages_for(max(need_emit, need_full)));
             pg = pool_wait_alloc(bm, npg, lane);
-            if (pg == NONE) { work_defer(io, lane, s); break; }
+            if (pg == NONE) { defer_s(s); break; }
             continue;
         }
         wave_sync();

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
     auto cbytes = [&](uint32_t n) { return align_up(8 * n, 16) + align_up(n, 16); };
 
     auto fail = [&](uint64_t s) {  // this sentence needs the HBM-lattice kernel: on to the next launch's list, or (no list) the host reruns the batch
-        if (io.out_list) work_defer(io, lane, s);
+        if (io.out_list) { work_defer(io, lane, s); if (lane == 0) a.tok_count[s] = 0; }
         else if (lane == 0) { a.status[s] = KGPU_SENT_NO_SCRATCH; a.tok_count[s] = 0; atomicExch(&a.ctl->window_fail, 1u); }
     };
     auto chunk_get = [&](uint32_t *table, uint32_t &have, uint32_t idx, uint32_t bytes) -> bool {  // make chunk idx exist (bytes: a multiple of 256)

@@ -67,7 +67,7 @@ class DeviceContext:
                 "batches": int(r.batches), "sentences": int(r.sentences), "deferred": [int(x) for x in r.deferred],
                 "redone": [int(x) for x in r.redone], "long_launches": int(r.long_launches),
                 "arena_regrows": int(r.arena_regrows), "first_ms": float(r.first_ms),
-                "small_calls": int(r.small_calls), "small_fallbacks": int(r.small_fallbacks), "window_reruns": int(r.window_reruns)}
+                "small_calls": int(r.small_calls), "small_fallbacks": int(r.small_fallbacks), "window_reruns": int(r.window_reruns), "tail_reruns": int(r.tail_reruns)}
 
     def plan(self) -> dict:
         """The launch plan (kgpu_plan_info): LDS bytes per workgroup and resident workgroups per CU of both kernels."""

@@ -291,7 +291,7 @@ def test_device_api_and_work_counters(full):
     assert np.array_equal(t.reshape(-1), exp.tokens.view(np.int32).reshape(-1))
     assert ctx.work() == exp.counters
     p = ctx.profile()
-    assert p["launches"] == 1 and p["tokenize_ms"] > 0
+    assert p["launches"] == 1 + p["tail_reruns"] and p["tokenize_ms"] > 0  # (a batch that finds the chain's tail left out is run twice)
 
 
 @pytest.mark.parametrize("pool,long_kib", [("0", "0"), ("0", "12"), ("0", "4"), ("0", "160"), ("80:10", "32"), ("80:8:20", "12"), ("80:8,160:4", "32"),
@@ -626,3 +626,29 @@ def test_byte_level_walk_is_kept_and_agrees(small, monkeypatch):
     monkeypatch.delenv("KGPU_BYTE_TRIE")
     assert_same(tok, orc, synth.make_corpus(sd, 3000, 41, "cfg2") + synth.make_corpus(sd, 300, 42, "cfg3") + synth.make_corpus(sd, 3, 43, "cfg5"))
     assert_same(tok, orc, synth.make_corpus(sd, 5, 44, "cfg2"))
+
+
+def test_chain_tail_is_left_out_and_comes_back(libs):
+    """While no recent batch left a sentence for the long-sentence kernels, the launch chain ends behind the pool kernel (no empty tail launch);
+    a batch that does need the tail is found by the last work list's count and run again with it (kgpu_routing.tail_reruns) -- same records
+    (src/tokenizer.rs:16: calls are independent, a rerun is invisible)."""
+    from kanpyo_amd import Tokenizer, synth
+    from kanpyo_amd.device import PROFILE_OFF
+
+    _, oracle = libs
+    sd = synth.build_dict(20000, seed=5)
+    tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
+    short = [s[:30] for s in synth.make_corpus(sd, 600, 9, "cfg2")]
+    reruns = 0
+    for k in range(14):  # the dictionary's contexts start with the tail armed; eight clean batches disarm it
+        ctx, t, toff, utf8, offs = _device_run(tok, short, PROFILE_OFF)
+        reruns += ctx.profile()["tail_reruns"]
+    assert reruns == 0
+    mixed = short[:100] + ["ア" * 900, "漢字かな" * 150] + synth.make_corpus(sd, 5, 10, "cfg3") + short[100:200]
+    ctx, t, toff, utf8, offs = _device_run(tok, mixed, PROFILE_OFF)
+    exp = orc.tokenize_batch(utf8, offs, 8)
+    assert np.array_equal(toff.astype(np.uint64), exp.offsets)
+    assert np.array_equal(t.reshape(-1), exp.tokens.view(np.int32).reshape(-1))
+    assert ctx.profile()["tail_reruns"] == 1
+    ctx, t, toff, utf8, offs = _device_run(tok, mixed, PROFILE_OFF)  # armed again: no rerun
+    assert np.array_equal(t.reshape(-1), exp.tokens.view(np.int32).reshape(-1)) and ctx.profile()["tail_reruns"] == 0
