@@ -907,7 +907,7 @@ def main():
 
             extras_orc = _orc.OracleTokenizer.from_dict(sd.dict)
         for kind, passes, lab in (("cfg5", 40, "BASELINE configs[4] (cfg 5): 1k sentences of 2048 chars, each with a same-category run > 1024 chars"),
-                                  ("cfg3", 2, f"BASELINE configs[2] (cfg 3): {args.cfg3_sentences} mixed-length (8-512 char) sentences incl. unknown-word path, batches of 16384")):
+                                  ("cfg3", 2, f"BASELINE configs[2] (cfg 3): {args.cfg3_sentences} mixed-length (8-512 char) sentences incl. unknown-word path, batches of 65536")):
             flag = os.path.join(extras_dir, kind + "_done.npy")
             t_wait = time.perf_counter()
             while not os.path.exists(flag) and extras_proc.is_alive() and time.perf_counter() - t_wait < 600:
@@ -919,9 +919,10 @@ def main():
             o = np.load(os.path.join(extras_dir, kind + "_offs.npy"))
             n_chars = int(np.load(flag)[0])
             try:
-                # cfg 3 names no batch size (BASELINE configs[2]): batches of 16384 -- a launch lasts as long as its longest sentence, and with one
-                # sentence per wavefront slot (4096) a few 500-char sentences decide a launch whose average is 120 (12.8 vs 15.6 M sentences/s)
-                wl_x = PackedWorkload(u, o, batch=16384 if kind == "cfg3" else BATCH)
+                # cfg 3 names no batch size (BASELINE configs[2]): batches of 65536 -- a launch lasts as long as its longest sentence, and with one
+                # sentence per wavefront slot (4096) a few 500-char sentences decide a launch whose average is 120 (round 3, M sentences/s by batch:
+                # 4096 12.8, 16384 19.0-19.2, 32768 19.5, 65536 19.9)
+                wl_x = PackedWorkload(u, o, batch=65536 if kind == "cfg3" else BATCH)
                 extra.append(measure_config(tok, dev, wl_x, n_chars, passes, args.queue, 0, lab, orc=extras_orc))
             except Exception as e:
                 print(f"{kind} leg failed: {e}", file=sys.stderr)

@@ -29,5 +29,9 @@ python "$REPO/tools/make_traffic_json.py" "$OUT/${TAG}_pmc_summary.json" "$OUT/p
 BENCH_Q=1 bash "$REPO/tools/pmc_passes.sh" "$OUT/pmc_cfg5" python "$REPO/tools/bench_cfg.py" cfg5 1000 > "$OUT/pmc_cfg5.log" 2>&1
 python "$REPO/tools/pmc_summary.py" "$OUT/pmc_cfg5" --json "$OUT/${TAG}_cfg5_pmc_summary.json" > "$OUT/${TAG}_cfg5_pmc_summary.txt"
 bash "$REPO/tools/pmc_phases.sh" "$OUT/phases" 1 2 3 4 5 6 7 0 > "$OUT/${TAG}_phase_counters.txt" 2>&1
+# the bench line once more, now that the counter files belong to this tree (traffic_stale false)
+cp "$OUT/pmc_traffic.json" "$OUT/pmc_instructions.json" "$REPO/profiles/"
+cp "$OUT/${TAG}_bench.json" "$OUT/${TAG}_bench_first.json"
+(cd "$REPO" && python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench2.err")
 rm -rf "$OUT"/trace "$OUT"/trace_cfg5 "$OUT"/trace_cfg3 "$OUT"/pmc/pass*/ "$OUT"/pmc_cfg5/pass*/ "$OUT"/phases
 echo done
