@@ -290,6 +290,35 @@ def dense_case(rng):
     return d, sents
 
 
+def width_case(rng):
+    """Like dense_case, over an alphabet of 1-, 2-, 3- and 4-byte characters (and U+FFFF): keys that are prefixes of each other across widths,
+    characters beyond the BMP at any place of a key -- what the character-level copy of the trie (kgpu_chartrie.cpp) has to get right.
+    -> (Dict, sentences)"""
+    nr = np.random.default_rng(rng.randrange(1 << 30))
+    pool = list("abé\u00dfλЖあい漢字\uffff") + ["\U00020BB7", "\U0001F600", "\U00029E3D", "\U0001D4B3"]
+    alpha = rng.sample(pool, rng.choice([3, 6, len(pool)]))
+    words = set()
+    for _ in range(rng.choice([10, 60, 400])):
+        words.add("".join(nr.choice(alpha, size=int(nr.integers(1, rng.choice([3, 5, 9]))))))
+    recs = []
+    for w in sorted(words, key=lambda x: x.encode()):
+        recs += [w] * int(nr.choice([1, 1, 2, 5]))
+    nctx = rng.choice([1, 4, 30])
+    morphs = np.stack([nr.integers(0, nctx, len(recs)), nr.integers(0, nctx, len(recs)), nr.integers(-2000, 9000, len(recs))], axis=1)
+    cat = np.zeros(65536, dtype=np.uint8)
+    for ch in alpha:
+        if ord(ch) < 65536 and rng.random() < 0.7:
+            cat[ord(ch)] = 1
+    unk = {0: (1, 1), 1: (2, rng.choice([1, 2]))}
+    um = [(0, 0, 5000)] + [(int(nr.integers(0, nctx)), int(nr.integers(0, nctx)), int(nr.integers(1000, 9000))) for _ in range(unk[1][1])]
+    d = Dict.from_parts(recs, morphs, nctx, nctx, nr.integers(-3000, 3000, nctx * nctx), ["DEFAULT", "H"], cat,
+                        np.array([0, rng.choice([0, 1])], dtype=np.uint8), np.array([1, rng.choice([0, 1])], dtype=np.uint8), unk, um)
+    text = alpha + list("xy\U0001F601")
+    sents = ["".join(nr.choice(text, size=int(nr.integers(1, rng.choice([8, 40, 200, 1500])))))
+             for _ in range(rng.choice([1, 7, 128, 129, 700, 3000]))]
+    return d, sents
+
+
 EDGE_SENTENCES = ["", "あ", "ア" * 700, "a" * 300, "𠮷野家で𩸽", "すもももももももものうち", "　　", "1234567890" * 40, "。" * 65]
 
 

@@ -63,6 +63,29 @@ def test_dense_dictionaries_every_sweep_shape(libs, seed, monkeypatch):
     assert total > 0
 
 
+@pytest.mark.parametrize("seed", [20260929, 1234])
+def test_keys_of_every_utf8_width_random_chains(libs, seed, monkeypatch):
+    """Sixteen dictionaries per seed over alphabets of 1- to 4-byte characters (synth.width_case): the character-level copy of the trie
+    (kgpu_chartrie.cpp) against the reference's byte-level walk (trie/da.rs:155-182) under random launch chains, the windowed kernel on or
+    off, and -- one in five -- with the byte-level walk itself on the device (KGPU_BYTE_TRIE)."""
+    from kanpyo_amd import Tokenizer, synth
+
+    _, oracle = libs
+    rng = random.Random(seed)
+    total = 0
+    for k in range(16):
+        pool, long_kib, window_kib = rng.choice(POOLS), rng.choice(LONGS), rng.choice(["0", "12", "16"])
+        byte_trie = rng.random() < 0.2
+        monkeypatch.setenv("KGPU_POOL", pool)
+        monkeypatch.setenv("KGPU_LONG", long_kib)
+        monkeypatch.setenv("KGPU_WINDOW", window_kib)
+        monkeypatch.setenv("KGPU_BYTE_TRIE", "1" if byte_trie else "0")
+        d, sents = synth.width_case(rng)
+        tok, orc = Tokenizer(d), oracle.OracleTokenizer.from_dict(d)
+        total += _same(tok, orc, sents, f"seed {seed} round {k} pool={pool} long={long_kib} window={window_kib} byte_trie={byte_trie}")
+    assert total > 0
+
+
 @pytest.mark.parametrize("seed,nkeys", [(9001, 20000), (4242, 6000), (777, 60000)])
 def test_mixed_corpora_random_chains(libs, seed, nkeys, monkeypatch):
     """IPADIC-shaped dictionaries of random size, shuffled mixes of cfg 2 / cfg 3 / cfg 5 text and edge sentences, three

@@ -14,6 +14,7 @@ from kanpyo_amd import Tokenizer, synth
 from kanpyo_amd.tokenizer import pack_sentences
 from oracle import oracle
 
+os.environ["KGPU_TEST_HOOKS_REREAD"] = "1"
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
@@ -24,10 +25,11 @@ while time.time() < t_end:
     long_kib = rng.choice(["0", "4", "12", "32", "160"])
     window_kib = rng.choice(["0", "0", "12", "16", "24"])  # the windowed long-sentence kernel in the chain (0 = off, the default)
     os.environ["KGPU_POOL"], os.environ["KGPU_LONG"], os.environ["KGPU_WINDOW"] = pool, long_kib, window_kib
-    if rng.random() < 0.4:  # a dense little dictionary: wide buckets, many targets
-        dd, mix = synth.dense_case(rng)
+    os.environ["KGPU_BYTE_TRIE"] = "1" if rng.random() < 0.15 else "0"  # (read at dictionary creation: KGPU_TEST_HOOKS_REREAD below)
+    if rng.random() < 0.4:  # a dense little dictionary: wide buckets, many targets -- or keys of every UTF-8 width
+        dd, mix = synth.dense_case(rng) if rng.random() < 0.6 else synth.width_case(rng)
         tok, orc = Tokenizer(dd), oracle.OracleTokenizer.from_dict(dd)
-        print(f"[{time.time() - (t_end - budget):6.1f}s] dense dictionary pool={pool} long={long_kib} window={window_kib} n={len(mix)}", flush=True)
+        print(f"[{time.time() - (t_end - budget):6.1f}s] dense / width dictionary byte_trie={os.environ['KGPU_BYTE_TRIE']} pool={pool} long={long_kib} window={window_kib} n={len(mix)}", flush=True)
         utf8, offs = pack_sentences(mix)
         exp = orc.tokenize_batch(utf8, offs, 16)
         got_t, got_off, status = tok.tokenize_packed(utf8, offs)
@@ -39,7 +41,7 @@ while time.time() < t_end:
         continue
     sd = synth.build_dict(nkeys, seed=rng.randrange(1 << 30))
     tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
-    print(f"[{time.time() - (t_end - budget):6.1f}s] keys={nkeys} pool={pool} long={long_kib} window={window_kib}", flush=True)
+    print(f"[{time.time() - (t_end - budget):6.1f}s] keys={nkeys} byte_trie={os.environ['KGPU_BYTE_TRIE']} pool={pool} long={long_kib} window={window_kib}", flush=True)
     for _ in range(3):
         mix = synth.mixed_case(sd, rng)
         utf8, offs = pack_sentences(mix)
