@@ -603,6 +603,7 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
     } else if (timed) HIPCHECK(hipEventRecord(ef, c->stream));
     if (timed) HIPCHECK(hipEventRecord(e1, c->stream));
     {
+        c->h_ctl->pack_overflow = 0;  // set by the compaction's workgroups in the host copy directly; this context's previous batch has been synced
         hipError_t e = (hipError_t)launch_scan_compact(a, c->h_ctl_dev, c->stream);
         if (e != hipSuccess) { set_error("scan/compact launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     }

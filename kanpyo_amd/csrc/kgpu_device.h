@@ -34,6 +34,14 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t /*lane*/
     v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2, 3
     return v;
 }
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {  // every lane gets the total
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64), lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {  // every lane gets the total
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0), 63);
 }

@@ -829,6 +829,82 @@ __global__ __launch_bounds__(256) void k_compact8(BatchArgs a, Control *host_ctl
     }
 }
 
+// Scan + compaction in ONE launch (batches of up to 65 536 sentences): workgroup w owns `per_wg` consecutive sentences; it sums the token counts in
+// front of them itself (a few KB of L2 reads) instead of waiting for a scan kernel -- whose single 1024-thread workgroup had to find a CU with
+// sixteen free wavefront slots on a chip full of pool-kernel wavefronts (8.5 us per batch, a second launch on the stream).  The LAST workgroup knows
+// the total: it writes tok_offsets[n], publishes the control block to the host copy and zeroes the device copy (every field but pack_overflow, which
+// this kernel's workgroups set in the host copy directly; the host clears it before the launch).
+template <bool REC8>
+__global__ __launch_bounds__(256) void k_scan_compact(BatchArgs a, Control *host_ctl, uint32_t per_wg) {
+    __shared__ uint64_t wsum[4];
+    __shared__ uint64_t loff[256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint64_t s0 = (uint64_t)blockIdx.x * per_wg;
+    uint64_t part = 0;
+    for (uint64_t i = tid; i < s0; i += 256) part += a.tok_count[i];
+    part = wave_sum64(part);
+    if (lane == 0) wsum[wid] = part;
+    __syncthreads();
+    const uint64_t prefix = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    const uint64_t si = s0 + tid;
+    const uint32_t v = (tid < per_wg && si < a.n) ? a.tok_count[si] : 0u;
+    const uint32_t vs = wave_incl_scan(v, lane);
+    if (lane == 63) wsum[wid] = vs;
+    __syncthreads();
+    uint64_t woff = 0;
+    for (uint32_t w = 0; w < wid; ++w) woff += wsum[w];
+    const uint64_t mine = prefix + woff + vs - v;
+    loff[tid] = mine;
+    if (tid < per_wg && si < a.n) a.tok_offsets[si] = mine;
+    const bool last_wg = s0 + per_wg >= a.n;
+    const uint64_t total = prefix + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (last_wg) {
+        if (tid == 0) a.tok_offsets[a.n] = total;
+        static_assert(sizeof(Control) % 4 == 0 && sizeof(Control) / 4 <= 256 * 4, "Control is copied a few dwords per thread");
+        for (uint32_t k = tid; k < sizeof(Control) / 4; k += 256) {
+            uint32_t *dc = (uint32_t *)a.ctl, *hc = (uint32_t *)host_ctl;
+            uint32_t x = dc[k];
+            const uint32_t nt = (uint32_t)(offsetof(Control, n_tokens) / 4);
+            if (k == nt) x = (uint32_t)total;
+            if (k == nt + 1) x = (uint32_t)(total >> 32);
+            if (k != (uint32_t)(offsetof(Control, pack_overflow) / 4)) __hip_atomic_store(&hc[k], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            dc[k] = 0;
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = wid; t < per_wg; t += 4) {   // one wavefront per sentence
+        const uint64_t sx = s0 + t;
+        if (sx >= a.n) break;
+        const uint64_t dst = loff[t];
+        const uint64_t nxt = t + 1 < 256 ? loff[t + 1] : total;  // (threads past the workgroup's sentences scanned zeros)
+        const uint32_t cnt = (uint32_t)(nxt - dst);
+        const kgpu_token *src = a.stage + (a.offsets[sx] - a.offsets[0] + sx);
+        if constexpr (REC8) {
+            if (lane == 0) {
+                const uint2 f = cnt ? make_uint2(src[0].position, src[0].start) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+                *(uint2 *)(a.first8 + 2 * sx) = f;
+                if (a.status8) a.status8[sx] = a.status[sx];
+                if (a.toff8) { a.toff8[sx] = dst; if (sx + 1 == a.n) a.toff8[a.n] = dst + cnt; }
+            }
+            if (dst + cnt > a.out_cap) continue;
+            bool bad = false;
+            for (uint32_t k = lane; k < cnt; k += 64) {
+                const kgpu_token tk = src[k];
+                const uint32_t chars = tk.end - tk.start;
+                bad |= chars > 0xFFFu || tk.byte_len > 0x3FFFFu;
+                *(uint2 *)(a.out8 + dst + k) = make_uint2((uint32_t)tk.id, tk.cls | (chars << 2) | (tk.byte_len << 14));
+            }
+            if (__ballot(bad) != 0 && lane == 0) __hip_atomic_store(&host_ctl->pack_overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            if (dst + cnt > a.out_cap) continue;
+            const uint32_t *srcw = (const uint32_t *)src;
+            uint32_t *out = (uint32_t *)(a.out + dst);
+            for (uint32_t w = lane; w < cnt * 6; w += 64) out[w] = srcw[w];
+        }
+    }
+}
+
 int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t pool_bytes, uint32_t waves,
                          uint32_t max_pages, int n_workgroups, uint32_t stop_after, void *stream);  // kgpu_pool.hip
 int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
@@ -907,6 +983,19 @@ int launch_general_only(const DictView &d, const BatchArgs &a, void *stream) {
 }
 
 int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream) {
+    // Measured (tools/ab_scan.sh): records bound for mapped host memory (the large host call: a.toff8) 83.8 against 66.6 M sentences/s end to end in one
+    // launch; the device-resident 24-byte path 92.8 against 96.9 -- there the separate kernels stay.  KGPU_SCAN_COMPACT=1 / 2 force one form (experiments),
+    // KGPU_SCAN_WG the sentences per workgroup.
+    static const int mode = [] { const char *e = getenv("KGPU_SCAN_COMPACT"); return e ? atoi(e) : 0; }();
+    static const int wg_env = [] { const char *e = getenv("KGPU_SCAN_WG"); const int v = e ? atoi(e) : 0; return (v >= 4 && v <= 256) ? v : 0; }();
+    if (a.n <= 65536 && (mode == 1 || (mode == 0 && a.toff8))) {
+        uint32_t per_wg = wg_env ? (uint32_t)wg_env : a.n <= 4096 ? 64u : a.n <= 16384 ? 128u : 256u;
+        if ((a.n + per_wg - 1) / per_wg > 65536) per_wg = 256;
+        const uint64_t wgs = a.n ? (a.n + per_wg - 1) / per_wg : 1;
+        if (a.out8) hipLaunchKernelGGL(k_scan_compact<true>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a, host_ctl, per_wg);
+        else hipLaunchKernelGGL(k_scan_compact<false>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a, host_ctl, per_wg);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, host_ctl);
     uint64_t blocks = (a.n + 3) / 4;
     if (blocks > 2048) blocks = 2048;
