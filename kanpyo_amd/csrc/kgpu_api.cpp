@@ -118,6 +118,28 @@ static TestHooks test_hooks() {
     return cur;
 }
 
+// Every slot of a double array has ONE parent (its check), so the child edges can only loop back through the root: a root that is itself some
+// node's child means a corrupt array whose breadth-first re-indexing (kgpu_chartrie.cpp) would never end.  Such a dictionary is walked byte by byte
+// (a walk is bounded by the sentence, whatever the array looks like).
+static bool char_trie_buildable(const std::vector<DaNode> &da) {
+    if (da.size() < 2) return false;
+    const int64_t p = da[1].check;
+    if (p < 1 || (size_t)p >= da.size() || p == 1) return true;
+    const int64_t b = da[(size_t)p].base, c = 1 - b;
+    return !(b >= 0 && c >= 0 && c <= 255);
+}
+// Test hook (tests/test_chartrie_cpu.py): would kgpu_dict_create build the character-level copy for this index.dict blob?
+extern "C" int kgpu_debug_char_trie_usable(const uint8_t *index_blob, size_t blob_len) {
+    if (!index_blob || blob_len < 8) return -1;
+    uint64_t n = 0;
+    std::memcpy(&n, index_blob, 8);
+    if (n > (blob_len - 8) / 8) return -1;
+    std::vector<DaNode> da((size_t)n);
+    if (n) std::memcpy(da.data(), index_blob + 8, (size_t)n * 8);
+    CharTrie ct;
+    return char_trie_buildable(da) && build_char_trie(da, nullptr, 0, ct) ? 1 : 0;
+}
+
 struct kgpu_dict {
     int device = 0;
     DictView view{};
@@ -449,7 +471,7 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
     }
     // Character-level copy of the trie (kgpu_chartrie.cpp): one dependent load per character instead of one per byte.
     CharTrie ct;
-    const bool have_ct = !test_hooks().byte_trie && build_char_trie(da, cat.data(), cat.size(), ct);
+    const bool have_ct = !test_hooks().byte_trie && char_trie_buildable(da) && build_char_trie(da, cat.data(), cat.size(), ct);
     if (have_ct) {
         if ((rc = upload(d, ct.da, &d->view.da2)) || (rc = upload(d, ct.rec, &d->view.crec)) ||
             (rc = upload(d, ct.nb_cp, &d->view.nb_cp)) || (rc = upload(d, ct.nb_code, &d->view.nb_code))) {

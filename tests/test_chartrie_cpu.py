@@ -99,3 +99,39 @@ def test_duplicate_keys_and_a_large_dictionary():
     assert info[0] < 8 * len(base)  # the array stays compact: a few slots per key
     for q, g in zip(queries, got):
         assert g == byte_level_search(blob, q)
+
+
+def test_what_the_copy_cannot_represent_falls_back_to_the_byte_walk():
+    """65 535 or more distinct characters in the keys (16-bit codes, 0xFFFF = none), or a corrupt array whose child edges loop: the builder
+    says no (the dictionary is then walked byte by byte on the device, as in rounds 1-2) instead of looping or running out of memory."""
+    chars = [chr(c) for c in range(0x20, 0xD800)] + [chr(c) for c in range(0xE000, 0xFFFE)] + [chr(c) for c in range(0x10000, 0x10000 + 3000)]
+    assert len(chars) >= 0xFFFF
+    blob = index_table_build(sorted(chars, key=lambda s: s.encode()))
+    L = _lib.lib()
+    f = L.kgpu_debug_chartrie_search
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+
+    def built(b):
+        offs, out, ooff, info = np.zeros(2, dtype=np.uint64), np.zeros((4, 2), dtype=np.uint32), np.zeros(2, dtype=np.uint64), np.zeros(3, dtype=np.uint64)
+        offs[1] = 1
+        t = np.frombuffer(b"a", dtype=np.uint8)
+        assert f(b, len(b), t.ctypes.data, offs.ctypes.data, 1, out.ctypes.data, 4, ooff.ctypes.data, info.ctypes.data) == 0
+        return int(info[2])
+
+    assert built(blob) == 0
+    # a loop: the root (slot 1, base 2) has child 'a' at slot 99, whose base 0 makes slot 1 ITS child by byte 0x01 -- kgpu_dict_create checks the
+    # root's parent before it hands the array to the builder (every slot has one parent, so a loop can only close through the root)
+    usable = L.kgpu_debug_char_trie_usable
+    usable.restype = C.c_int
+    usable.argtypes = [C.c_void_p, C.c_size_t]
+    n = 200
+    da = np.zeros((n, 2), dtype="<i4")
+    da[1] = (2, 99)
+    da[99] = (0, 1)
+    looped = struct.pack("<Q", n) + da.tobytes() + struct.pack("<Q", 0)
+    assert usable(looped, len(looped)) == 0
+    da[1] = (2, 0)  # ... the same array without the loop is fine
+    ok = struct.pack("<Q", n) + da.tobytes() + struct.pack("<Q", 0)
+    assert usable(ok, len(ok)) == 1 and built(ok) == 1
+    assert usable(blob, len(blob)) == 0
