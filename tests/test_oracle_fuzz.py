@@ -72,3 +72,27 @@ def test_pyref_and_c_oracle_agree(seed):
             assert [tuple(int(x) for x in t) for t in got] == exp, (seed, s)
             total += 1
     assert total >= 2500  # x 4 seeds = 11 000 sentences
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_pyref_and_c_oracle_agree_on_keys_of_every_utf8_width(seed):
+    """synth.width_case (1- to 4-byte characters and U+FFFF anywhere in a key): the dictionaries the gpu tests use to pin the device's
+    character-level trie walk -- here the two CPU restatements of the byte-level walk (trie/da.rs:155-182) against each other."""
+    import random
+
+    from kanpyo_amd import synth
+
+    rng = random.Random(seed)
+    total = 0
+    for _ in range(12):
+        d, sents = synth.width_case(rng)
+        parts = (d.index_dict, d.connection_dict, d.morph_dict, d.unk_dict, d.char_category, d.invoke_list, d.group_list)
+        o = oracle.OracleTokenizer(*parts)
+        p = pyref.PyDict(*parts)
+        for s in sents[:40]:
+            s = s[:60]
+            exp = pyref.tokenize(p, s)
+            got, _ctr = o.tokenize(s)
+            assert [tuple(int(x) for x in t) for t in got] == exp, (seed, s)
+            total += 1
+    assert total >= 200
