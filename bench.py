@@ -681,7 +681,7 @@ def main():
             "avg_kernel_ms": avg_kernel_s * 1e3, "launches_timed": prof["launches"],
             "avg_kernel_what": f"HIP events on the ctx stream around the k_tokenize_pool launch of every 4th batch, {Q} batches in flight on the "
                                "chip, four of them running (a launch therefore lasts several times its share of the chip's work; see "
-                               "kernel_alone_ms and frac_at_job_rate); profiles/r02_kernel_stats.csv holds rocprofv3's average for the same kernel",
+                               "kernel_alone_ms and frac_at_job_rate); profiles/r04_kernel_stats.csv / r04_pool_dispatches.txt hold rocprofv3's durations of the same kernel for the same command",
             "avg_launch_chain_ms": avg_chain_s * 1e3,
             "aux_kernels_avg_ms": prof["aux_ms"] / max(prof["launches"], 1),
             "launches_in_flight": Q,
@@ -838,7 +838,7 @@ def main():
                 result["pcie_inclusive"][name + "_calls_ms"] = [round(x * 1e3, 3) for x in ts]
                 del big
             result["pcie_inclusive"]["large_call_what"] = (f"kgpu_tokenize_batch, ONE call over {n_big} sentences (the cfg 2 corpus x {reps_c}), host memory in, dense 24-byte "
-                                                          "records out: chunks of <= 16384 sentences, 8-byte records written by the compaction kernel into mapped pinned "
+                                                          "records out: chunks of <= 8192 sentences, 8-byte records written by the compaction kernel into mapped pinned "
                                                           "memory, expanded into the caller's buffer by worker threads while later chunks compute")
             result["value_end_to_end"] = {"value": max(result["pcie_inclusive"]["large_call_pageable"], result["pcie_inclusive"]["large_call_pinned"]),
                                           "unit": "sentences/s", "what": "SURVEY 8(d) end-to-end incl. H2D / D2H: the better of pcie_inclusive.large_call_{pageable,pinned}; "

@@ -141,8 +141,10 @@ typedef struct kgpu_routing {
                                  in-kernel rendezvous timed out)                                                     */
     uint64_t window_reruns;   /* batches rerun with the HBM-lattice kernel because the windowed long-sentence kernel
                                  handed a sentence back                                                              */
-    uint64_t tail_reruns;     /* batches rerun with the long-sentence kernel because the tail of the launch chain had been
-                                 left out (no recent batch needed it) and a sentence did need it                     */
+    uint64_t tail_reruns;     /* batches whose long-sentence tail was launched afterwards (over the last work list only) because
+                                 the tail of the launch chain had been left out (no recent batch needed it) and a sentence did need it */
+    uint64_t combined_calls;  /* small kgpu_tokenize_batch calls that shared their launch with other threads' calls (the combiner) */
+    uint64_t combined_launches; /* ... and the launches they shared                                                      */
 } kgpu_routing;
 
 /* The launch plan a context runs with (SURVEY.md 8d cfg 5: "LDS bytes / workgroup and achieved occupancy" as data). */
@@ -158,7 +160,10 @@ typedef struct kgpu_plan_info {
     uint32_t window_lds_bytes;        /* windowed kernel (very long sentences): LDS per single-wavefront workgroup, 0 = off */
     uint32_t window_workgroups_per_cu;/* ... resident per CU (occupancy API)                                       */
     uint32_t window_min_bytes;        /* ... sentences at least this long take it                                  */
-    uint32_t reserved[5];
+    uint32_t streams;                 /* HIP streams the dictionary's NULL-stream contexts share: 4 when the process has GPU_MAX_HW_QUEUES >= 5
+                                         (the library sets it to 8 itself when it is loaded before the HIP runtime initialises and the variable
+                                         is unset), else 3 -- and kgpu_last_error() then carries a warning after kgpu_dict_create            */
+    uint32_t reserved[4];
 } kgpu_plan_info;
 int kgpu_ctx_get_plan(kgpu_ctx *c, kgpu_plan_info *out, size_t out_size);
 
@@ -211,6 +216,29 @@ int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint64_t *offse
                         kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets,
                         uint8_t *status, uint64_t *n_tokens);
 
+/* The same call over several devices of one node (reference src/tokenizer.rs:16 is &self, Send + Sync: a server shards its
+ * sentences; BASELINE cfg 4: "sharded round-robin"): sentence i goes to dicts[i mod n_dicts] -- one dictionary handle per device,
+ * made by kgpu_dict_create on that device (the same handle may appear more than once: its device then takes several shards) --
+ * one host thread per entry drives its device's chunk pipeline, every device's compaction kernel writes its 8-byte records into
+ * pinned host memory, and the records are expanded into `tokens` in the caller's ORIGINAL sentence order: the result is
+ * byte-for-byte what kgpu_tokenize_batch gives on one device.  No data-path collective: the shards are independent. */
+int kgpu_tokenize_batch_multi(kgpu_dict *const *dicts, int n_dicts, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
+                              kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets, uint8_t *status, uint64_t *n_tokens);
+
+/* Device-resident multi-device step with the result gather (the "trivial result gather over xGMI"): shard g -- n[g] sentences, packed
+ * as kgpu_tokenize_device wants them -- is resident on dicts[g]'s device; its compaction kernel stores the 8-byte records (and the
+ * per-sentence first position / start, token offsets and status bytes) straight into the ROOT device's memory through peer access
+ * (root_* [g]: device pointers on dicts[0]'s device, one set per shard) -- the stores are the transfer, there is no copy node and no
+ * collective.  `slot` in [0, slots): independent sets of contexts, so that several steps are in flight; kgpu_multi_sync(slot) waits
+ * for that slot's shards and reports the token count of each. */
+typedef struct kgpu_multi kgpu_multi;
+int kgpu_multi_create(kgpu_dict *const *dicts, int n_dicts, int slots, kgpu_multi **out);
+void kgpu_multi_destroy(kgpu_multi *m);
+int kgpu_multi_tokenize_device(kgpu_multi *m, int slot, const uint8_t *const *d_utf8, const uint64_t *const *d_offsets, const uint64_t *n,
+                               const uint64_t *total_bytes, kgpu_token8 *const *root_tokens8, const uint64_t *token_capacity,
+                               uint32_t *const *root_first, uint64_t *const *root_tok_offsets, uint8_t *const *root_status);
+int kgpu_multi_sync(kgpu_multi *m, int slot, uint64_t *n_tokens /* [n_dicts], may be NULL */);
+
 /* Pinned host memory for the buffers of kgpu_tokenize_batch (optional): with it the host<->device copies of a
  * large call run as DMA and overlap the kernels of its other chunks; pageable buffers work, more slowly. */
 void *kgpu_host_alloc(uint64_t bytes);
@@ -243,6 +271,9 @@ int kgpu_ctx_set_profiling(kgpu_ctx *c, int mode /* KGPU_PROFILE_* bit mask */);
 int kgpu_ctx_get_profile(kgpu_ctx *c, kgpu_profile *out, int reset);
 /* Copies min(out_size, sizeof(kgpu_routing)) bytes: a caller built against an older, shorter kgpu_routing stays valid. */
 int kgpu_ctx_get_routing(kgpu_ctx *c, kgpu_routing *out, size_t out_size, int reset);
+/* The same counters summed over the dictionary's pooled contexts -- the ones kgpu_tokenize_batch and kgpu_lattice_dump check out per call (idle
+ * ones only: a context serving a call right now is counted once it is back).  This is where small_calls / combined_calls show. */
+int kgpu_dict_get_routing(kgpu_dict *d, kgpu_routing *out, size_t out_size, int reset);
 /* Measurement only (bench.py's per-stage roofline): every sentence of the following batches stops
  * after the given stage of the fused kernel, yields zero tokens and status KGPU_SENT_TRUNCATED.
  * 0 = off (normal operation).  Stages: 5 = lattice built (SURVEY.md 8d Stage A: load, decode, trie

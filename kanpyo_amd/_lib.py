@@ -25,16 +25,19 @@ SYMBOLS = [
     "kgpu_tokenize_batch", "kgpu_ctx_create", "kgpu_ctx_destroy", "kgpu_tokenize_device", "kgpu_tokenize_device_compact", "kgpu_expand_tokens", "kgpu_ctx_sync",
     "kgpu_ctx_set_profiling", "kgpu_ctx_set_ablation", "kgpu_ctx_get_profile", "kgpu_ctx_get_routing", "kgpu_ctx_get_plan", "kgpu_ctx_get_work", "kgpu_ctx_get_phase_cycles", "kgpu_index_build", "kgpu_free",
     "kgpu_host_alloc", "kgpu_host_free", "kgpu_lattice_dump", "kgpu_lattice_free",
+    "kgpu_dict_get_routing", "kgpu_tokenize_batch_multi", "kgpu_multi_create", "kgpu_multi_destroy", "kgpu_multi_tokenize_device", "kgpu_multi_sync",
 ]
 
 
 def kernel_source_hash() -> str:
-    """sha256[:16] over the HIP sources of the library (kanpyo_amd/csrc: kernels, device helpers, shared structs).  Profile-derived
-    files under profiles/ record it, bench.py compares: a counter file measured on other kernel code says so (`stale`)."""
+    """sha256[:16] over every source and header the library is built from (the Makefile's SRCS and HDRS: kernels, device helpers,
+    shared structs, the runtime's launch planning).  Profile-derived files under profiles/ record it, bench.py compares: a counter
+    file measured on other code says so (`stale`)."""
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("kgpu_pool.hip", "kgpu_kernels.hip", "kgpu_device.h", "kgpu_internal.h", "kgpu_chartrie.cpp"):
+    for name in ("kgpu_pool.hip", "kgpu_kernels.hip", "kgpu_window.hip", "kgpu_device.h", "kgpu_internal.h", "kgpu_chartrie.cpp",
+                 "kgpu_api.cpp", "kgpu_multi.cpp", "kgpu_runtime.h", "kgpu_index_build.cpp", "../../include/kanpyo_gpu.h"):
         with open(os.path.join(_HERE, "csrc", name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
@@ -68,12 +71,14 @@ class Profile(C.Structure):  # kgpu_profile: 24 bytes, frozen
 class Routing(C.Structure):  # kgpu_routing: read with its size, fields are only ever appended
     _fields_ = [("batches", C.c_uint64), ("sentences", C.c_uint64), ("deferred", C.c_uint64 * 4), ("redone", C.c_uint64 * 4),
                 ("long_launches", C.c_uint64), ("arena_regrows", C.c_uint64), ("first_ms", C.c_double),
-                ("small_calls", C.c_uint64), ("small_fallbacks", C.c_uint64), ("window_reruns", C.c_uint64), ("tail_reruns", C.c_uint64)]
+                ("small_calls", C.c_uint64), ("small_fallbacks", C.c_uint64), ("window_reruns", C.c_uint64), ("tail_reruns", C.c_uint64),
+                ("combined_calls", C.c_uint64), ("combined_launches", C.c_uint64)]
 
 
 class PlanInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("compute_units", "pool_lds_bytes", "pool_wavefronts", "pool_workgroups_per_cu", "pool_max_pages",
-                                          "long_lds_bytes", "long_workgroups_per_cu", "long_workgroups", "window_lds_bytes", "window_workgroups_per_cu", "window_min_bytes")] + [("reserved", C.c_uint32 * 5)]
+                                          "long_lds_bytes", "long_workgroups_per_cu", "long_workgroups", "window_lds_bytes", "window_workgroups_per_cu", "window_min_bytes",
+                                          "streams")] + [("reserved", C.c_uint32 * 4)]
 
 
 class LatticeNode(C.Structure):
@@ -85,6 +90,14 @@ class LatticeNode(C.Structure):
 class LatticeOut(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("n_positions", C.c_uint64), ("nodes", C.POINTER(LatticeNode)),
                 ("edge_offsets", C.POINTER(C.c_uint32)), ("edge_nodes", C.POINTER(C.c_uint32))]
+
+
+class Token(C.Structure):  # kgpu_token
+    _fields_ = [("id", C.c_int32), ("cls", C.c_uint32), ("position", C.c_uint32), ("start", C.c_uint32), ("end", C.c_uint32), ("byte_len", C.c_uint32)]
+
+
+class Token8(C.Structure):  # kgpu_token8
+    _fields_ = [("id", C.c_int32), ("packed", C.c_uint32)]
 
 
 class Work(C.Structure):
@@ -125,6 +138,7 @@ def lib():
         L.kgpu_ctx_set_ablation.argtypes = [vp, C.c_int]
         L.kgpu_ctx_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
         L.kgpu_ctx_get_routing.argtypes = [vp, C.POINTER(Routing), C.c_size_t, C.c_int]
+        L.kgpu_dict_get_routing.argtypes = [vp, C.POINTER(Routing), C.c_size_t, C.c_int]
         L.kgpu_ctx_get_plan.argtypes = [vp, C.POINTER(PlanInfo), C.c_size_t]
         L.kgpu_ctx_get_work.argtypes = [vp, C.POINTER(Work), C.c_int]
         L.kgpu_ctx_get_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64 * 10), C.c_int]
@@ -138,6 +152,12 @@ def lib():
         L.kgpu_lattice_dump.argtypes = [vp, vp, C.c_uint64, C.POINTER(LatticeOut)]
         L.kgpu_lattice_free.argtypes = [C.POINTER(LatticeOut)]
         L.kgpu_lattice_free.restype = None
+        L.kgpu_tokenize_batch_multi.argtypes = [C.POINTER(vp), C.c_int, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, C.POINTER(C.c_uint64)]
+        L.kgpu_multi_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp)]
+        L.kgpu_multi_destroy.argtypes = [vp]
+        L.kgpu_multi_destroy.restype = None
+        L.kgpu_multi_tokenize_device.argtypes = [vp, C.c_int] + [vp] * 9
+        L.kgpu_multi_sync.argtypes = [vp, C.c_int, vp]
         _lib = L
     return _lib
 

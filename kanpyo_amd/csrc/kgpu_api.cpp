@@ -14,6 +14,7 @@
 #include <deque>
 #include <functional>
 #include <thread>
+#include <pthread.h>
 #include <unistd.h>
 #include <cstdarg>
 #include <cstdio>
@@ -23,7 +24,7 @@
 #include <mutex>
 #include <vector>
 
-#include "kgpu_internal.h"
+#include "kgpu_runtime.h"
 
 namespace kgpu {
 
@@ -38,15 +39,6 @@ void set_error(const char *fmt, ...) {
 }  // namespace kgpu
 
 using namespace kgpu;
-
-#define HIPCHECK(expr)                                                                  \
-    do {                                                                                \
-        hipError_t e_ = (expr);                                                         \
-        if (e_ != hipSuccess) {                                                         \
-            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return KGPU_ERR_HIP;                                                        \
-        }                                                                               \
-    } while (0)
 
 namespace {
 
@@ -63,43 +55,14 @@ struct Reader {
     size_t left() const { return n - at; }
 };
 
-struct DevBuf {
-    void *p = nullptr; size_t bytes = 0;
-    int ensure(size_t need) {
-        if (need <= bytes) return KGPU_OK;
-        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-        size_t want = need + need / 4 + 256;
-        HIPCHECK(hipMalloc(&p, want));
-        bytes = want;
-        return KGPU_OK;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
-};
-
-// Pinned host memory, optionally device-mapped (the device then reads / writes it over PCIe by itself).
-struct PinBuf {
-    void *h = nullptr, *d = nullptr; size_t bytes = 0;
-    int ensure(size_t need, bool mapped) {
-        if (need <= bytes) return KGPU_OK;
-        release();
-        size_t want = need + need / 4 + 4096;
-        if (hipHostMalloc(&h, want, mapped ? hipHostMallocMapped : hipHostMallocDefault) != hipSuccess) { h = nullptr; set_error("pinned allocation of %zu bytes failed", want); return KGPU_ERR_HIP; }
-        d = h;
-        if (mapped && hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); h = d = nullptr; set_error("hipHostGetDevicePointer failed"); return KGPU_ERR_HIP; }
-        bytes = want;
-        return KGPU_OK;
-    }
-    void release() { if (h) (void)hipHostFree(h); h = d = nullptr; bytes = 0; }
-};
 
 }  // namespace
 
 // Test-only environment hooks.  getenv is not thread-safe against setenv, and kgpu_tokenize_batch may be called from many
 // threads: the hooks are read under a mutex, ONCE per process -- unless KGPU_TEST_HOOKS_REREAD is set (tests/conftest.py sets
 // it: the tests flip the hooks between calls).
-struct TestHooks { bool no_small_calls = false, legacy_host_path = false, plain_leaves = false, byte_trie = false; uint64_t chunk_bytes = 4ull << 20, chunk_sents = 16384, depth = 12; };
 static bool env_flag_now(const char *name) { const char *e = getenv(name); return e && *e && *e != '0'; }
-static TestHooks test_hooks() {
+TestHooks kgpu::test_hooks() {
     static std::mutex mu;
     static TestHooks cur;
     static bool init = false;
@@ -114,6 +77,7 @@ static TestHooks test_hooks() {
         if (const char *e = getenv("KGPU_HOST_DEPTH")) cur.depth = strtoull(e, nullptr, 10);
         if (const char *e = getenv("KGPU_HOST_CHUNK_BYTES")) cur.chunk_bytes = strtoull(e, nullptr, 10);
         if (const char *e = getenv("KGPU_HOST_CHUNK_SENTS")) cur.chunk_sents = strtoull(e, nullptr, 10);
+        if (const char *e = getenv("KGPU_MULTI_CHUNK_SENTS")) cur.multi_chunk_sents = strtoull(e, nullptr, 10);  // kgpu_tokenize_batch_multi: sentences per device and chunk (tests: many small super-chunks)
     }
     return cur;
 }
@@ -140,88 +104,46 @@ extern "C" int kgpu_debug_char_trie_usable(const uint8_t *index_blob, size_t blo
     return char_trie_buildable(da) && build_char_trie(da, nullptr, 0, ct) ? 1 : 0;
 }
 
-struct kgpu_dict {
-    int device = 0;
-    DictView view{};
-    kgpu_dict_info info{};
-    std::vector<void *> allocs;
-    std::mutex pool_mu;
-    std::vector<kgpu_ctx *> pool;
-    // LDS bytes reserved per input byte (x256) by the pool kernel before the lattice is known; a
-    // property of the dictionary + the text, so it is learnt once and shared by all contexts
-    std::atomic<uint32_t> est_q8{80 * 256};
-    // Batches left for which the second (whole-CU) pool is launched.  Its workgroups need a CU's
-    // entire LDS just to start and find their list empty, which stalls them -- and the launches
-    // queued behind -- until both 80 KB pools of that CU have drained; so it is only issued while
-    // recent batches actually overflowed the first pool (otherwise those rare sentences take the
-    // HBM-scratch kernel).  Performance heuristic only: the chain is complete either way.
-    std::atomic<int> big_pool_batches{0};
-    // Same for the long-sentence kernel (its workgroups hold 32 KB of LDS each): issued while recent
-    // batches still had sentences left after the pools.
-    std::atomic<int> window_batches{64};  // same for the windowed kernel: armed while recent batches held sentences of WINDOW_MIN_BYTES or more (Control::very_long)
-    std::atomic<int> long_batches{64};  // starts armed: a corpus of long sentences does not spend its first batches in the last-resort kernel (3.8 ms per batch on cfg 3)
-    // Streams handed round-robin to contexts created without one.  HIP multiplexes streams onto three
-    // hardware queues: a 4th stream queues behind the 1st and unbalances them (measured -25 %), so any
-    // number of contexts shares three streams; each context waits on its own completion event.
-    std::vector<hipStream_t> streams;
-    unsigned next_stream = 0;
-    std::vector<uint32_t> left_of_rank, right_of_rank;  // device (ranked) context id -> the dictionary's own; empty = identity
-    // One reference for the handle the caller holds plus one per live context: the tables and the shared
-    // streams go when the last one does (a context outliving kgpu_dict_destroy keeps working).
-    std::atomic<int> refs{1};
-};
+static Combiner *combiner_new();
+static void combiner_delete(Combiner *c);
 
 static void dict_release(kgpu_dict *d) {
     if (d->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+    combiner_delete(d->combiner);
     (void)hipSetDevice(d->device);
     for (hipStream_t st : d->streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (void *p : d->allocs) (void)hipFree(p);
     delete d;
 }
 
-struct kgpu_ctx {
-    kgpu_dict *dict = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t done_ev = nullptr;  // recorded behind the batch's last kernel: contexts may share a stream
-    Control *d_ctl = nullptr;
-    Control *h_ctl = nullptr;  // pinned + device-mapped: the scan kernel publishes the launch's Control block here
-    Control *h_ctl_dev = nullptr;  // device-side address of h_ctl
-    bool ctl_dirty = true;     // d_ctl must be zeroed by the host (first launch, or after a failed enqueue)
-    uint32_t launch_seq = 0;
-    int last_pools = 0;        // pool launches issued for the pending batch
-    bool last_long = false;    // ... and whether the long-sentence kernel was
-    bool last_window = false;  // ... and whether the windowed kernel was
-    bool force_legacy_long = false;  // the pending batch is a rerun: the windowed kernel handed a sentence back
-    bool last_tail = true;     // ... whether the last-resort launch closed the chain (left out while no recent batch needed the tail)
-    uint32_t event_every = 1;  // KGPU_PROFILE_SAMPLED: HIP events on every 4th launch only
-    DevBuf arena, stage, tok_count;
-    // host-buffer path staging
-    DevBuf in_utf8, in_off, out_tok, out_off, out_status;
-    PinBuf pin_in, pin_out;       // large host calls: input staging (offsets | bytes), mapped result block (records | first | token offsets | status)
-    DevBuf in_block;              // ... and the device copy of the input block
-    // single-launch small calls: one pinned, device-mapped block (input | offsets | tokens | token offsets | status)
-    uint8_t *sm_host = nullptr, *sm_dev = nullptr;
-    uint32_t sm_seq = 0;
-    // last enqueued batch (for the arena-overflow retry and for sync)
-    BatchArgs last{};
-    bool pending = false;
-    LaunchPlan plan{};
-    DevBuf ovf;
-    DevBuf stat_slots;                             // profiling runs: per-wavefront counters of the pool kernel (BatchArgs::stat_slots)
-    std::vector<unsigned long long> stat_host;
-    // profiling
-    bool profiling = false;   // KGPU_PROFILE_EVENTS
-    bool count_work = false;  // KGPU_PROFILE_WORK
-    uint32_t stop_after = 0;  // kgpu_ctx_set_ablation: measurement mode, 0 = off
-    kgpu_work work{};
-    uint64_t phase[10] = {0};
-    std::vector<hipEvent_t> ev_pool;
-    size_t ev_used = 0;
-    kgpu_profile prof{};
-    kgpu_routing rt{};
-};
-
 extern "C" const char *kgpu_last_error(void) { return g_err; }
+
+// Concurrent launches need hardware queues: HIP gives a process GPU_MAX_HW_QUEUES of them (default 4, of which its streams get three), and
+// four launches side by side are the optimum of this library.  The variable is read when the HIP runtime initialises, so the
+// library sets it itself when it is loaded early enough -- before any HIP / HSA call of the process, i.e. while /dev/kfd is not open yet --
+// and the caller has not set it.  Loaded too late (or with the variable set below 5) it runs on three streams and says so
+// (kgpu_plan_info.streams, and a warning in kgpu_last_error after kgpu_dict_create).
+static bool g_queues_ok = false;
+static bool kfd_is_open() {
+    char link[64], target[256];
+    for (int fd = 0; fd < 256; ++fd) {
+        snprintf(link, sizeof link, "/proc/self/fd/%d", fd);
+        const ssize_t k = readlink(link, target, sizeof target - 1);
+        if (k > 0) { target[k] = 0; if (strcmp(target, "/dev/kfd") == 0) return true; }
+    }
+    return false;
+}
+__attribute__((constructor)) static void kgpu_preinit() {
+    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    if (e) { g_queues_ok = atoi(e) >= 5; return; }   // the caller's choice stands
+    if (kfd_is_open()) return;                          // the runtime is up already: too late, three streams
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    g_queues_ok = true;
+}
+static unsigned planned_streams() {
+    static const unsigned n = getenv("KGPU_STREAMS") && atoi(getenv("KGPU_STREAMS")) > 0 ? (unsigned)atoi(getenv("KGPU_STREAMS")) : (g_queues_ok ? 4u : 3u);
+    return n;
+}
 
 extern "C" int kgpu_device_count(void) {
     int n = 0;
@@ -444,6 +366,7 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
     if (device < 0 || device >= ndev) { set_error("kgpu_dict_create: device %d out of range (0..%d)", device, ndev - 1); return KGPU_ERR_INVALID_ARG; }
     HIPCHECK(hipSetDevice(device));
     kgpu_dict *d = new kgpu_dict();
+    d->combiner = combiner_new();
     d->device = device;
     d->right_of_rank.resize(rank_r.size()); d->left_of_rank.resize(rank_l.size());
     for (uint32_t i = 0; i < rank_r.size(); ++i) d->right_of_rank[rank_r[i]] = i;
@@ -500,6 +423,11 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
     d->info.da_len = da.size(); d->info.n_morphs = morphs.size(); d->info.n_unk_morphs = unk_morphs.size();
     d->info.conn_rows = rows; d->info.conn_cols = cols; d->info.device = device;
     *out = d;
+    g_err[0] = 0;
+    if (planned_streams() < 4)   // not an error: the handle is good, the message is there for whoever looks
+        set_error("warning: running on %u streams -- GPU_MAX_HW_QUEUES was %s when the HIP runtime initialised; set GPU_MAX_HW_QUEUES=8 in the environment "
+                  "(or load this library before the first HIP call) for the full rate of concurrent batches", planned_streams(),
+                  getenv("GPU_MAX_HW_QUEUES") ? "below 5" : "unset");
     return KGPU_OK;
 }
 
@@ -540,8 +468,7 @@ extern "C" int kgpu_ctx_create(kgpu_dict *d, void *hip_stream, kgpu_ctx **out) {
         // which its streams get one fewer; a stream beyond that shares a queue and unbalances them (4 streams on the
         // default: 52 M sentences/s instead of 68).  Four concurrent launches are the optimum (71.5; five: 58), so:
         // 4 streams when the process was started with GPU_MAX_HW_QUEUES >= 5, else 3.  KGPU_STREAMS overrides.
-        static const unsigned n_streams = getenv("KGPU_STREAMS") && atoi(getenv("KGPU_STREAMS")) > 0 ? (unsigned)atoi(getenv("KGPU_STREAMS"))
-                                          : (getenv("GPU_MAX_HW_QUEUES") && atoi(getenv("GPU_MAX_HW_QUEUES")) >= 5 ? 4u : 3u);
+        const unsigned n_streams = planned_streams();
         if (d->streams.size() < n_streams) {
             hipStream_t st = nullptr;
             hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
@@ -637,7 +564,7 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
     return KGPU_OK;
 }
 
-static int tokenize_device_impl(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n, uint64_t total_bytes,
+int kgpu::tokenize_device_impl(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n, uint64_t total_bytes,
                                 kgpu_token *d_tokens, kgpu_token8 *d_tokens8, uint32_t *d_first, uint8_t *status8, uint64_t *toff8, uint64_t token_capacity,
                                 uint64_t *d_tok_offsets, uint8_t *d_status, const char *who) {
     if (!c || !d_offsets || !d_tok_offsets || (n && !d_status) || (total_bytes && !d_utf8) ||
@@ -677,6 +604,25 @@ static int tokenize_device_impl(kgpu_ctx *c, const uint8_t *d_utf8, const uint64
     a.est_q8 = c->dict->est_q8.load(std::memory_order_relaxed);
     for (int k = 0; k < 4; ++k) a.ovf[k] = (uint32_t *)c->ovf.p + (size_t)k * (n + 1);
     return enqueue(c, a);
+}
+
+// The long-sentence kernel alone over work list `li` of the pending batch (which the chain left unserved), then scan + compaction again.
+static int enqueue_tail(kgpu_ctx *c, int li) {
+    const BatchArgs &a = c->last;
+    // (pinned source that must outlive the copy: a field of the context; the stream orders the copy before the kernels and after the scan kernel's zeroing)
+    HIPCHECK(hipMemcpyAsync(&c->d_ctl->ovf_count[li], &c->tail_count, sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    c->ctl_dirty = true;
+    c->last_long = true;
+    c->last_tail = true;
+    hipError_t e = (hipError_t)launch_tail_only(c->dict->view, a, c->plan, li, c->stream);
+    if (e != hipSuccess) { set_error("tail launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    c->h_ctl->pack_overflow = 0;
+    e = (hipError_t)launch_scan_compact(a, c->h_ctl_dev, c->stream);
+    if (e != hipSuccess) { set_error("scan/compact launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    HIPCHECK(hipEventRecord(c->done_ev, c->stream));
+    c->ctl_dirty = false;
+    c->pending = true;
+    return KGPU_OK;
 }
 
 extern "C" int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n,
@@ -732,12 +678,18 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
         }
         if (!c->last_tail && !c->last_long && c->last.n && !c->h_ctl->arena_overflow &&
             c->h_ctl->ovf_count[c->last_pools - 1 + (c->last_window ? 1 : 0)] > 0) {
-            // the chain ended without its tail and a sentence needed it: the batch once more, the long-sentence kernel armed
+            // The chain ended without its tail and a sentence needed it: ONLY the missing kernel, over the last work list (still in device
+            // memory; its length goes back into the control block the scan kernel zeroed), then scan + compaction once more.  The pool
+            // kernel's work is not repeated: a corpus with a sparse but steady share of long sentences pays one small launch per such
+            // batch, not the batch twice.  What the first pass counted (routing, estimate feedback, work counters) is kept and merged below.
+            const int li = c->last_pools - 1 + (c->last_window ? 1 : 0);
             c->dict->long_batches.store(64, std::memory_order_relaxed);
             c->rt.tail_reruns++;
-            if (c->last.stat_slots) HIPCHECK(hipMemsetAsync(c->last.stat_slots, 0, (size_t)STAT_SLOTS * STAT_WORDS * 8, c->stream));
-            int rc = enqueue(c, c->last);
-            if (rc) { c->pending = false; return rc; }
+            c->tail_saved = *c->h_ctl;
+            c->tail_pass = true;
+            c->tail_count = c->h_ctl->ovf_count[li];
+            int rc = enqueue_tail(c, li);
+            if (rc) { c->pending = false; c->tail_pass = false; return rc; }
             continue;
         }
         if (c->h_ctl->arena_overflow) {
@@ -749,6 +701,7 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
             BatchArgs a = c->last;
             a.arena = (uint8_t *)c->arena.p; a.arena_bytes = c->arena.bytes;
             c->rt.arena_regrows++;
+            c->tail_pass = false;  // (the whole batch runs again: nothing of an earlier pass is merged)
             // the rerun counts everything again: drop what the aborted run left in the per-wavefront slots (ctl->work went with the control block)
             if (a.stat_slots) HIPCHECK(hipMemsetAsync(a.stat_slots, 0, (size_t)STAT_SLOTS * STAT_WORDS * 8, c->stream));
             if ((rc = enqueue(c, a))) { c->pending = false; return rc; }
@@ -757,6 +710,17 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
         break;
     }
     c->pending = false;
+    if (c->tail_pass) {   // the published block is the tail pass's: put back what the first pass had counted
+        c->tail_pass = false;
+        Control &h = *c->h_ctl;
+        const Control &sv = c->tail_saved;
+        const int li = c->last_pools - 1 + (c->last_window ? 1 : 0);   // the list the tail served: it and the ones before it are the first pass's
+        for (int k = 0; k < 4; ++k) { if (k <= li) h.ovf_count[k] = sv.ovf_count[k]; h.late_count[k] += sv.late_count[k]; }
+        h.very_long += sv.very_long;
+        for (int k = 0; k < 7; ++k) h.work[k] += sv.work[k];
+        for (int k = 0; k < 10; ++k) h.phase[k] += sv.phase[k];
+        h.pack_overflow |= sv.pack_overflow;
+    }
     c->rt.batches++; c->rt.sentences += c->last.n;
     for (int k = 0; k < 4; ++k) { c->rt.deferred[k] += c->h_ctl->ovf_count[k]; c->rt.redone[k] += c->h_ctl->late_count[k]; }
     if (c->last_long && c->last.n) c->rt.long_launches++;
@@ -878,6 +842,7 @@ extern "C" int kgpu_ctx_get_plan(kgpu_ctx *c, kgpu_plan_info *out, size_t out_si
     p.long_workgroups_per_cu = c->plan.long_lds_bytes ? (uint32_t)long_workgroups_per_cu(c->plan.long_lds_bytes) : 0u;
     p.window_lds_bytes = c->plan.window_lds_bytes; p.window_min_bytes = WINDOW_MIN_BYTES;
     p.window_workgroups_per_cu = c->plan.window_lds_bytes ? (uint32_t)window_workgroups_per_cu(c->plan.window_lds_bytes) : 0u;
+    p.streams = planned_streams();
     std::memcpy(out, &p, std::min(out_size, sizeof p));
     return KGPU_OK;
 }
@@ -889,7 +854,40 @@ extern "C" int kgpu_ctx_get_routing(kgpu_ctx *c, kgpu_routing *out, size_t out_s
     return KGPU_OK;
 }
 
+extern "C" int kgpu_dict_get_routing(kgpu_dict *d, kgpu_routing *out, size_t out_size, int reset) {
+    if (!d || !out || out_size < 8) { set_error("kgpu_dict_get_routing: bad argument"); return KGPU_ERR_INVALID_ARG; }
+    kgpu_routing sum{};
+    {
+        std::lock_guard<std::mutex> g(d->pool_mu);
+        for (kgpu_ctx *c : d->pool) {
+            const kgpu_routing &r = c->rt;
+            sum.batches += r.batches; sum.sentences += r.sentences;
+            for (int k = 0; k < 4; ++k) { sum.deferred[k] += r.deferred[k]; sum.redone[k] += r.redone[k]; }
+            sum.long_launches += r.long_launches; sum.arena_regrows += r.arena_regrows; sum.first_ms += r.first_ms;
+            sum.small_calls += r.small_calls; sum.small_fallbacks += r.small_fallbacks; sum.window_reruns += r.window_reruns; sum.tail_reruns += r.tail_reruns;
+            sum.combined_calls += r.combined_calls; sum.combined_launches += r.combined_launches;
+            if (reset) c->rt = kgpu_routing{};
+        }
+    }
+    std::memcpy(out, &sum, std::min(out_size, sizeof sum));
+    return KGPU_OK;
+}
+
 // ------------------------------------------------------- host-buffer entry point
+int kgpu::pool_get(kgpu_dict *d, kgpu_ctx **out) {
+    kgpu_ctx *c = nullptr;
+    {
+        std::lock_guard<std::mutex> g(d->pool_mu);
+        if (!d->pool.empty()) { c = d->pool.back(); d->pool.pop_back(); }
+    }
+    if (!c) { int rc = kgpu_ctx_create(d, nullptr, &c); if (rc) return rc; }
+    *out = c;
+    return KGPU_OK;
+}
+void kgpu::pool_put(kgpu_dict *d, kgpu_ctx *c) {
+    std::lock_guard<std::mutex> g(d->pool_mu);
+    d->pool.push_back(c);
+}
 
 // ---- host-buffer entry point ---------------------------------------------------------------------------
 // One chunk of a host call in flight on one pooled context: H2D + kernels enqueued, results still on the device.
@@ -952,33 +950,56 @@ static int host_job_finish(HostJob &j, kgpu_token *tokens, uint64_t token_capaci
 // 8-byte kgpu_token8 records straight into pinned, device-mapped host memory (its stores are the transfer: no copy node, no
 // D2H call), and worker threads expand them into the caller's 24-byte records (any memory: the expansion replaces the copy
 // a pageable destination costs anyway) while the next chunks compute.
-struct WorkerPool {
-    std::mutex mu; std::condition_variable cv; std::deque<std::function<void()>> q; std::vector<std::thread> th; bool stop = false;
-    pid_t owner = 0;
-    void start() {
-        std::lock_guard<std::mutex> g(mu);
-        if (!th.empty() && owner == getpid()) return;
-        if (!th.empty()) {  // a fork()ed child: the parent's threads do not exist here; forget them (never joined) and start afresh
-            auto *leaked = new std::vector<std::thread>(std::move(th));  // (std::thread objects of threads that do not exist: neither joined nor destroyed)
-            (void)leaked;
-            th.clear(); q.clear();
-        }
-        owner = getpid();
-        unsigned n = 0;
-        if (const char *e = getenv("KGPU_HOST_THREADS")) n = (unsigned)atoi(e);
-        if (n == 0) n = std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 8));
-        for (unsigned i = 0; i < n; ++i) th.emplace_back([this] {
-            for (;;) {
-                std::function<void()> f;
-                { std::unique_lock<std::mutex> l(mu); cv.wait(l, [this] { return stop || !q.empty(); }); if (q.empty()) return; f = std::move(q.front()); q.pop_front(); }
-                f();
-            }
-        });
+namespace kgpu {
+// A few host threads for the large calls: expansion of the 8-byte records, staging copies.  Heap-allocated and never destroyed (its
+// threads end with the process).  fork(): the child has none of the parent's threads, and its copy of the pool may hold a locked mutex
+// or a condition variable with waiters -- the child handler abandons it and the first use there makes a fresh one.  Thread creation
+// can fail (std::system_error): start() reports how many threads run, and with none the caller takes the path that needs none.
+unsigned WorkerPool::start() {
+    std::lock_guard<std::mutex> g(mu);
+    if (!th.empty()) return (unsigned)th.size();
+    unsigned n = 0;
+    if (const char *e = getenv("KGPU_HOST_THREADS")) n = (unsigned)atoi(e);
+    if (n == 0) n = std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 8));
+    for (unsigned i = 0; i < n; ++i) {
+        try {
+            th.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> f;
+                    { std::unique_lock<std::mutex> l(mu); cv.wait(l, [this] { return !q.empty(); }); f = std::move(q.front()); q.pop_front(); }
+                    f();
+                }
+            });
+        } catch (...) { break; }  // out of threads: run with what there is
     }
-    void submit(std::function<void()> f) { { std::lock_guard<std::mutex> g(mu); q.push_back(std::move(f)); } cv.notify_one(); }
-    ~WorkerPool() { { std::lock_guard<std::mutex> g(mu); stop = true; } cv.notify_all(); for (auto &t : th) t.join(); }
-};
-static WorkerPool &workers() { static WorkerPool w; return w; }
+    return (unsigned)th.size();
+}
+void WorkerPool::submit(std::function<void()> f) { { std::lock_guard<std::mutex> g(mu); q.push_back(std::move(f)); } cv.notify_one(); }
+// A counter of tasks reaching zero: a short spin (the common case: the workers are almost through), then sleeps on the pool's
+// completion signal instead of burning a core the workers could use.
+void WorkerPool::wait_zero(std::atomic<int> &counter) {
+    for (int spin = 0; spin < 256; ++spin) { if (counter.load(std::memory_order_acquire) == 0) return; std::this_thread::yield(); }
+    std::unique_lock<std::mutex> l(done_mu);
+    while (counter.load(std::memory_order_acquire) != 0) done_cv.wait_for(l, std::chrono::microseconds(200));
+}
+void WorkerPool::task_done(std::atomic<int> &counter) {
+    if (counter.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> g(done_mu); done_cv.notify_all(); }
+}
+static std::atomic<WorkerPool *> g_pool{nullptr};
+static std::atomic<int> g_pool_lock{0};
+static void pool_atfork_child() { g_pool.store(nullptr, std::memory_order_relaxed); g_pool_lock.store(0, std::memory_order_relaxed); }
+WorkerPool &workers() {
+    WorkerPool *w = g_pool.load(std::memory_order_acquire);
+    if (w) return *w;
+    while (g_pool_lock.exchange(1, std::memory_order_acquire)) std::this_thread::yield();
+    static bool hooked = false;
+    if (!hooked) { hooked = true; pthread_atfork(nullptr, nullptr, pool_atfork_child); }
+    w = g_pool.load(std::memory_order_relaxed);
+    if (!w) { w = new WorkerPool(); g_pool.store(w, std::memory_order_release); }
+    g_pool_lock.store(0, std::memory_order_release);
+    return *w;
+}
+}  // namespace kgpu
 
 struct PipeJob {
     kgpu_ctx *c = nullptr;
@@ -989,7 +1010,7 @@ struct PipeJob {
 };
 
 // memcpy of a large block with the workers' help (the calling thread's staging copy is what limits a large call otherwise)
-static void parallel_copy(void *dst, const void *src, size_t bytes) {
+void kgpu::parallel_copy(void *dst, const void *src, size_t bytes) {
     constexpr size_t PIECE = 256 * 1024;
     if (bytes < 2 * PIECE) { std::memcpy(dst, src, bytes); return; }
     const size_t np = std::min<size_t>(8, bytes / PIECE), each = ((bytes + np - 1) / np + 63) & ~(size_t)63;  // np * each >= bytes (rounded UP: a floor here lost the last bytes of a chunk)
@@ -997,13 +1018,13 @@ static void parallel_copy(void *dst, const void *src, size_t bytes) {
     for (size_t k = 1; k < np; ++k) {
         const size_t lo = k * each, hi = std::min(bytes, lo + each);
         std::atomic<int> *l = &left;
-        workers().submit([=] { if (hi > lo) std::memcpy((uint8_t *)dst + lo, (const uint8_t *)src + lo, hi - lo); l->fetch_sub(1, std::memory_order_acq_rel); });
+        workers().submit([=] { if (hi > lo) std::memcpy((uint8_t *)dst + lo, (const uint8_t *)src + lo, hi - lo); workers().task_done(*l); });
     }
     std::memcpy(dst, src, std::min(bytes, each));
-    while (left.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    workers().wait_zero(left);
 }
 
-static bool is_pinned_host(const void *p) {
+bool kgpu::is_pinned_host(const void *p) {
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return at.type == hipMemoryTypeHost;
@@ -1014,7 +1035,7 @@ static bool is_pinned_host(const void *p) {
 // the context's pinned staging block, filled with the workers' help.
 static int pipe_submit(PipeJob &j, const uint8_t *utf8, const uint64_t *offsets, bool pinned_in) {
     kgpu_ctx *c = j.c;
-    while (j.tasks.load(std::memory_order_acquire) != 0) std::this_thread::yield();  // the block's previous results are still being expanded
+    workers().wait_zero(j.tasks);  // the block's previous results are still being expanded
     const uint64_t *off = offsets + j.lo;
     const uint64_t n = j.m, base = off[0], total = off[n] - base;
     j.total = total;
@@ -1059,6 +1080,9 @@ static int pipe_finish(PipeJob &j, const uint8_t *utf8, const uint64_t *offsets,
     uint64_t got = 0;
     int rc = kgpu_ctx_sync(c, &got);
     if (rc == KGPU_ERR_CAPACITY && c->h_ctl->pack_overflow) {  // a token beyond the 8-byte packing: this chunk once more, 24-byte records, the plain way
+        // (the previous chunk's last expansion slice stores tok_offsets[j.lo] too -- the boundary entry -- and host_job_finish copies and then adds
+        // to it: wait for the expansions in flight first)
+        workers().wait_zero(outstanding);
         HostJob hj;
         hj.c = c; hj.lo = j.lo; hj.m = j.m;
         if ((rc = host_job_submit(hj, utf8, offsets))) return rc;
@@ -1090,8 +1114,8 @@ static int pipe_finish(PipeJob &j, const uint8_t *utf8, const uint64_t *offsets,
                 if (b == m) tok_offsets[lo + m] = tok_base + toff[m];
             }
             if (status) std::memcpy(status + lo + a, st + a, (size_t)(b - a));
-            jt->fetch_sub(1, std::memory_order_acq_rel);
-            out->fetch_sub(1, std::memory_order_acq_rel);
+            workers().task_done(*jt);
+            workers().task_done(*out);
         });
     }
     return KGPU_OK;
@@ -1107,25 +1131,45 @@ static constexpr size_t SM_OFF_OFFS = SMALL_MAX_BYTES + 64, SM_OFF_TOK = SM_OFF_
                         SM_OFF_TOFF = SM_OFF_TOK + (SMALL_MAX_BYTES + SMALL_MAX_N) * sizeof(kgpu_token),
                         SM_OFF_STATUS = SM_OFF_TOFF + (SMALL_MAX_N + 1) * 8 + 56, SM_BYTES = SM_OFF_STATUS + SMALL_MAX_N + 64;
 
-// KGPU_OK: done; KGPU_ERR_CAPACITY: done, caller's buffer too small; -1: not served here (a sentence needs the long way)
-static int small_call(kgpu_dict *d, kgpu_ctx *c, const uint8_t *utf8, const uint64_t *offsets, uint64_t n, kgpu_token *tokens,
-                      uint64_t token_capacity, uint64_t *tok_offsets, uint8_t *status, uint64_t *n_tokens) {
-    const uint64_t base = offsets[0], total = offsets[n] - base;
+// One caller's part of a single-launch small call.
+struct SmallReq {
+    const uint8_t *utf8; const uint64_t *offsets; uint64_t n;
+    kgpu_token *tokens; uint64_t token_capacity; uint64_t *tok_offsets; uint8_t *status; uint64_t *n_tokens;
+    int rc = -1;              // KGPU_OK: done; KGPU_ERR_CAPACITY: done, this caller's buffer too small; -1: not served here (a sentence needs the long way)
+    char err[160] = "";       // the message behind rc (set_error is thread-local: the caller's thread repeats it)
+    bool done = false;
+};
+
+// The launch for one or more callers' sentences (`reqs` in arrival order; together at most SMALL_MAX_N sentences / SMALL_MAX_BYTES).
+// Returns KGPU_OK when the launch itself went through (every request then has its own rc), else the error (no request was served).
+static int small_call(kgpu_dict *d, kgpu_ctx *c, SmallReq *const *reqs, size_t nreq) {
+    uint64_t n = 0, total = 0;
+    for (size_t r = 0; r < nreq; ++r) { n += reqs[r]->n; total += reqs[r]->offsets[reqs[r]->n] - reqs[r]->offsets[0]; }
     int rc;
     if (!c->sm_host) {
         if (hipHostMalloc((void **)&c->sm_host, SM_BYTES, hipHostMallocMapped) != hipSuccess ||
             hipHostGetDevicePointer((void **)&c->sm_dev, c->sm_host, 0) != hipSuccess) {
             if (c->sm_host) { (void)hipHostFree(c->sm_host); c->sm_host = nullptr; }
-            return -1;
+            (void)hipGetLastError();
+            return KGPU_OK;  // every request keeps rc = -1: the general path
         }
     }
     if (c->pending && (rc = kgpu_ctx_sync(c, nullptr)) != KGPU_OK && rc != KGPU_ERR_CAPACITY) return rc;
     if ((rc = c->arena.ensure(ARENA_INITIAL)) || (rc = c->stage.ensure((size_t)(total + n + 1) * sizeof(kgpu_token) + 64)) ||
         (rc = c->tok_count.ensure((size_t)(n + 1) * 4)) || (rc = c->ovf.ensure((size_t)(n + 1) * 4 * 4)))
         return rc;
-    std::memcpy(c->sm_host, utf8 + base, (size_t)total);
     uint64_t *h_off = (uint64_t *)(c->sm_host + SM_OFF_OFFS);
-    for (uint64_t i = 0; i <= n; ++i) h_off[i] = offsets[i] - base;
+    {
+        uint64_t at = 0, si = 0;
+        for (size_t r = 0; r < nreq; ++r) {
+            const SmallReq &q = *reqs[r];
+            const uint64_t base = q.offsets[0], bytes = q.offsets[q.n] - base;
+            if (bytes) std::memcpy(c->sm_host + at, q.utf8 + base, (size_t)bytes);
+            for (uint64_t i = 0; i < q.n; ++i) h_off[si + i] = at + (q.offsets[i] - base);
+            at += bytes; si += q.n;
+        }
+        h_off[n] = at;
+    }
     const uint32_t seq = ++c->sm_seq ? c->sm_seq : ++c->sm_seq;  // never 0
     __atomic_store_n(&c->h_ctl->small_flag, 0u, __ATOMIC_RELEASE);
     BatchArgs a{};
@@ -1161,22 +1205,109 @@ static int small_call(kgpu_dict *d, kgpu_ctx *c, const uint8_t *utf8, const uint
     c->ctl_dirty = false;  // the publishing wavefront zeroed the device block
     c->rt.batches++; c->rt.sentences += n;
     c->rt.deferred[0] += c->h_ctl->ovf_count[0]; c->rt.redone[0] += c->h_ctl->late_count[0];
-    c->rt.small_calls++;
+    c->rt.small_calls += nreq;
+    if (nreq > 1) { c->rt.combined_calls += nreq; c->rt.combined_launches++; }
     if (c->h_ctl->ovf_count[0] != 0 || c->h_ctl->arena_overflow || c->h_ctl->small_abort) {  // a sentence left for the long / HBM-scratch kernels, or the rendezvous timed out
-        c->rt.small_fallbacks++;
-        return -1;
+        c->rt.small_fallbacks += nreq;
+        return KGPU_OK;  // rc = -1 everywhere: each caller takes the general path with its own sentences
     }
-    const uint64_t got = c->h_ctl->n_tokens;
-    if (n_tokens) *n_tokens = got;
     const uint64_t *h_toff = (const uint64_t *)(c->sm_host + SM_OFF_TOFF);
-    if (got > token_capacity) {
-        set_error("token buffer too small: need %llu, capacity %llu", (unsigned long long)got, (unsigned long long)token_capacity);
-        return KGPU_ERR_CAPACITY;
+    const kgpu_token *h_tok = (const kgpu_token *)(c->sm_host + SM_OFF_TOK);
+    uint64_t si = 0;
+    for (size_t r = 0; r < nreq; ++r) {   // every caller's dense slice
+        SmallReq &q = *reqs[r];
+        const uint64_t t0 = h_toff[si], got = h_toff[si + q.n] - t0;
+        if (q.n_tokens) *q.n_tokens = got;
+        if (got > q.token_capacity) {
+            snprintf(q.err, sizeof q.err, "token buffer too small: need %llu, capacity %llu", (unsigned long long)got, (unsigned long long)q.token_capacity);
+            q.rc = KGPU_ERR_CAPACITY;
+        } else {
+            if (got) std::memcpy(q.tokens, h_tok + t0, (size_t)got * sizeof(kgpu_token));
+            for (uint64_t i = 0; i <= q.n; ++i) q.tok_offsets[i] = h_toff[si + i] - t0;
+            if (q.status) std::memcpy(q.status, c->sm_host + SM_OFF_STATUS + si, (size_t)q.n);
+            q.rc = KGPU_OK;
+        }
+        si += q.n;
     }
-    std::memcpy(tokens, c->sm_host + SM_OFF_TOK, (size_t)got * sizeof(kgpu_token));
-    std::memcpy(tok_offsets, h_toff, (size_t)(n + 1) * 8);
-    if (status) std::memcpy(status, c->sm_host + SM_OFF_STATUS, (size_t)n);
     return KGPU_OK;
+}
+
+// ---- the combiner: concurrent small calls share one launch -------------------------------------------------------------
+// The reference's tokenize() takes &self and is Send + Sync (src/tokenizer.rs:16): a server calls it from many threads, one sentence
+// per call (src/bin/kanpyo.rs:106-126).  A launch costs the same ~50 us whether it carries one sentence or a hundred, so callers that
+// arrive while another small call is being assembled join it: the first one in is the leader -- it keeps the batch open for a short
+// window (only while other callers are inside the entry point: a lone caller never waits), takes a pooled context, launches, and hands
+// every follower its own dense slice back.  Followers sleep on a condition variable meanwhile.
+struct Combiner {
+    struct Batch { std::vector<SmallReq *> reqs; uint64_t n = 0, bytes = 0; bool closed = false; int launch_rc = KGPU_OK; char err[200] = ""; };
+    std::mutex mu;
+    std::condition_variable cv;
+    Batch *open = nullptr;
+    std::atomic<int> callers{0};
+};
+static Combiner *combiner_new() { return new Combiner(); }
+static void combiner_delete(Combiner *c) { delete c; }
+static Combiner &combiner_of(kgpu_dict *d) { return *d->combiner; }
+static unsigned combine_window_us() {
+    static const unsigned us = [] { const char *e = getenv("KGPU_COMBINE_US"); const int v = e ? atoi(e) : 15; return (unsigned)(v < 0 ? 0 : v > 1000 ? 1000 : v); }();
+    return us;
+}
+
+// KGPU_OK / KGPU_ERR_CAPACITY: served; -1: take the general path; other: error
+static int small_call_combined(kgpu_dict *d, SmallReq &me) {
+    Combiner &cb = combiner_of(d);
+    const uint64_t my_bytes = me.offsets[me.n] - me.offsets[0];
+    struct CallerCount { std::atomic<int> &c; CallerCount(std::atomic<int> &c_) : c(c_) { c.fetch_add(1, std::memory_order_acq_rel); } ~CallerCount() { c.fetch_sub(1, std::memory_order_acq_rel); } } in(cb.callers);
+    Combiner::Batch mine;
+    {
+        std::unique_lock<std::mutex> l(cb.mu);
+        Combiner::Batch *b = cb.open;
+        if (b && !b->closed && b->n + me.n <= SMALL_MAX_N && b->bytes + my_bytes <= SMALL_MAX_BYTES) {   // join the batch being assembled
+            b->reqs.push_back(&me); b->n += me.n; b->bytes += my_bytes;
+            cb.cv.wait(l, [&] { return me.done; });
+            if (me.rc > 0 && me.err[0]) set_error("%s", me.err);
+            return me.rc;
+        }
+        mine.reqs.push_back(&me); mine.n = me.n; mine.bytes = my_bytes;
+        cb.open = &mine;   // (a batch another leader still holds open but that has no room for me stays its leader's: it closes it itself)
+    }
+    // leader: keep the batch open for a short window while other callers are around (spinning: the window is shorter than a futex sleep)
+    const unsigned win = combine_window_us();
+    if (win && cb.callers.load(std::memory_order_acquire) > 1) {
+        timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (;;) {
+            for (int k = 0; k < 32; ++k) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+            timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000 >= (long long)win) break;
+            std::lock_guard<std::mutex> g(cb.mu);
+            if (mine.n >= SMALL_MAX_N || mine.bytes + 256 > SMALL_MAX_BYTES || (int)mine.reqs.size() >= cb.callers.load(std::memory_order_acquire)) break;  // full, or everyone who is here is in
+        }
+    }
+    {
+        std::lock_guard<std::mutex> g(cb.mu);
+        mine.closed = true;
+        if (cb.open == &mine) cb.open = nullptr;
+    }
+    kgpu_ctx *c = nullptr;
+    int rc = pool_get(d, &c);
+    if (!rc) {
+        rc = c->plan.n_pools ? small_call(d, c, mine.reqs.data(), mine.reqs.size()) : KGPU_OK;
+        pool_put(d, c);
+    }
+    {
+        std::lock_guard<std::mutex> g(cb.mu);
+        for (SmallReq *q : mine.reqs) {
+            if (rc) { q->rc = rc; snprintf(q->err, sizeof q->err, "%s", kgpu_last_error()); }
+            q->done = true;
+        }
+    }
+    if (mine.reqs.size() > 1) cb.cv.notify_all();
+    if (me.rc > 0 && me.rc != rc && me.err[0]) set_error("%s", me.err);
+    return me.rc;
 }
 
 // The plain form of a large call (24-byte records, device-to-host copies on the context's stream): what a chunk falls back to when
@@ -1249,18 +1380,8 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
     HIPCHECK(hipSetDevice(d->device));
 
     if (n >= 1 && n <= SMALL_MAX_N && offsets[n] - offsets[0] <= SMALL_MAX_BYTES && !test_hooks().no_small_calls) {
-        kgpu_ctx *c = nullptr;
-        {
-            std::lock_guard<std::mutex> g(d->pool_mu);
-            if (!d->pool.empty()) { c = d->pool.back(); d->pool.pop_back(); }
-        }
-        int rc = c ? KGPU_OK : kgpu_ctx_create(d, nullptr, &c);
-        if (rc) return rc;
-        rc = c->plan.n_pools ? small_call(d, c, utf8, offsets, n, tokens, token_capacity, tok_offsets, status, n_tokens) : -1;
-        {
-            std::lock_guard<std::mutex> g(d->pool_mu);
-            d->pool.push_back(c);
-        }
+        SmallReq me{utf8, offsets, n, tokens, token_capacity, tok_offsets, status, n_tokens};
+        const int rc = small_call_combined(d, me);
         if (rc != -1) return rc;  // -1: a sentence needs a kernel this path does not launch: take the general path below
     }
 
@@ -1268,7 +1389,7 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
     // chunk k+1 .. k+4 compute and chunk k+5's input is on its way.  Results are delivered in order, so the tokens stay dense.
     const TestHooks hooks = test_hooks();
     if (hooks.legacy_host_path) return tokenize_batch_legacy(d, utf8, offsets, n, tokens, token_capacity, tok_offsets, status, n_tokens, hooks);
-    workers().start();
+    if (workers().start() == 0) return tokenize_batch_legacy(d, utf8, offsets, n, tokens, token_capacity, tok_offsets, status, n_tokens, hooks);  // no worker threads to be had
     static const bool trace = env_flag_now("KGPU_HOST_TRACE");  // where the calling thread's time goes, per call, on stderr
     double t_submit = 0, t_finish = 0, t_tail = 0;
     auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
@@ -1318,7 +1439,7 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
         head = (head + 1) % DEPTH; --inflight;
     }
     const double t_drained = now();
-    while (outstanding.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    workers().wait_zero(outstanding);
     t_tail = now() - t_drained;
     {
         std::lock_guard<std::mutex> g(d->pool_mu);

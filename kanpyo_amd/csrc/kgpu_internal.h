@@ -150,6 +150,7 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
                     void *event_after_first /* hipEvent_t recorded behind the first (dominant) launch, or null */,
                     bool window_now = false /* the windowed kernel in front of the HBM-lattice one (plan.window_lds_bytes) */,
                     bool tail_now = true /* false: no last-resort launch behind a chain that has a work list (the host reruns the batch if one was needed) */);
+int launch_tail_only(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int list_index, void *stream);  // the long-sentence kernel over work list `list_index` (whose length the host has put back), leaving list_index + 1
 int window_workgroups_per_cu(uint32_t lds_bytes);
 int launch_general_only(const DictView &d, const BatchArgs &a, void *stream);
 int launch_small_call(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, void *stream);  // pool kernel alone, one sentence per wavefront  // kgpu_lattice_dump: HBM-scratch kernel alone

@@ -969,6 +969,25 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
     return (int)hipGetLastError();
 }
 
+// The tail of a chain that was launched without it: the HBM-lattice kernel over work list `li` (kgpu_api.cpp: enqueue_tail).
+int launch_tail_only(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int li, void *stream) {
+    Control *ctl = a.ctl;
+    if (li < 0 || li > 2) return (int)hipErrorInvalidValue;
+    if (plan.long_lds_bytes) {
+        WorkIO io{a.ovf[li], &ctl->ovf_count[li], a.ovf[li + 1], &ctl->ovf_count[li + 1], nullptr};
+        if (plan.long_lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_general<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.long_lds_bytes);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(k_tokenize_general<true>, dim3((unsigned)(plan.long_workgroups ? plan.long_workgroups : 1)), dim3(64), plan.long_lds_bytes, (hipStream_t)stream, d, a, io,
+                           plan.long_lds_bytes, 0u);
+    } else {
+        WorkIO io{a.ovf[li], &ctl->ovf_count[li], nullptr, nullptr, nullptr};
+        hipLaunchKernelGGL(k_tokenize_general<false>, dim3((unsigned)(plan.general_workgroups ? plan.general_workgroups : 1)), dim3(64), 0, (hipStream_t)stream, d, a, io, 0u, 0u);
+    }
+    return (int)hipGetLastError();
+}
+
 int launch_small_call(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, void *stream) {
     Control *ctl = a.ctl;
     WorkIO io{nullptr, nullptr, a.ovf[0], &ctl->ovf_count[0], &ctl->late_count[0]};

@@ -1,0 +1,162 @@
+// kanpyo_amd/csrc/kgpu_runtime.h -- the host runtime's own types, shared by kgpu_api.cpp (dictionary, contexts, the host-buffer
+// entry points) and kgpu_multi.cpp (the multi-device entry points).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "kgpu_internal.h"
+
+#define HIPCHECK(expr)                                                                  \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return KGPU_ERR_HIP;                                                        \
+        }                                                                               \
+    } while (0)
+
+namespace kgpu {
+
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return KGPU_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        size_t want = need + need / 4 + 256;
+        HIPCHECK(hipMalloc(&p, want));
+        bytes = want;
+        return KGPU_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+// Pinned host memory, optionally device-mapped (the device then reads / writes it over PCIe by itself).
+struct PinBuf {
+    void *h = nullptr, *d = nullptr; size_t bytes = 0;
+    int ensure(size_t need, bool mapped) {
+        if (need <= bytes) return KGPU_OK;
+        release();
+        size_t want = need + need / 4 + 4096;
+        if (hipHostMalloc(&h, want, mapped ? hipHostMallocMapped : hipHostMallocDefault) != hipSuccess) { h = nullptr; set_error("pinned allocation of %zu bytes failed", want); return KGPU_ERR_HIP; }
+        d = h;
+        if (mapped && hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); h = d = nullptr; set_error("hipHostGetDevicePointer failed"); return KGPU_ERR_HIP; }
+        bytes = want;
+        return KGPU_OK;
+    }
+    void release() { if (h) (void)hipHostFree(h); h = d = nullptr; bytes = 0; }
+};
+
+}  // namespace kgpu
+
+using namespace kgpu;  // (a private header of two translation units that both speak this namespace's vocabulary)
+
+struct Combiner;  // kgpu_api.cpp: concurrent small calls sharing a launch
+
+struct kgpu_dict {
+    int device = 0;
+    Combiner *combiner = nullptr;
+    DictView view{};
+    kgpu_dict_info info{};
+    std::vector<void *> allocs;
+    std::mutex pool_mu;
+    std::vector<kgpu_ctx *> pool;
+    // LDS bytes reserved per input byte (x256) by the pool kernel before the lattice is known; a
+    // property of the dictionary + the text, so it is learnt once and shared by all contexts
+    std::atomic<uint32_t> est_q8{80 * 256};
+    // Batches left for which the second (whole-CU) pool is launched.  Its workgroups need a CU's
+    // entire LDS just to start and find their list empty, which stalls them -- and the launches
+    // queued behind -- until both 80 KB pools of that CU have drained; so it is only issued while
+    // recent batches actually overflowed the first pool (otherwise those rare sentences take the
+    // HBM-scratch kernel).  Performance heuristic only: the chain is complete either way.
+    std::atomic<int> big_pool_batches{0};
+    // Same for the long-sentence kernel (its workgroups hold 32 KB of LDS each): issued while recent
+    // batches still had sentences left after the pools.
+    std::atomic<int> window_batches{64};  // same for the windowed kernel: armed while recent batches held sentences of WINDOW_MIN_BYTES or more (Control::very_long)
+    std::atomic<int> long_batches{64};  // starts armed: a corpus of long sentences does not spend its first batches in the last-resort kernel (3.8 ms per batch on cfg 3)
+    // Streams handed round-robin to contexts created without one.  HIP multiplexes streams onto three
+    // hardware queues: a 4th stream queues behind the 1st and unbalances them (measured -25 %), so any
+    // number of contexts shares three streams; each context waits on its own completion event.
+    std::vector<hipStream_t> streams;
+    unsigned next_stream = 0;
+    std::vector<uint32_t> left_of_rank, right_of_rank;  // device (ranked) context id -> the dictionary's own; empty = identity
+    // One reference for the handle the caller holds plus one per live context: the tables and the shared
+    // streams go when the last one does (a context outliving kgpu_dict_destroy keeps working).
+    std::atomic<int> refs{1};
+};
+
+struct kgpu_ctx {
+    kgpu_dict *dict = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t done_ev = nullptr;  // recorded behind the batch's last kernel: contexts may share a stream
+    Control *d_ctl = nullptr;
+    Control *h_ctl = nullptr;  // pinned + device-mapped: the scan kernel publishes the launch's Control block here
+    Control *h_ctl_dev = nullptr;  // device-side address of h_ctl
+    bool ctl_dirty = true;     // d_ctl must be zeroed by the host (first launch, or after a failed enqueue)
+    uint32_t launch_seq = 0;
+    int last_pools = 0;        // pool launches issued for the pending batch
+    bool last_long = false;    // ... and whether the long-sentence kernel was
+    bool last_window = false;  // ... and whether the windowed kernel was
+    bool force_legacy_long = false;  // the pending batch is a rerun: the windowed kernel handed a sentence back
+    bool last_tail = true;     // ... whether the last-resort launch closed the chain (left out while no recent batch needed the tail)
+    bool tail_pass = false;    // the pending launches are the tail of the batch's chain alone (it had been left out and a sentence needed it)
+    Control tail_saved{};      // ... what the first pass had published
+    unsigned tail_count = 0;   // ... the length of the work list the tail serves (source of an asynchronous copy: lives here)
+    uint32_t event_every = 1;  // KGPU_PROFILE_SAMPLED: HIP events on every 4th launch only
+    DevBuf arena, stage, tok_count;
+    // host-buffer path staging
+    DevBuf in_utf8, in_off, out_tok, out_off, out_status;
+    PinBuf pin_in, pin_out;       // large host calls: input staging (offsets | bytes), mapped result block (records | first | token offsets | status)
+    DevBuf in_block;              // ... and the device copy of the input block
+    // single-launch small calls: one pinned, device-mapped block (input | offsets | tokens | token offsets | status)
+    uint8_t *sm_host = nullptr, *sm_dev = nullptr;
+    uint32_t sm_seq = 0;
+    // last enqueued batch (for the arena-overflow retry and for sync)
+    BatchArgs last{};
+    bool pending = false;
+    LaunchPlan plan{};
+    DevBuf ovf;
+    DevBuf stat_slots;                             // profiling runs: per-wavefront counters of the pool kernel (BatchArgs::stat_slots)
+    std::vector<unsigned long long> stat_host;
+    // profiling
+    bool profiling = false;   // KGPU_PROFILE_EVENTS
+    bool count_work = false;  // KGPU_PROFILE_WORK
+    uint32_t stop_after = 0;  // kgpu_ctx_set_ablation: measurement mode, 0 = off
+    kgpu_work work{};
+    uint64_t phase[10] = {0};
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    kgpu_profile prof{};
+    kgpu_routing rt{};
+};
+
+
+namespace kgpu {
+
+struct WorkerPool {
+    std::mutex mu; std::condition_variable cv; std::deque<std::function<void()>> q; std::vector<std::thread> th;
+    std::mutex done_mu; std::condition_variable done_cv;
+    unsigned start();                         // threads running (0: none could be created)
+    void submit(std::function<void()> f);
+    void wait_zero(std::atomic<int> &counter); // until the tasks counted there are through
+    void task_done(std::atomic<int> &counter); // a task's last statement
+};
+WorkerPool &workers();
+struct TestHooks { bool no_small_calls = false, legacy_host_path = false, plain_leaves = false, byte_trie = false; uint64_t chunk_bytes = 4ull << 20, chunk_sents = 16384, depth = 12, multi_chunk_sents = 0; };
+TestHooks test_hooks();  // test-only environment hooks, read once per process (or per call under KGPU_TEST_HOOKS_REREAD)
+void parallel_copy(void *dst, const void *src, size_t bytes);
+bool is_pinned_host(const void *p);
+// the pooled contexts of a dictionary (one per call in flight)
+int pool_get(kgpu_dict *d, kgpu_ctx **c);
+void pool_put(kgpu_dict *d, kgpu_ctx *c);
+int tokenize_device_impl(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n, uint64_t total_bytes,
+                         kgpu_token *d_tokens, kgpu_token8 *d_tokens8, uint32_t *d_first, uint8_t *status8, uint64_t *toff8, uint64_t token_capacity,
+                         uint64_t *d_tok_offsets, uint8_t *d_status, const char *who);
+
+}  // namespace kgpu

@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import struct
+import zipfile
 from dataclasses import dataclass, field
 from typing import Iterable, Mapping, Sequence
 
@@ -133,5 +134,5 @@ class Dict:
             return cls(z["index_dict"].tobytes(), z["connection_dict"].tobytes(), z["morph_dict"].tobytes(),
                        z["unk_dict"].tobytes(), z["char_category"], z["invoke_list"], z["group_list"],
                        [str(x) for x in json.loads(z["char_class"].tobytes().decode("utf-8"))])
-        except (ValueError, KeyError, UnicodeDecodeError, OSError) as e:
+        except (ValueError, KeyError, UnicodeDecodeError, zipfile.BadZipFile) as e:  # (a missing or unreadable file is an OSError and stays one)
             raise ValueError(f"stale dictionary cache {path}: {e}; delete it and rebuild") from e

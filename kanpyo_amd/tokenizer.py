@@ -21,6 +21,7 @@ from .token import Token, TokenClass
 TOKEN_DTYPE = np.dtype(
     [("id", "<i4"), ("cls", "<u4"), ("position", "<u4"), ("start", "<u4"), ("end", "<u4"), ("byte_len", "<u4")]
 )
+TOKEN8_DTYPE = np.dtype([("id", "<i4"), ("packed", "<u4")])  # kgpu_token8: cls | chars << 2 | byte_len << 14
 
 
 def pinned_empty(shape, dtype=np.uint8) -> np.ndarray:
@@ -128,6 +129,12 @@ class Tokenizer:
             _lib.check(rc)
             return tokens[: int(got.value)], toff[: n + 1], status[:n]
 
+    def routing(self, reset: bool = False) -> dict:
+        """kgpu_dict_get_routing: the routing counters of the handle's pooled contexts (small_calls, combined_calls, ...)."""
+        r = _lib.Routing()
+        _lib.check(_lib.lib().kgpu_dict_get_routing(self._h, C.byref(r), C.sizeof(r), 1 if reset else 0))
+        return {n: (list(getattr(r, n)) if n in ("deferred", "redone") else getattr(r, n)) for n, *_ in r._fields_}
+
     # ---- reference-shaped API --------------------------------------------------
     def tokenize_batch(self, sentences: Sequence[str]) -> List[List[Token]]:
         utf8, offs = pack_sentences(sentences)
@@ -149,3 +156,36 @@ class Tokenizer:
     def tokenize(self, input: str) -> List[Token]:
         """Tokenizer::tokenize (src/tokenizer.rs:16-45): one sentence == a batch of one."""
         return self.tokenize_batch([input])[0]
+
+
+def tokenize_packed_multi(tokenizers: Sequence[Tokenizer], utf8: np.ndarray, offsets: np.ndarray, token_capacity: int | None = None, out=None):
+    """kgpu_tokenize_batch_multi: sentence i -> tokenizers[i mod G] (one Tokenizer per device; the same one may appear more than once), results in
+    the caller's original order -- byte for byte what Tokenizer.tokenize_packed gives on one device.
+    -> (tokens[TOKEN_DTYPE], tok_offsets[uint64 n+1], status[uint8 n])."""
+    utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = offsets.size - 1
+    if n < 0:
+        raise ValueError("offsets needs n+1 entries")
+    total = int(offsets[-1] - offsets[0]) if n else 0
+    cap = int(token_capacity) if token_capacity is not None else total // 2 + n + 64
+    L = _lib.lib()
+    handles = (C.c_void_p * len(tokenizers))(*[t.handle for t in tokenizers])
+    while True:
+        if out is not None:
+            tokens, toff, status = out
+            cap = tokens.size
+            token_capacity = cap
+        else:
+            tokens = np.empty(cap, dtype=TOKEN_DTYPE)
+            toff = np.empty(n + 1, dtype=np.uint64)
+            status = np.empty(max(n, 1), dtype=np.uint8)
+        status[: max(n, 1)] = 0
+        got = C.c_uint64(0)
+        rc = L.kgpu_tokenize_batch_multi(handles, len(tokenizers), utf8.ctypes.data if utf8.size else None, offsets.ctypes.data, n,
+                                         tokens.ctypes.data, cap, toff.ctypes.data, status.ctypes.data, C.byref(got))
+        if rc == _lib.KGPU_ERR_CAPACITY and token_capacity is None:
+            cap = int(got.value) + 64
+            continue
+        _lib.check(rc)
+        return tokens[: int(got.value)], toff[: n + 1], status[:n]

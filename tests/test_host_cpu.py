@@ -141,3 +141,8 @@ def test_npz_cache_round_trip_and_stale_format(tmp_path, fixture_dict):
     np.savez_compressed(tmp_path / "old.npz", index_dict=np.zeros(4, dtype=np.uint8), char_class=np.array(["DEFAULT"]))
     with pytest.raises(ValueError, match="stale dictionary cache"):
         Dict.load_npz(tmp_path / "old.npz")
+    with pytest.raises(FileNotFoundError):  # a missing file is not a stale cache
+        Dict.load_npz(tmp_path / "absent.npz")
+    (tmp_path / "junk.npz").write_bytes(b"not a zip archive")
+    with pytest.raises(ValueError, match="stale dictionary cache"):
+        Dict.load_npz(tmp_path / "junk.npz")
