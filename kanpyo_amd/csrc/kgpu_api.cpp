@@ -22,6 +22,7 @@
 #include <cstring>
 #include <ctime>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "kgpu_runtime.h"
@@ -1582,4 +1583,67 @@ extern "C" double kgpu_debug_pool_repeat(kgpu_ctx *c, const uint8_t *d_utf8, con
     if (hipStreamSynchronize(c->stream) != hipSuccess) return -1.0;
     clock_gettime(CLOCK_MONOTONIC, &t1);
     return (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+}
+
+// ---- measurement / test only (bench.py's concurrent_callers leg, tests/test_gpu_concurrent.py; not part of include/kanpyo_gpu.h): `threads` host
+// threads call kgpu_tokenize_batch in a loop, thread t with n_pattern[t % n_pat] sentences per call (the reference's shape is 1: src/bin/kanpyo.rs:106-126),
+// walking round the corpus from its own starting point.  With `expect_tokens` / `expect_offsets` (the whole corpus tokenized once, e.g. by the oracle)
+// every call's records are compared: stats[4] counts the calls that differ.  stats: [0] wall seconds, [1] p50 / [2] p99 / [3] mean call latency in us,
+// [4] mismatching calls, [5] calls made, [6] sentences tokenized.  Python threads cannot drive this: the GIL serialises what surrounds each call.
+extern "C" int kgpu_debug_concurrent_callers(kgpu_dict *d, const uint8_t *utf8, const uint64_t *offsets, uint64_t n_sentences, int threads, int calls_per_thread,
+                                             const int *n_pattern, int n_pat, const kgpu_token *expect_tokens, const uint64_t *expect_offsets, double *stats) {
+    if (!d || !offsets || !n_sentences || threads < 1 || threads > 1024 || calls_per_thread < 1 || !n_pattern || n_pat < 1 || !stats) { set_error("kgpu_debug_concurrent_callers: bad argument"); return KGPU_ERR_INVALID_ARG; }
+    std::vector<std::vector<float>> lat((size_t)threads);
+    std::vector<uint64_t> bad((size_t)threads, 0), sent((size_t)threads, 0);
+    std::vector<int> rcs((size_t)threads, KGPU_OK);
+    std::vector<std::string> errs((size_t)threads);
+    std::atomic<int> ready{0};
+    std::atomic<bool> go{false};
+    auto now_us = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; };
+    auto body = [&](int t) {
+        const uint64_t npc = (uint64_t)std::max(1, n_pattern[t % n_pat]);
+        uint64_t maxb = 0;
+        for (uint64_t i = 0; i < n_sentences; ++i) maxb = std::max(maxb, offsets[i + 1] - offsets[i]);
+        std::vector<kgpu_token> tok((size_t)(npc * (maxb + 1) + 8));
+        std::vector<uint64_t> toff((size_t)npc + 1), off2((size_t)npc + 1);
+        std::vector<uint8_t> st((size_t)npc + 1), text;
+        lat[(size_t)t].reserve((size_t)calls_per_thread);
+        uint64_t at = ((uint64_t)t * 7919u) % n_sentences;
+        ready.fetch_add(1);
+        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+        for (int k = 0; k < calls_per_thread; ++k) {
+            if (at + npc > n_sentences) at = 0;
+            const uint64_t m = std::min(npc, n_sentences - at);
+            uint64_t got = 0;
+            const double t0 = now_us();
+            const int rc = kgpu_tokenize_batch(d, utf8, offsets + at, m, tok.data(), tok.size(), toff.data(), st.data(), &got);
+            lat[(size_t)t].push_back((float)(now_us() - t0));
+            if (rc) { rcs[(size_t)t] = rc; errs[(size_t)t] = kgpu_last_error(); return; }
+            sent[(size_t)t] += m;
+            if (expect_tokens && expect_offsets) {
+                const uint64_t e0 = expect_offsets[at], en = expect_offsets[at + m] - e0;
+                bool same = got == en && std::memcmp(tok.data(), expect_tokens + e0, (size_t)en * sizeof(kgpu_token)) == 0;
+                for (uint64_t i = 0; same && i <= m; ++i) same = toff[(size_t)i] == expect_offsets[at + i] - e0;
+                if (!same) bad[(size_t)t]++;
+            }
+            at += m;
+        }
+    };
+    std::vector<std::thread> th;
+    try { for (int t = 0; t < threads; ++t) th.emplace_back(body, t); }
+    catch (...) { go.store(true); for (auto &x : th) x.join(); set_error("kgpu_debug_concurrent_callers: could not start %d threads", threads); return KGPU_ERR_INTERNAL; }
+    while (ready.load() < threads) std::this_thread::yield();
+    const double t0 = now_us();
+    go.store(true, std::memory_order_release);
+    for (auto &x : th) x.join();
+    const double wall = (now_us() - t0) * 1e-6;
+    for (int t = 0; t < threads; ++t) if (rcs[(size_t)t]) { set_error("%s", errs[(size_t)t].c_str()); return rcs[(size_t)t]; }
+    std::vector<float> all;
+    uint64_t nbad = 0, nsent = 0;
+    for (int t = 0; t < threads; ++t) { all.insert(all.end(), lat[(size_t)t].begin(), lat[(size_t)t].end()); nbad += bad[(size_t)t]; nsent += sent[(size_t)t]; }
+    std::sort(all.begin(), all.end());
+    double mean = 0; for (float x : all) mean += x;
+    stats[0] = wall; stats[1] = all[all.size() / 2]; stats[2] = all[(size_t)((double)all.size() * 0.99)]; stats[3] = mean / (double)all.size();
+    stats[4] = (double)nbad; stats[5] = (double)all.size(); stats[6] = (double)nsent;
+    return KGPU_OK;
 }

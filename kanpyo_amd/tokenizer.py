@@ -189,3 +189,25 @@ def tokenize_packed_multi(tokenizers: Sequence[Tokenizer], utf8: np.ndarray, off
             continue
         _lib.check(rc)
         return tokens[: int(got.value)], toff[: n + 1], status[:n]
+
+
+def concurrent_callers(tok: Tokenizer, utf8: np.ndarray, offsets: np.ndarray, threads: int, calls_per_thread: int, n_pattern=(1,), expect=None) -> dict:
+    """Measurement / test helper (kgpu_debug_concurrent_callers, not part of the public header): `threads` native host threads call
+    kgpu_tokenize_batch in a loop -- thread t with n_pattern[t % len] sentences per call -- walking round the corpus.  expect=(tokens, offsets)
+    of the whole corpus (e.g. the oracle's): every call's records are compared, `mismatching_calls` counts the ones that differ."""
+    utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    L = _lib.lib()
+    f = L.kgpu_debug_concurrent_callers
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    pat = np.ascontiguousarray(n_pattern, dtype=np.int32)
+    stats = np.zeros(8, dtype=np.float64)
+    et = eo = None
+    if expect is not None:
+        et = np.ascontiguousarray(expect[0]); eo = np.ascontiguousarray(expect[1], dtype=np.uint64)
+        assert et.dtype == TOKEN_DTYPE
+    _lib.check(f(tok.handle, utf8.ctypes.data, offsets.ctypes.data, offsets.size - 1, int(threads), int(calls_per_thread), pat.ctypes.data, pat.size,
+                 et.ctypes.data if et is not None else None, eo.ctypes.data if eo is not None else None, stats.ctypes.data))
+    return {"wall_s": float(stats[0]), "p50_us": float(stats[1]), "p99_us": float(stats[2]), "mean_us": float(stats[3]), "mismatching_calls": int(stats[4]),
+            "calls": int(stats[5]), "sentences": int(stats[6]), "sentences_per_s": float(stats[6] / stats[0]) if stats[0] > 0 else 0.0,
+            "threads": int(threads), "n_pattern": [int(x) for x in pat]}

@@ -48,6 +48,7 @@ def _run_threads(tok, orc, work, nthreads):
 
 
 def test_32_threads_mixed_call_sizes_bit_exact(env):
+    """Python threads (the GIL serialises what surrounds each call, so few calls meet inside the library): every caller gets its own records."""
     from kanpyo_amd import synth
     from kanpyo_amd.tokenizer import pack_sentences
 
@@ -66,9 +67,28 @@ def test_32_threads_mixed_call_sizes_bit_exact(env):
     tok.routing(reset=True)
     errors = _run_threads(tok, orc, work, nthreads)
     assert not errors, errors[:5]
-    rt = tok.routing()
-    assert rt["small_calls"] > 0
-    assert rt["combined_calls"] >= 2 and rt["combined_launches"] >= 1, rt  # 32 threads of n = 1 calls: some did share a launch
+    assert tok.routing()["small_calls"] > 0
+
+
+def test_native_threads_share_launches_and_stay_bit_exact(env):
+    """32 and 64 NATIVE host threads (kgpu_debug_concurrent_callers: no GIL between the calls) x mixed n: calls do meet inside the entry point, share
+    launches (kgpu_routing.combined_calls), and every call's records equal the oracle's for exactly its sentences."""
+    from kanpyo_amd import synth
+    from kanpyo_amd.tokenizer import concurrent_callers, pack_sentences
+
+    sd, tok, orc = env
+    sents = synth.make_corpus(sd, 3000, 61, "cfg2") + synth.make_corpus(sd, 150, 62, "cfg3") + ["", "テ", "すもももももももものうち"] * 5
+    np.random.default_rng(3).shuffle(sents)
+    utf8, offs = pack_sentences(sents)
+    exp = orc.tokenize_batch(utf8, offs, 8)
+    for threads, pattern, calls in ((32, (1, 1, 1, 2, 5, 1, 17, 1, 64, 1, 130, 1), 60), (64, (1,), 100), (8, (128, 1), 40)):
+        tok.routing(reset=True)
+        r = concurrent_callers(tok, utf8, offs, threads, calls, pattern, expect=(exp.tokens, exp.offsets))
+        assert r["mismatching_calls"] == 0 and r["calls"] == threads * calls, r
+        rt = tok.routing()
+        assert rt["small_calls"] > 0
+        if threads >= 32:
+            assert rt["combined_calls"] >= 2 and 1 <= rt["combined_launches"] < rt["combined_calls"], rt
 
 
 def test_n1_from_64_threads_and_a_long_sentence_among_them(env):
