@@ -329,8 +329,12 @@ def _extras_child(sd, outdir, cfg3_n):
     while not os.path.exists(os.path.join(outdir, "go")):
         time.sleep(0.05)
 
-    for kind, n, seed in (("cfg5", 1000, 5), ("cfg3", cfg3_n, 2)):
-        sents = synth.make_corpus(sd, n, seed, kind)
+    # the dense-lattice variant of the dictionary (same record count, N/C ~ 9, more than eight predecessors at about half of the positions) and a
+    # cfg 2-shaped corpus over it: SURVEY 8(a) a15's natural density, which the default synthetic shape (N/C = 5.4) does not reach
+    sd_dense = synth.build_dict(dense=True)
+    sd_dense.dict.save_npz(os.path.join(outdir, "dense_dict.npz"))
+    for kind, n, seed, sdx in (("dense", N_SENT, 1, sd_dense), ("cfg5", 1000, 5, sd), ("cfg3", cfg3_n, 2, sd)):
+        sents = synth.make_corpus(sdx, n, seed, "cfg2" if kind == "dense" else kind)
         utf8, offs = pack_sentences(sents)
         np.save(os.path.join(outdir, kind + "_utf8.npy"), utf8)
         np.save(os.path.join(outdir, kind + "_offs.npy"), offs)
@@ -814,6 +818,28 @@ def main():
                                                          "result arrays), host buffers in and out, wall time per call; n <= 128 takes the single-launch "
                                                          "path (pinned in/out, the kernel compacts and publishes itself), of which ~40 us are the one "
                                                          "sentence's own dependent chain on one wavefront")
+        # ---- the reference's server shape: many host threads, ONE sentence per call (src/tokenizer.rs:16 is &self, Send + Sync; src/bin/kanpyo.rs:106-126).
+        # Native threads (kgpu_debug_concurrent_callers: Python threads would measure the GIL); concurrent small calls share launches (the combiner).
+        try:
+            from kanpyo_amd.tokenizer import concurrent_callers
+
+            utf8_c, offs_c = pack_sentences(corpora[0][:20000])
+            cc = {}
+            for nthr, calls in ((1, 400), (16, 300), (64, 300), (256, 150)):
+                concurrent_callers(tok, utf8_c, offs_c, nthr, 20)  # warm: contexts, pinned blocks
+                tok.routing(reset=True)
+                r = concurrent_callers(tok, utf8_c, offs_c, nthr, calls)
+                rt = tok.routing()
+                r["combined_calls"], r["combined_launches"], r["small_calls"] = rt["combined_calls"], rt["combined_launches"], rt["small_calls"]
+                r["sentences_per_launch"] = r["sentences"] / max(rt["small_calls"] - rt["combined_calls"] + rt["combined_launches"], 1)
+                cc[f"threads{nthr}"] = r
+            cc["what"] = ("kgpu_tokenize_batch with n = 1 in a loop from N native host threads over the first 20k cfg 2 sentences; closed loop, so "
+                          "sentences/s = threads / mean latency (Little): calls that arrive while another thread's small launch is being assembled "
+                          "join it (leader / follower, <= 15 us window, <= 128 sentences)")
+            cc["host_cpus"] = cpu_quota()
+            result["pcie_inclusive"]["concurrent_callers"] = cc
+        except Exception as e:
+            print(f"concurrent_callers leg failed: {e}", file=sys.stderr)
         if not args.no_extras:
             # one large call: the whole 100k-sentence corpus four times over (400k sentences, ~45 MB in, ~300 MB of 24-byte records out)
             reps_c = 4
@@ -906,8 +932,18 @@ def main():
             from oracle import oracle as _orc
 
             extras_orc = _orc.OracleTokenizer.from_dict(sd.dict)
-        for kind, passes, lab in (("cfg5", 40, "BASELINE configs[4] (cfg 5): 1k sentences of 2048 chars, each with a same-category run > 1024 chars"),
-                                  ("cfg3", 2, f"BASELINE configs[2] (cfg 3): {args.cfg3_sentences} mixed-length (8-512 char) sentences incl. unknown-word path, batches of 65536")):
+        cfg2_relax_per_s = result["value"] * result["work_per_sentence"]["E"]
+        for kind, passes, lab in (("dense", 10, "cfg 2-shaped text (100k sentences, ~40 chars, batch 4096) over the DENSE variant of the 392k-record dictionary: natural lattice "
+                                                "density (SURVEY 8a a15: N ~ 8-10 x C; more than eight predecessors at about half of the positions)"),
+                                  ("cfg5", 40, "BASELINE configs[4] (cfg 5): 1k sentences of 2048 chars, each with a same-category run > 1024 chars"),
+                                  ("cfg3", 2, f"BASELINE configs[2] (cfg 3): {args.cfg3_sentences} mixed-length (8-512 char) sentences incl. unknown-word path, batches of 65536"),
+                                  ("cfg3@4096", 2, f"BASELINE configs[2] (cfg 3): the same {args.cfg3_sentences} sentences in batches of 4096 (one sentence per wavefront slot: "
+                                                   "a launch lasts as long as its longest sentence)")):
+            batch_x = BATCH
+            if kind == "cfg3":
+                batch_x = 65536
+            elif kind == "cfg3@4096":
+                kind = "cfg3"
             flag = os.path.join(extras_dir, kind + "_done.npy")
             t_wait = time.perf_counter()
             while not os.path.exists(flag) and extras_proc.is_alive() and time.perf_counter() - t_wait < 600:
@@ -922,8 +958,25 @@ def main():
                 # cfg 3 names no batch size (BASELINE configs[2]): batches of 65536 -- a launch lasts as long as its longest sentence, and with one
                 # sentence per wavefront slot (4096) a few 500-char sentences decide a launch whose average is 120 (round 3, M sentences/s by batch:
                 # 4096 12.8, 16384 19.0-19.2, 32768 19.5, 65536 19.9)
-                wl_x = PackedWorkload(u, o, batch=65536 if kind == "cfg3" else BATCH)
-                extra.append(measure_config(tok, dev, wl_x, n_chars, passes, args.queue, 0, lab, orc=extras_orc))
+                wl_x = PackedWorkload(u, o, batch=batch_x)
+                if kind == "dense":
+                    from kanpyo_amd.dict import Dict as _Dict
+
+                    dd = _Dict.load_npz(os.path.join(extras_dir, "dense_dict.npz"))
+                    tok_d = Tokenizer(dd, device=local_rank)
+                    orc_d = _orc.OracleTokenizer.from_dict(dd) if extras_orc is not None else None
+                    line = measure_config(tok_d, dev, wl_x, n_chars, passes, args.queue, 0, lab, orc=orc_d)
+                    w = line["work_per_sentence"]
+                    line["lattice_density"] = {"nodes_per_char": w["N"] / max(w["C"], 1e-9), "relaxations_per_node": w["E"] / max(w["N"], 1e-9),
+                                               "cfg2_nodes_per_char": result["work_per_sentence"]["N"] / result["work_per_sentence"]["C"]}
+                    line["relaxations_per_s"] = line["value"] * w["E"]
+                    line["relaxations_per_s_vs_cfg2"] = line["relaxations_per_s"] / max(cfg2_relax_per_s, 1e-9)
+                    line["routing_what"] = ("deferred[0]: sentences that left the pool kernel (more than 8 dictionary prefixes at one position -- MAXM -- or a "
+                                            "lattice beyond the LDS routing limit); redone[0]: of which after the walk had been paid for")
+                    tok_d.close()
+                    extra.append(line)
+                else:
+                    extra.append(measure_config(tok, dev, wl_x, n_chars, passes, args.queue, 0, lab, orc=extras_orc))
             except Exception as e:
                 print(f"{kind} leg failed: {e}", file=sys.stderr)
         result["extra"] = extra

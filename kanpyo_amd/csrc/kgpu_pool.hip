@@ -175,7 +175,9 @@ struct PoolArgs {
     DictView d; BatchArgs a; WorkIO io;
     uint32_t pool_bytes, max_pages, stop_after /* ablation timing only; 0 = run everything */;
 };
-template <bool PROF>
+// BYTE: the dictionary has no character-level copy of its trie (KGPU_BYTE_TRIE, or a key set it cannot represent): the walk goes byte by byte.
+// A separate instantiation chosen at launch: the product kernel carries one walker, not two (SGPRs, spill code, instruction cache).
+template <bool PROF, bool BYTE>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_WPE))) void k_tokenize_pool(PoolArgs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t pool[];
     typedef const __attribute__((address_space(4))) PoolArgs *KArgs;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                     cnt += nrec;
                     atomicAdd(&boff[i + nch], nrec);
                 };
-                if (d.da2) {
+                if constexpr (!BYTE) {
                     // Character-level array (kgpu_chartrie.cpp): ONE 16-byte record per character gives its category, its code and the
                     // root's child for it; the codes replace the code points in LDS (the chunks are walked last to first, so the
                     // characters a walk runs into already have theirs), then every further character costs one dependent load.
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                     if (i + 1 < C) ncat = ccat[i + 1];
                     if (active) {
                         ct_walk(d, p0, bp0, lf0, [&](uint32_t dep) -> uint32_t { return i + dep < C ? (uint32_t)cp16[i + dep] : 0xFFFFu; }, on_match);
-                        if (prof) wT += da_walk_first(d, text, cpi, cbyte[i], cbyte[i + 1], B, base_root, [](uint32_t, uint32_t, uint32_t) {});  // the reference's byte steps (work counters)
+                        if constexpr (PROF) wT += da_walk_first(d, text, cpi, cbyte[i], cbyte[i + 1], B, base_root, [](uint32_t, uint32_t, uint32_t) {});  // the reference's byte steps (work counters)
                         mcnt[i] = (uint8_t)(m < MAXM ? m : MAXM);
                     }
                 } else {
@@ -896,28 +898,28 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
 // granularity makes this smaller than 160 KB / pool_bytes would suggest for odd sizes).
 int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves) {
     if (pool_bytes > 64 * 1024)
-        if (hipFuncSetAttribute((const void *)k_tokenize_pool<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)k_tokenize_pool<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes) != hipSuccess) return 0;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_pool<false>, (int)(64 * waves), (size_t)pool_bytes) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_pool<false, false>, (int)(64 * waves), (size_t)pool_bytes) != hipSuccess) return 0;
     return n;
+}
+
+template <bool PROF, bool BYTE>
+static int launch_pool_inst(const PoolArgs &pa, uint32_t pool_bytes, uint32_t waves, int n_workgroups, void *stream) {
+    if (pool_bytes > 64 * 1024) {  // beyond the default dynamic-LDS cap the kernel has to opt in
+        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool<PROF, BYTE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((k_tokenize_pool<PROF, BYTE>), dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, pa);
+    return (int)hipGetLastError();
 }
 
 int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t pool_bytes, uint32_t waves,
                          uint32_t max_pages, int n_workgroups, uint32_t stop_after, void *stream) {
-    if (pool_bytes > 64 * 1024) {  // beyond the default dynamic-LDS cap the kernel has to opt in
-        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
-        if (e != hipSuccess) return (int)e;
-    }
-    if (a.count_work) {
-        if (pool_bytes > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
-            if (e != hipSuccess) return (int)e;
-        }
-        hipLaunchKernelGGL(k_tokenize_pool<true>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, PoolArgs{d, a, io, pool_bytes, max_pages, stop_after});
-    } else {
-        hipLaunchKernelGGL(k_tokenize_pool<false>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, PoolArgs{d, a, io, pool_bytes, max_pages, stop_after});
-    }
-    return (int)hipGetLastError();
+    const PoolArgs pa{d, a, io, pool_bytes, max_pages, stop_after};
+    const bool byte_walk = d.da2 == nullptr;
+    if (a.count_work) return byte_walk ? launch_pool_inst<true, true>(pa, pool_bytes, waves, n_workgroups, stream) : launch_pool_inst<true, false>(pa, pool_bytes, waves, n_workgroups, stream);
+    return byte_walk ? launch_pool_inst<false, true>(pa, pool_bytes, waves, n_workgroups, stream) : launch_pool_inst<false, false>(pa, pool_bytes, waves, n_workgroups, stream);
 }
 
 // Measurement only (tools/anyorder_probe.py): the pool kernel `reps` times over the same batch on one stream, nothing between the
@@ -926,15 +928,16 @@ int launch_pool_repeat(const DictView &d, const BatchArgs &a, uint32_t pool_byte
                        int n_workgroups, int reps, bool any_order, void *stream) {
     const WorkIO io{nullptr, nullptr, a.ovf[0], &a.ctl->ovf_count[0], &a.ctl->late_count[0]};
     if (pool_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
         if (e != hipSuccess) return (int)e;
     }
+    if (!d.da2) return (int)hipErrorInvalidValue;  // (probe of the product kernel only)
     for (int r = 0; r < reps; ++r) {
         if (any_order)
-            hipExtLaunchKernelGGL(k_tokenize_pool<false>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, nullptr, nullptr,
+            hipExtLaunchKernelGGL((k_tokenize_pool<false, false>), dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, nullptr, nullptr,
                                   hipExtAnyOrderLaunch, PoolArgs{d, a, io, pool_bytes, max_pages, 0u});
         else
-            hipLaunchKernelGGL(k_tokenize_pool<false>, dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, PoolArgs{d, a, io, pool_bytes, max_pages, 0u});
+            hipLaunchKernelGGL((k_tokenize_pool<false, false>), dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, PoolArgs{d, a, io, pool_bytes, max_pages, 0u});
     }
     return (int)hipGetLastError();
 }

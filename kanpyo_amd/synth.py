@@ -92,7 +92,11 @@ def _make_words(rng, pool, weights, count, len_lo, len_hi, len_p, seen, out):
                     break
 
 
-def build_dict(n_records: int = 392_000, seed: int = SEED_DICT, n_context: int = N_CONTEXT) -> SynthDict:
+def build_dict(n_records: int = 392_000, seed: int = SEED_DICT, n_context: int = N_CONTEXT, dense: bool = False) -> SynthDict:
+    """dense=True: the same record count laid out for the lattice density real IPADIC text shows (N ~ 8-10 x C; the default shape
+    gives 5.4): more short hiragana / kanji surfaces and nested prefixes (more dictionary words per start position), more records per surface
+    (homographs: up to 12 on the single-kana particles), corpus weights that favour them -- buckets of more than eight predecessors at about
+    half of the positions (the default: 13 %), which is where the sweep's P <= 16 / P <= 32 bodies and the MAXM = 8 parked-prefix limit are met."""
     rng = np.random.default_rng(seed)
     hira = np.arange(0x3041, 0x3094)
     kata = np.arange(0x30A1, 0x30F7)
@@ -109,10 +113,13 @@ def build_dict(n_records: int = 392_000, seed: int = SEED_DICT, n_context: int =
     for c in hira:  # every single hiragana is a word (particles, auxiliaries)
         words.append(chr(c)); seen.add(chr(c))
     n_single_hira = len(words)
-    tgt_unique = int(n_records / 1.178)  # ~15 % of surfaces carry 1-8 extra records
+    tgt_unique = int(n_records / (1.9 if dense else 1.178))  # ~15 % of surfaces carry 1-8 extra records (dense: about half of them)
     plan = [
         (hira, w_hira, 0.070, 2, 7, 0.50), (kanji, w_kanji, 0.020, 1, 1, 0.99), (kanji, w_kanji, 0.520, 2, 12, 0.62),
         (kata, w_kata, 0.080, 2, 12, 0.38), (alpha, w_alpha, 0.004, 2, 10, 0.35),
+    ] if not dense else [
+        (hira, w_hira, 0.160, 2, 6, 0.55), (kanji, w_kanji, 0.030, 1, 1, 0.99), (kanji, w_kanji, 0.420, 2, 8, 0.75),
+        (kata, w_kata, 0.060, 2, 10, 0.40), (alpha, w_alpha, 0.004, 2, 10, 0.35),
     ]
     for pool, w, frac, lo, hi, p in plan:
         _make_words(rng, pool, w, int(tgt_unique * frac), lo, hi, p, seen, words)
@@ -138,14 +145,14 @@ def build_dict(n_records: int = 392_000, seed: int = SEED_DICT, n_context: int =
 
     # records per surface
     nrec = np.ones(len(words), dtype=np.int64)
-    multi = rng.random(len(words)) < 0.15
-    nrec[multi] += np.minimum(rng.geometric(0.45, size=int(multi.sum())), 7)
-    nrec[:n_single_hira] = rng.integers(3, 9, size=n_single_hira)
+    multi = rng.random(len(words)) < (0.50 if dense else 0.15)
+    nrec[multi] += np.minimum(rng.geometric(0.40 if dense else 0.45, size=int(multi.sum())), 7)
+    nrec[:n_single_hira] = rng.integers(5, 13, size=n_single_hira) if dense else rng.integers(3, 9, size=n_single_hira)
     diff = n_records - int(nrec.sum())
     i = n_single_hira
     idle = 0
     while diff != 0:  # hit the record count exactly
-        if diff > 0 and nrec[i] < 8:
+        if diff > 0 and nrec[i] < (12 if dense else 8):
             nrec[i] += 1; diff -= 1; idle = 0
         elif diff < 0 and nrec[i] > 1:
             nrec[i] -= 1; diff += 1; idle = 0
@@ -192,6 +199,8 @@ def build_dict(n_records: int = 392_000, seed: int = SEED_DICT, n_context: int =
     wts[:n_single_hira] *= 40.0
     is_hira = np.array([0x3041 <= ord(w[0]) <= 0x3093 and 0x3041 <= ord(w[-1]) <= 0x3093 for w in words])
     wts[is_hira] *= 4.0
+    if dense:  # the corpus leans on what makes lattices dense: short surfaces with many records and many longer words starting with them
+        wts *= np.asarray(nrec, dtype=np.float64) ** 0.5
     wts /= wts.sum()
     return SynthDict(d, words, wts, total)
 

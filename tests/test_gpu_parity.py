@@ -291,7 +291,7 @@ def test_device_api_and_work_counters(full):
     assert np.array_equal(t.reshape(-1), exp.tokens.view(np.int32).reshape(-1))
     assert ctx.work() == exp.counters
     p = ctx.profile()
-    assert p["launches"] == 1 + p["tail_reruns"] and p["tokenize_ms"] > 0  # (a batch that finds the chain's tail left out is run twice)
+    assert p["launches"] == 1 and p["tokenize_ms"] > 0  # (a batch that finds the chain's tail left out gets the tail alone afterwards: the chain is timed once)
 
 
 @pytest.mark.parametrize("pool,long_kib", [("0", "0"), ("0", "12"), ("0", "4"), ("0", "160"), ("80:10", "32"), ("80:8:20", "12"), ("80:8,160:4", "32"),
