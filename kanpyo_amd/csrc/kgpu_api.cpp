@@ -15,6 +15,10 @@
 #include <functional>
 #include <thread>
 #include <pthread.h>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <climits>
+#include <memory>
 #include <unistd.h>
 #include <cstdarg>
 #include <cstdio>
@@ -979,7 +983,13 @@ void WorkerPool::submit(std::function<void()> f) { { std::lock_guard<std::mutex>
 // A counter of tasks reaching zero: a short spin (the common case: the workers are almost through), then sleeps on the pool's
 // completion signal instead of burning a core the workers could use.
 void WorkerPool::wait_zero(std::atomic<int> &counter) {
-    for (int spin = 0; spin < 256; ++spin) { if (counter.load(std::memory_order_acquire) == 0) return; std::this_thread::yield(); }
+    // (the tasks waited for here are tens of microseconds long: a sleep costs more than it saves until the wait has lasted a while)
+    timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+        for (int spin = 0; spin < 64; ++spin) { if (counter.load(std::memory_order_acquire) == 0) return; std::this_thread::yield(); }
+        timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000 > 2000) break;
+    }
     std::unique_lock<std::mutex> l(done_mu);
     while (counter.load(std::memory_order_acquire) != 0) done_cv.wait_for(l, std::chrono::microseconds(200));
 }
@@ -1240,75 +1250,91 @@ static int small_call(kgpu_dict *d, kgpu_ctx *c, SmallReq *const *reqs, size_t n
 // window (only while other callers are inside the entry point: a lone caller never waits), takes a pooled context, launches, and hands
 // every follower its own dense slice back.  Followers sleep on a condition variable meanwhile.
 struct Combiner {
-    struct Batch { std::vector<SmallReq *> reqs; uint64_t n = 0, bytes = 0; bool closed = false; int launch_rc = KGPU_OK; char err[200] = ""; };
+    // A batch lives on the heap, shared by its leader and its followers (a follower may still be reading its own result when the leader returns).
+    struct Batch {
+        std::vector<SmallReq *> reqs; uint64_t n = 0, bytes = 0; bool closed = false;
+        std::atomic<uint32_t> done{0};   // futex word: followers sleep on it, ONE wake-all syscall releases them (no shared condition variable: a
+    };                                   // batch's completion wakes its own followers only, and nobody queues on a mutex to find out)
     std::mutex mu;
-    std::condition_variable cv;
-    Batch *open = nullptr;
-    std::atomic<int> callers{0};
+    std::shared_ptr<Batch> open;
+    std::atomic<int> callers{0};     // threads inside the small-call entry
+    std::atomic<int> in_flight{0};   // launches between close and completion
 };
 static Combiner *combiner_new() { return new Combiner(); }
 static void combiner_delete(Combiner *c) { delete c; }
 static Combiner &combiner_of(kgpu_dict *d) { return *d->combiner; }
 static unsigned combine_window_us() {
-    static const unsigned us = [] { const char *e = getenv("KGPU_COMBINE_US"); const int v = e ? atoi(e) : 15; return (unsigned)(v < 0 ? 0 : v > 1000 ? 1000 : v); }();
+    static const unsigned us = [] { const char *e = getenv("KGPU_COMBINE_US"); const int v = e ? atoi(e) : 12; return (unsigned)(v < 0 ? 0 : v > 1000 ? 1000 : v); }();
     return us;
 }
+static int combine_max_in_flight() {
+    static const int v = [] { const char *e = getenv("KGPU_COMBINE_LAUNCHES"); const int x = e ? atoi(e) : 4; return x < 1 ? 1 : x > 64 ? 64 : x; }();
+    return v;
+}
+static void futex_wait(std::atomic<uint32_t> *w, uint32_t expected) { syscall(SYS_futex, (uint32_t *)w, FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0); }
+static void futex_wake_all(std::atomic<uint32_t> *w) { syscall(SYS_futex, (uint32_t *)w, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
 
 // KGPU_OK / KGPU_ERR_CAPACITY: served; -1: take the general path; other: error
 static int small_call_combined(kgpu_dict *d, SmallReq &me) {
     Combiner &cb = combiner_of(d);
     const uint64_t my_bytes = me.offsets[me.n] - me.offsets[0];
     struct CallerCount { std::atomic<int> &c; CallerCount(std::atomic<int> &c_) : c(c_) { c.fetch_add(1, std::memory_order_acq_rel); } ~CallerCount() { c.fetch_sub(1, std::memory_order_acq_rel); } } in(cb.callers);
-    Combiner::Batch mine;
+    std::shared_ptr<Combiner::Batch> mine;
     {
         std::unique_lock<std::mutex> l(cb.mu);
-        Combiner::Batch *b = cb.open;
+        std::shared_ptr<Combiner::Batch> b = cb.open;
         if (b && !b->closed && b->n + me.n <= SMALL_MAX_N && b->bytes + my_bytes <= SMALL_MAX_BYTES) {   // join the batch being assembled
             b->reqs.push_back(&me); b->n += me.n; b->bytes += my_bytes;
-            cb.cv.wait(l, [&] { return me.done; });
+            l.unlock();
+            while (b->done.load(std::memory_order_acquire) == 0) futex_wait(&b->done, 0);   // the leader has written my records and my rc before it sets the word
             if (me.rc > 0 && me.err[0]) set_error("%s", me.err);
             return me.rc;
         }
-        mine.reqs.push_back(&me); mine.n = me.n; mine.bytes = my_bytes;
-        cb.open = &mine;   // (a batch another leader still holds open but that has no room for me stays its leader's: it closes it itself)
+        mine = std::make_shared<Combiner::Batch>();
+        mine->reqs.push_back(&me); mine->n = me.n; mine->bytes = my_bytes;
+        cb.open = mine;   // (a batch another leader still holds open but that has no room for me stays its leader's: it closes it itself)
     }
-    // leader: keep the batch open for a short window while other callers are around (spinning: the window is shorter than a futex sleep)
+    // Leader.  A lone caller launches at once.  With other callers inside the entry point the batch stays open for a short window -- and, when
+    // the device already has its fill of small launches in flight, until one of them completes (or the batch is full): the batch size follows the
+    // load (group commit), the number of launches per second stays what the streams carry.  Spinning: the waits are shorter than a futex sleep.
     const unsigned win = combine_window_us();
     if (win && cb.callers.load(std::memory_order_acquire) > 1) {
         timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
         for (;;) {
-            for (int k = 0; k < 32; ++k) {
+            for (int k = 0; k < 16; ++k) {
 #if defined(__x86_64__)
                 __builtin_ia32_pause();
 #endif
             }
             timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
-            if ((t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000 >= (long long)win) break;
+            const long long us = (t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000;
+            const bool busy = cb.in_flight.load(std::memory_order_acquire) >= combine_max_in_flight();
+            if ((us >= (long long)win && !busy) || us >= 400) break;
             std::lock_guard<std::mutex> g(cb.mu);
-            if (mine.n >= SMALL_MAX_N || mine.bytes + 256 > SMALL_MAX_BYTES || (int)mine.reqs.size() >= cb.callers.load(std::memory_order_acquire)) break;  // full, or everyone who is here is in
+            if (mine->n >= SMALL_MAX_N || mine->bytes + 256 > SMALL_MAX_BYTES) break;  // full
+            if (!busy && (int)mine->reqs.size() >= cb.callers.load(std::memory_order_acquire)) break;  // everyone who is here is in
         }
     }
     {
         std::lock_guard<std::mutex> g(cb.mu);
-        mine.closed = true;
-        if (cb.open == &mine) cb.open = nullptr;
+        mine->closed = true;
+        if (cb.open == mine) cb.open.reset();
     }
+    cb.in_flight.fetch_add(1, std::memory_order_acq_rel);
     kgpu_ctx *c = nullptr;
     int rc = pool_get(d, &c);
     if (!rc) {
-        rc = c->plan.n_pools ? small_call(d, c, mine.reqs.data(), mine.reqs.size()) : KGPU_OK;
+        rc = c->plan.n_pools ? small_call(d, c, mine->reqs.data(), mine->reqs.size()) : KGPU_OK;
         pool_put(d, c);
     }
-    {
-        std::lock_guard<std::mutex> g(cb.mu);
-        for (SmallReq *q : mine.reqs) {
-            if (rc) { q->rc = rc; snprintf(q->err, sizeof q->err, "%s", kgpu_last_error()); }
-            q->done = true;
-        }
-    }
-    if (mine.reqs.size() > 1) cb.cv.notify_all();
-    if (me.rc > 0 && me.rc != rc && me.err[0]) set_error("%s", me.err);
-    return me.rc;
+    cb.in_flight.fetch_sub(1, std::memory_order_acq_rel);
+    const int my_rc = rc ? rc : me.rc;
+    if (rc) for (SmallReq *q : mine->reqs) { q->rc = rc; snprintf(q->err, sizeof q->err, "%s", kgpu_last_error()); }
+    const bool had_followers = mine->reqs.size() > 1;
+    mine->done.store(1, std::memory_order_release);   // (followers may return -- and their SmallReq die -- from here on: nothing of theirs is touched below)
+    if (had_followers) futex_wake_all(&mine->done);
+    if (my_rc > 0 && !rc && me.err[0]) set_error("%s", me.err);
+    return my_rc;
 }
 
 // The plain form of a large call (24-byte records, device-to-host copies on the context's stream): what a chunk falls back to when
