@@ -410,11 +410,9 @@ def measure_config(tok, dev, wl, n_chars, passes, queue, streams, label, orc=Non
         "batch": wl.batch, "batches_per_pass": wl.nb(0), "batches_in_flight": eng.Q,
         "first_batch_bit_exact_vs_oracle": bit_exact,
         "launch_plan": plan,
-        "lds_bytes_per_workgroup": {"pool_kernel": plan["pool_lds_bytes"], "long_sentence_kernel": plan["long_lds_bytes"], "windowed_kernel": plan["window_lds_bytes"]},
-        "resident_workgroups_per_cu": {"pool_kernel": plan["pool_workgroups_per_cu"], "long_sentence_kernel": plan["long_workgroups_per_cu"],
-                                       "windowed_kernel": plan["window_workgroups_per_cu"]},
-        "resident_wavefronts_per_cu": {"pool_kernel": plan["pool_workgroups_per_cu"] * plan["pool_wavefronts"], "long_sentence_kernel": plan["long_workgroups_per_cu"],
-                                       "windowed_kernel": plan["window_workgroups_per_cu"]},
+        "lds_bytes_per_workgroup": {"pool_kernel": plan["pool_lds_bytes"], "windowed_kernel": plan["window_lds_bytes"]},
+        "resident_workgroups_per_cu": {"pool_kernel": plan["pool_workgroups_per_cu"], "windowed_kernel": plan["window_workgroups_per_cu"]},
+        "resident_wavefronts_per_cu": {"pool_kernel": plan["pool_workgroups_per_cu"] * plan["pool_wavefronts"], "windowed_kernel": plan["window_workgroups_per_cu"]},
     }
 
 

@@ -128,11 +128,11 @@ typedef struct kgpu_routing {
     uint64_t batches;         /* batches completed                                            */
     uint64_t sentences;       /* sentences in them                                            */
     uint64_t deferred[4];     /* sentences handed from launch k of the chain to launch k+1
-                                 ([0]: left the LDS-resident kernel for the long-sentence /
-                                 HBM-scratch kernels)                                         */
+                                 ([0]: left the LDS-resident kernel for the windowed kernel;
+                                 [1]: left that one for the general, HBM-scratch kernel)       */
     uint64_t redone[4];       /* ... of which only after the trie walk had been paid for
                                  (LDS reservation too small: the sentence was redone)         */
-    uint64_t long_launches;   /* batches for which the long-sentence kernel was launched      */
+    uint64_t long_launches;   /* batches for which the windowed (long-sentence) kernel was launched */
     uint64_t arena_regrows;   /* batches rerun because the HBM scratch arena was too small    */
     double first_ms;          /* with KGPU_PROFILE_EVENTS: sum over the timed batches of the FIRST launch alone, the dominant
                                  kernel (k_tokenize_pool) -- the number rocprofv3's kernel stats report for it        */
@@ -154,12 +154,13 @@ typedef struct kgpu_plan_info {
     uint32_t pool_wavefronts;         /* ... independent wavefronts (= sentences in flight) sharing it             */
     uint32_t pool_workgroups_per_cu;  /* ... workgroups resident per CU (occupancy API)                            */
     uint32_t pool_max_pages;          /* ... pages of 64 a sentence may take before it is routed to the long path  */
-    uint32_t long_lds_bytes;          /* long-sentence kernel: LDS per single-wavefront workgroup (sweep blocks)    */
-    uint32_t long_workgroups_per_cu;  /* ... resident per CU (occupancy API)                                       */
-    uint32_t long_workgroups;         /* ... grid of one launch                                                    */
-    uint32_t window_lds_bytes;        /* windowed kernel (very long sentences): LDS per single-wavefront workgroup, 0 = off */
+    uint32_t long_lds_bytes;          /* (rounds 2-3: a second long-sentence kernel; removed -- always 0.  The fields keep their places.)  */
+    uint32_t long_workgroups_per_cu;
+    uint32_t long_workgroups;
+    uint32_t window_lds_bytes;        /* windowed kernel (everything the pool kernel routes away: ~150 characters and more, any length; dense
+                                         lattices): LDS per single-wavefront workgroup, 0 = off                          */
     uint32_t window_workgroups_per_cu;/* ... resident per CU (occupancy API)                                       */
-    uint32_t window_min_bytes;        /* ... sentences at least this long take it                                  */
+    uint32_t window_workgroups;       /* ... grid of one launch                                                    */
     uint32_t streams;                 /* HIP streams the dictionary's NULL-stream contexts share: 4 when the process has GPU_MAX_HW_QUEUES >= 5
                                          (the library sets it to 8 itself when it is loaded before the HIP runtime initialises and the variable
                                          is unset), else 3 -- and kgpu_last_error() then carries a warning after kgpu_dict_create            */
@@ -184,6 +185,8 @@ typedef struct kgpu_work {
 #define KGPU_PROFILE_EVENTS 1 /* HIP events around the kernels            */
 #define KGPU_PROFILE_WORK 2   /* device-side work counters (kgpu_work)    */
 #define KGPU_PROFILE_SAMPLED 4 /* with EVENTS: time every 4th launch only  */
+#define KGPU_PROFILE_NO_T 8    /* with WORK: leave kgpu_work.T at 0 -- the byte-level walk that counts the reference's trie steps runs
+                                  beside the product's character-level walk and distorts the walk phase of kgpu_ctx_get_phase_cycles */
 
 const char *kgpu_last_error(void);
 int kgpu_device_count(void);

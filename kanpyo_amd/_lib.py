@@ -77,7 +77,7 @@ class Routing(C.Structure):  # kgpu_routing: read with its size, fields are only
 
 class PlanInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("compute_units", "pool_lds_bytes", "pool_wavefronts", "pool_workgroups_per_cu", "pool_max_pages",
-                                          "long_lds_bytes", "long_workgroups_per_cu", "long_workgroups", "window_lds_bytes", "window_workgroups_per_cu", "window_min_bytes",
+                                          "long_lds_bytes", "long_workgroups_per_cu", "long_workgroups", "window_lds_bytes", "window_workgroups_per_cu", "window_workgroups",
                                           "streams")] + [("reserved", C.c_uint32 * 4)]
 
 

@@ -542,17 +542,17 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
     if (a.n) {
         const int pools_now = c->dict->big_pool_batches.load(std::memory_order_relaxed) > 0 ? c->plan.n_pools : std::min(c->plan.n_pools, 1);
         c->last_pools = pools_now;
-        c->last_long = c->plan.long_lds_bytes && (c->plan.n_pools == 0 || c->dict->long_batches.load(std::memory_order_relaxed) > 0);
-        // the windowed kernel (very long sentences) is in the chain while recent batches held such sentences -- an empty launch of a few
-        // thousand workgroups behind a chip full of long-running wavefronts is not free -- or always, without a pool kernel to count them
-        const bool window_now = c->plan.window_lds_bytes && !c->force_legacy_long && !a.dump_lattice && c->stop_after == 0 &&
-                                (c->plan.n_pools == 0 || c->dict->window_batches.load(std::memory_order_relaxed) > 0);
+        // The windowed kernel is in the chain while recent batches left the pools sentences (starts armed) -- an empty launch of a few thousand
+        // workgroups behind a chip full of long-running wavefronts is not free -- or always, without a pool kernel in front of it.
+        const bool window_now = c->plan.window_lds_bytes && !c->no_window && !a.dump_lattice && c->stop_after == 0 &&
+                                (pools_now == 0 || c->dict->window_batches.load(std::memory_order_relaxed) > 0);
         c->last_window = window_now;
-        // The tail of the chain: the HBM-lattice kernel while recent batches left it sentences (last_long); otherwise nothing -- a sentence that
-        // does need it shows in the last work list's count, and kgpu_ctx_sync runs the batch again with the kernel armed.  (Without a
-        // long-sentence kernel in the plan, in ablation and dump runs the last-resort kernel closes every chain as before.)
-        c->last_tail = !(c->plan.n_pools > 0 && c->plan.long_lds_bytes && c->stop_after == 0 && !a.dump_lattice && !c->last_long);
-        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->last_long, c->stop_after, c->stream, ef, window_now, c->last_tail);
+        // The general kernel closes the chain when nothing else is in it, in ablation / dump runs, and while recent batches left it sentences;
+        // otherwise nothing does -- a sentence that needed more shows in the last work list's count, and kgpu_ctx_sync launches what is missing
+        // over that list.
+        c->last_tail = (pools_now == 0 && !window_now) || c->stop_after != 0 || a.dump_lattice || c->no_window ||
+                       c->dict->tail_batches.load(std::memory_order_relaxed) > 0;
+        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->stop_after, c->stream, ef, window_now, c->last_tail);
         if (e != hipSuccess) { set_error("k_tokenize launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     } else if (timed) HIPCHECK(hipEventRecord(ef, c->stream));
     if (timed) HIPCHECK(hipEventRecord(e1, c->stream));
@@ -593,7 +593,7 @@ int kgpu::tokenize_device_impl(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_
     a.tok_count = (uint32_t *)c->tok_count.p;
     a.status = d_status; a.out = d_tokens; a.out_cap = token_capacity; a.tok_offsets = d_tok_offsets;
     a.out8 = d_tokens8; a.first8 = d_first; a.status8 = status8; a.toff8 = toff8;
-    a.count_work = c->count_work ? 1u : 0u;
+    a.count_work = c->count_work ? (c->count_no_t ? 3u : 1u) : 0u;
 #ifdef KGPU_STEP_TIMING
     const bool want_stats = true;
 #else
@@ -614,13 +614,14 @@ int kgpu::tokenize_device_impl(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_
 // The long-sentence kernel alone over work list `li` of the pending batch (which the chain left unserved), then scan + compaction again.
 static int enqueue_tail(kgpu_ctx *c, int li) {
     const BatchArgs &a = c->last;
-    // (pinned source that must outlive the copy: a field of the context; the stream orders the copy before the kernels and after the scan kernel's zeroing)
+    // (the scan kernel zeroed the control block after publishing it; the completed batch is behind us on the stream)
     HIPCHECK(hipMemcpyAsync(&c->d_ctl->ovf_count[li], &c->tail_count, sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
     c->ctl_dirty = true;
-    c->last_long = true;
-    c->last_tail = true;
-    hipError_t e = (hipError_t)launch_tail_only(c->dict->view, a, c->plan, li, c->stream);
+    const bool window_was_in = c->last_window;
+    hipError_t e = (hipError_t)launch_tail_only(c->dict->view, a, c->plan, li, window_was_in || c->no_window, c->stream);
     if (e != hipSuccess) { set_error("tail launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    if (!window_was_in && !c->no_window && c->plan.window_lds_bytes) c->last_window = true;
+    c->last_tail = true;
     c->h_ctl->pack_overflow = 0;
     e = (hipError_t)launch_scan_compact(a, c->h_ctl_dev, c->stream);
     if (e != hipSuccess) { set_error("scan/compact launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
@@ -664,36 +665,38 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
     for (;;) {
         if (!c->pending) { if (n_tokens) *n_tokens = 0; return KGPU_OK; }
         HIPCHECK(hipEventSynchronize(c->done_ev));  // this context's batch only: later work on a shared stream is not waited for
-        if (c->h_ctl->window_fail && !c->h_ctl->arena_overflow && !c->force_legacy_long) {
-            // a sentence the windowed kernel cannot hold: the batch once more, long sentences through the HBM-lattice kernel
-            c->force_legacy_long = true;
+        if (c->h_ctl->window_fail && !c->h_ctl->arena_overflow && !c->no_window) {
+            // the windowed kernel met a sentence it cannot hold and had no list to hand it on to: the batch once more without it
+            c->no_window = true;
             c->rt.window_reruns++;
             static const bool wtrace = env_flag_now("KGPU_WINDOW_TRACE");
             if (wtrace) {
                 const unsigned long long *w = c->h_ctl->phase;
-                fprintf(stderr, "window kernel handed back sentences of a batch of %llu: seeds out of range %llu, > 8 prefixes %llu, node chunks %llu, FIFO full %llu, "
+                fprintf(stderr, "window kernel handed back sentences of a batch of %llu: seeds out of range %llu, prefix overflow %llu, node chunks %llu, FIFO full %llu, "
                                 "FIFO chunks %llu, FIFO order %llu, carry list %llu, window LDS %llu\n", (unsigned long long)c->last.n, w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
             }
             // the rerun counts everything again: drop what this run left in the per-wavefront slots
             if (c->last.stat_slots) HIPCHECK(hipMemsetAsync(c->last.stat_slots, 0, (size_t)STAT_SLOTS * STAT_WORDS * 8, c->stream));
+            c->tail_pass = false;
             int rc = enqueue(c, c->last);
-            c->force_legacy_long = false;
+            c->no_window = false;
             if (rc) { c->pending = false; return rc; }
             continue;
         }
-        if (!c->last_tail && !c->last_long && c->last.n && !c->h_ctl->arena_overflow &&
-            c->h_ctl->ovf_count[c->last_pools - 1 + (c->last_window ? 1 : 0)] > 0) {
-            // The chain ended without its tail and a sentence needed it: ONLY the missing kernel, over the last work list (still in device
-            // memory; its length goes back into the control block the scan kernel zeroed), then scan + compaction once more.  The pool
-            // kernel's work is not repeated: a corpus with a sparse but steady share of long sentences pays one small launch per such
-            // batch, not the batch twice.  What the first pass counted (routing, estimate feedback, work counters) is kept and merged below.
-            const int li = c->last_pools - 1 + (c->last_window ? 1 : 0);
-            c->dict->long_batches.store(64, std::memory_order_relaxed);
+        const int li_last = c->last_pools - 1 + (c->last_window ? 1 : 0);   // the list the chain ended on
+        if (!c->last_tail && c->last.n && li_last >= 0 && !c->h_ctl->arena_overflow && c->h_ctl->ovf_count[li_last] > 0) {
+            // The chain ended without its tail and a sentence needed it: ONLY what is missing (the windowed kernel if it was not in the chain,
+            // then the general kernel), over the last work list (still in device memory; its length goes back into the control block the scan
+            // kernel zeroed), then scan + compaction once more.  The pool kernel's work is not repeated: a corpus with a sparse but steady
+            // share of long sentences pays a small launch per such batch, not the batch twice.  What the first pass counted (routing,
+            // estimate feedback, work counters) is kept and merged below.
             c->rt.tail_reruns++;
             c->tail_saved = *c->h_ctl;
             c->tail_pass = true;
-            c->tail_count = c->h_ctl->ovf_count[li];
-            int rc = enqueue_tail(c, li);
+            c->tail_li = li_last;
+            c->tail_had_window = c->last_window;
+            c->tail_count = c->h_ctl->ovf_count[li_last];
+            int rc = enqueue_tail(c, li_last);
             if (rc) { c->pending = false; c->tail_pass = false; return rc; }
             continue;
         }
@@ -715,34 +718,39 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
         break;
     }
     c->pending = false;
+    bool first_window = c->last_window, first_tail = c->last_tail;   // what the FIRST pass of this batch had in its chain (the arming below decays on that)
     if (c->tail_pass) {   // the published block is the tail pass's: put back what the first pass had counted
         c->tail_pass = false;
+        first_window = c->tail_had_window; first_tail = false;
         Control &h = *c->h_ctl;
         const Control &sv = c->tail_saved;
-        const int li = c->last_pools - 1 + (c->last_window ? 1 : 0);   // the list the tail served: it and the ones before it are the first pass's
-        for (int k = 0; k < 4; ++k) { if (k <= li) h.ovf_count[k] = sv.ovf_count[k]; h.late_count[k] += sv.late_count[k]; }
-        h.very_long += sv.very_long;
+        for (int k = 0; k < 4; ++k) { if (k <= c->tail_li) h.ovf_count[k] = sv.ovf_count[k]; h.late_count[k] += sv.late_count[k]; }   // lists up to the one the tail served are the first pass's
         for (int k = 0; k < 7; ++k) h.work[k] += sv.work[k];
         for (int k = 0; k < 10; ++k) h.phase[k] += sv.phase[k];
         h.pack_overflow |= sv.pack_overflow;
     }
     c->rt.batches++; c->rt.sentences += c->last.n;
     for (int k = 0; k < 4; ++k) { c->rt.deferred[k] += c->h_ctl->ovf_count[k]; c->rt.redone[k] += c->h_ctl->late_count[k]; }
-    if (c->last_long && c->last.n) c->rt.long_launches++;
+    if (c->last_window && c->last.n) c->rt.long_launches++;
+    if (c->last.n && c->last_pools > 0) {
+        // arming of the launches behind the pools: what the pools left arms the windowed kernel, what the windowed kernel left arms the general
+        // kernel; eight clean batches disarm (a wrong guess costs one small extra launch over the batch's last list, not the batch)
+        const unsigned pool_left = c->h_ctl->ovf_count[c->last_pools - 1];
+        if (c->plan.window_lds_bytes) {
+            if (pool_left > 0) c->dict->window_batches.store(64, std::memory_order_relaxed);
+            else if (first_window) c->dict->window_batches.fetch_sub(8, std::memory_order_relaxed);
+        }
+        if (c->last_window || !c->plan.window_lds_bytes) {   // (a batch whose pools left sentences while the windowed kernel was disarmed re-arms that one, not this)
+            const unsigned behind = c->last_window ? c->h_ctl->ovf_count[c->last_pools] : pool_left;   // what the last launch in front of the general kernel left
+            if (behind > 0) c->dict->tail_batches.store(64, std::memory_order_relaxed);
+            else if (first_tail) c->dict->tail_batches.fetch_sub(8, std::memory_order_relaxed);
+        }
+    }
     if (c->last.n && c->plan.n_pools) {
         // The pool kernel reserves est LDS bytes per input byte up front: a reservation that proves
         // too small costs a redo (late_count), one that is too large only idles pages until the
         // lattice is known -- steer for a redo rate of 1-3 %.  Applied to the value the batch ran with; races between
         // contexts only lose an adjustment.
-        if (c->last_pools > 0 && c->plan.long_lds_bytes) {  // sentences that neither a pool nor the windowed kernel took
-            const int left = c->last_pools - 1 + (c->last_window ? 1 : 0);
-            if (c->h_ctl->ovf_count[left] > 0) c->dict->long_batches.store(64, std::memory_order_relaxed);
-            else if (c->last_long) c->dict->long_batches.fetch_sub(8, std::memory_order_relaxed);  // (eight clean batches disarm it: a wrong guess costs one batch in the last-resort kernel)
-        }
-        if (c->plan.window_lds_bytes) {
-            if (c->h_ctl->very_long > 0) c->dict->window_batches.store(64, std::memory_order_relaxed);
-            else if (c->last_window) c->dict->window_batches.fetch_sub(8, std::memory_order_relaxed);
-        }
         if (c->plan.n_pools > 1) {
             if (c->h_ctl->ovf_count[0] > 0) c->dict->big_pool_batches.store(64, std::memory_order_relaxed);
             else if (c->last_pools > 1) c->dict->big_pool_batches.fetch_sub(1, std::memory_order_relaxed);
@@ -804,6 +812,7 @@ extern "C" int kgpu_ctx_set_profiling(kgpu_ctx *c, int mode) {
     c->event_every = (mode & KGPU_PROFILE_SAMPLED) ? 4u : 1u;
     c->launch_seq = 0;
     c->count_work = (mode & KGPU_PROFILE_WORK) != 0;
+    c->count_no_t = (mode & KGPU_PROFILE_NO_T) != 0;
     return KGPU_OK;
 }
 
@@ -843,9 +852,7 @@ extern "C" int kgpu_ctx_get_plan(kgpu_ctx *c, kgpu_plan_info *out, size_t out_si
         p.pool_lds_bytes = c->plan.pool_bytes[0]; p.pool_wavefronts = c->plan.pool_waves[0]; p.pool_max_pages = c->plan.pool_max_pages[0];
         p.pool_workgroups_per_cu = (uint32_t)pool_workgroups_per_cu(c->plan.pool_bytes[0], c->plan.pool_waves[0]);
     }
-    p.long_lds_bytes = c->plan.long_lds_bytes; p.long_workgroups = (uint32_t)c->plan.long_workgroups;
-    p.long_workgroups_per_cu = c->plan.long_lds_bytes ? (uint32_t)long_workgroups_per_cu(c->plan.long_lds_bytes) : 0u;
-    p.window_lds_bytes = c->plan.window_lds_bytes; p.window_min_bytes = WINDOW_MIN_BYTES;
+    p.window_lds_bytes = c->plan.window_lds_bytes; p.window_workgroups = (uint32_t)c->plan.window_workgroups;
     p.window_workgroups_per_cu = c->plan.window_lds_bytes ? (uint32_t)window_workgroups_per_cu(c->plan.window_lds_bytes) : 0u;
     p.streams = planned_streams();
     std::memcpy(out, &p, std::min(out_size, sizeof p));
@@ -1153,7 +1160,14 @@ struct SmallReq {
 
 // The launch for one or more callers' sentences (`reqs` in arrival order; together at most SMALL_MAX_N sentences / SMALL_MAX_BYTES).
 // Returns KGPU_OK when the launch itself went through (every request then has its own rc), else the error (no request was served).
+// KGPU_SMALL_TRACE=1: where a small call's wall time goes, summed over the process (microseconds): kgpu_debug_small_trace reads and resets
+static std::atomic<uint64_t> g_st[8];  // launches, prep ns, launch-call ns, poll ns, hand-out ns, sentences
+static inline uint64_t now_ns() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
+extern "C" void kgpu_debug_small_trace(uint64_t out[8]) { for (int k = 0; k < 8; ++k) out[k] = g_st[k].exchange(0); }
+
 static int small_call(kgpu_dict *d, kgpu_ctx *c, SmallReq *const *reqs, size_t nreq) {
+    static const bool trace = env_flag_now("KGPU_SMALL_TRACE");
+    const uint64_t tt0 = trace ? now_ns() : 0;
     uint64_t n = 0, total = 0;
     for (size_t r = 0; r < nreq; ++r) { n += reqs[r]->n; total += reqs[r]->offsets[reqs[r]->n] - reqs[r]->offsets[0]; }
     int rc;
@@ -1194,10 +1208,12 @@ static int small_call(kgpu_dict *d, kgpu_ctx *c, SmallReq *const *reqs, size_t n
     a.fused_host = c->h_ctl_dev; a.fused_seq = seq;
     if (c->ctl_dirty) HIPCHECK(hipMemsetAsync(c->d_ctl, 0, sizeof(Control), c->stream));
     c->ctl_dirty = true;
+    const uint64_t tt1 = trace ? now_ns() : 0;
     {
         hipError_t e = (hipError_t)launch_small_call(d->view, a, c->plan, c->stream);
         if (e != hipSuccess) { set_error("small-call launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     }
+    const uint64_t tt2 = trace ? now_ns() : 0;
     // poll the sequence number (the kernel's last store); a stream query now and then catches a failed launch
     for (uint64_t spin = 0;; ++spin) {
         if (__atomic_load_n(&c->h_ctl->small_flag, __ATOMIC_ACQUIRE) == seq) break;
@@ -1213,6 +1229,8 @@ static int small_call(kgpu_dict *d, kgpu_ctx *c, SmallReq *const *reqs, size_t n
         __builtin_ia32_pause();
 #endif
     }
+    const uint64_t tt3 = trace ? now_ns() : 0;
+    struct TraceOut { bool on; uint64_t t0, t1, t2, t3, n; ~TraceOut() { if (on) { const uint64_t t4 = now_ns(); g_st[0] += 1; g_st[1] += t1 - t0; g_st[2] += t2 - t1; g_st[3] += t3 - t2; g_st[4] += t4 - t3; g_st[5] += n; } } } trace_out{trace, tt0, tt1, tt2, tt3, n};
     c->ctl_dirty = false;  // the publishing wavefront zeroed the device block
     c->rt.batches++; c->rt.sentences += n;
     c->rt.deferred[0] += c->h_ctl->ovf_count[0]; c->rt.redone[0] += c->h_ctl->late_count[0];

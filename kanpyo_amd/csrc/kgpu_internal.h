@@ -88,7 +88,7 @@ struct Control {
     unsigned int pack_overflow;       // compact records: a token did not fit kgpu_token8 (chars > 4095 or bytes > 262143): the host falls back to 24-byte records
     unsigned int window_fail;         // the windowed long-sentence kernel met a sentence it cannot hold AND had no list to hand it on to: the host reruns the batch with the HBM-lattice kernel
     unsigned int small_abort;         // ... a wavefront gave up waiting at the rendezvous: the host redoes the call on the general path
-    unsigned int very_long;           // sentences of WINDOW_MIN_BYTES or more seen by the pool kernel (arms the windowed kernel for the following batches)
+    unsigned int pad2;
     unsigned int pad3;
     unsigned long long dump[8];       // kgpu_lattice_dump: arena offsets of the sentence's two slabs, B, C, N, 1 = valid, dp of EOS
 };
@@ -119,16 +119,12 @@ struct BatchArgs {
     uint8_t *status8;                // optional (host path): the compaction kernel mirrors status[] there (mapped host memory)
     uint64_t *toff8;                 // optional (host path): ... and tok_offsets[] (n + 1), so that it reads its offsets from HBM, not back over PCIe
 };                                   // (added to by its owner, summed on the host: hot atomics on a few words would distort the run)
-#ifndef KGPU_WINDOW_MIN_BYTES
-#define KGPU_WINDOW_MIN_BYTES 3072
-#endif
-constexpr uint32_t WINDOW_MIN_BYTES = KGPU_WINDOW_MIN_BYTES;  // sentences at least this long (~1000 characters) take the windowed kernel; shorter long ones the HBM-lattice kernel
 constexpr uint32_t STAT_SLOTS = 16384, STAT_WORDS = 32;  // words 0..6: Control::work, 16..25: Control::phase
 
 // Launch plan of one batch: the LDS page-pool kernel (kgpu_pool.hip) once or twice -- W independent
-// wavefronts per workgroup share pool_bytes of LDS, each sentence takes what it needs -- then the
-// general kernel, whose lattices live in HBM scratch, for whatever fits no pool.  A sentence that
-// a launch cannot serve is pushed onto the next launch's work list.
+// wavefronts per workgroup share pool_bytes of LDS, each sentence takes what it needs -- then the windowed kernel
+// (kgpu_window.hip: bounded LDS whatever the length) for whatever fits no pool, then the general kernel, whose lattices
+// live in HBM scratch, as the last resort.  A sentence that a launch cannot serve is pushed onto the next launch's work list.
 struct LaunchPlan {
     int n_pools;
     uint32_t pool_bytes[2];
@@ -136,27 +132,24 @@ struct LaunchPlan {
     uint32_t pool_max_pages[2];  // of 64: larger reservations are routed to the next launch
     int pool_workgroups[2];   // persistent grid per pool launch
     int general_workgroups;
-    uint32_t long_lds_bytes;  // 0: no long-sentence kernel (general kernel with an LDS-blocked sweep)
-    int long_workgroups;
-    uint32_t window_lds_bytes;  // > 0: the windowed long-sentence kernel (kgpu_window.hip) takes the long-sentence kernel's place in the chain
+    uint32_t window_lds_bytes;  // > 0: the windowed kernel (kgpu_window.hip) behind the pools; 0: the general kernel serves what they route away
     int window_workgroups;
 };
 
 // Launchers (kgpu_kernels.hip).  `stream` is a hipStream_t.
 // n_pools_now <= plan.n_pools: how many of the pool launches to issue for this batch (the chain
 // stays complete without the later ones: their work falls through to the next launch).
-int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now,
+int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now,
                     uint32_t stop_after /* kgpu_ctx_set_ablation; 0 = run everything */, void *stream,
                     void *event_after_first /* hipEvent_t recorded behind the first (dominant) launch, or null */,
-                    bool window_now = false /* the windowed kernel in front of the HBM-lattice one (plan.window_lds_bytes) */,
-                    bool tail_now = true /* false: no last-resort launch behind a chain that has a work list (the host reruns the batch if one was needed) */);
-int launch_tail_only(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int list_index, void *stream);  // the long-sentence kernel over work list `list_index` (whose length the host has put back), leaving list_index + 1
+                    bool window_now /* the windowed kernel behind the pools (plan.window_lds_bytes) */,
+                    bool tail_now /* false: nothing behind a chain that has a work list (the host launches what is missing if a sentence needed it) */);
+int launch_tail_only(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int list_index, bool window_was_in_chain, void *stream);
 int window_workgroups_per_cu(uint32_t lds_bytes);
 int launch_general_only(const DictView &d, const BatchArgs &a, void *stream);
 int launch_small_call(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, void *stream);  // pool kernel alone, one sentence per wavefront  // kgpu_lattice_dump: HBM-scratch kernel alone
 int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream);  // host_ctl: device pointer of the pinned result block
 LaunchPlan default_launch_plan(int device);
-int long_workgroups_per_cu(uint32_t lds_bytes);
 int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
 
 }  // namespace kgpu

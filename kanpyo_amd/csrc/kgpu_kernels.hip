@@ -18,15 +18,12 @@
 //   phase 5  backtrace (lattice.rs:144-153) + Node -> Token (tokenizer.rs:22-43)
 // Integer/indexing work only: no MFMA anywhere.
 //
-// This file holds the GENERAL kernel: every per-sentence array lives in a
-// bump-allocated HBM scratch slab, so any sentence length / lattice size works.
-// Two instantiations.  LDS_SWEEP = false: no LDS at all, every step of the Viterbi
-// chain is a global-memory round trip (the always-launched last resort; its
-// workgroups can start on a CU whose LDS is fully taken).  LDS_SWEEP = true: the
-// lattice is still built in HBM, but the sweep runs over blocks of up to 64
-// positions staged in LDS (bucket entries, word costs, gathered connection costs):
-// one global round trip per block instead of three per position, and a blocked
-// backtrace -- the long-document path (BASELINE cfg 5: 2048-char sentences).
+// This file holds the GENERAL kernel: every per-sentence array lives in a bump-allocated HBM scratch slab and every
+// step of the Viterbi chain is a global-memory round trip -- no LDS at all, so its workgroups start on a CU whose LDS is
+// fully taken, and any sentence length / lattice shape works.  It is the LAST RESORT of the launch chain (what the LDS-resident
+// pool kernel, kgpu_pool.hip, and the windowed kernel, kgpu_window.hip, cannot hold) and the kernel behind kgpu_lattice_dump: its
+// slabs ARE the lattice.  (Round 2-3 also instantiated it with an LDS-blocked sweep as "the long-sentence kernel"; the windowed kernel
+// took that place in round 4.)  Also here: scan / compaction kernels and the launch chain.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -72,24 +69,11 @@ __device__ __forceinline__ void wave_fence() {
 
 }  // namespace
 
-template <bool LDS_SWEEP>
-__global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a, WorkIO io, uint32_t lds_bytes,
-                                                          uint32_t stop_after /* ablation timing only */) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+__global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a, WorkIO io, uint32_t stop_after /* ablation timing only */) {
     const uint32_t lane = threadIdx.x;
     Slab sa{nullptr, 0}, sn{nullptr, 0};
     const int32_t base_root = d.da[1].base;
     uint64_t accW[7] = {0, 0, 0, 0, 0, 0, 0};  // work counters of this workgroup, flushed once at exit
-#ifdef KGPU_STEP_TIMING  // measurement build: s_memtime ticks of this kernel's phases and of the pieces of a sweep block
-    uint64_t gt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // decode+count, scan, emit, block set-up, targets+gather, chain, write-back, global steps, backtrace+tokens, blocks
-#define KGPU_GT(k, expr) do { const uint64_t t0_ = __builtin_amdgcn_s_memtime(); expr; gt[k] += __builtin_amdgcn_s_memtime() - t0_; } while (0)
-#define KGPU_GTICK(v) const uint64_t v = __builtin_amdgcn_s_memtime()
-#define KGPU_GADD(k, a_, b_) gt[k] += (b_) - (a_)
-#else
-#define KGPU_GT(k, expr) expr
-#define KGPU_GTICK(v)
-#define KGPU_GADD(k, a_, b_)
-#endif
 
     for (uint32_t iter = 0;; ++iter) {
         uint64_t s = 0;
@@ -98,7 +82,6 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         const uint64_t b0 = a.offsets[s];
         const uint32_t B = (uint32_t)(a.offsets[s + 1] - b0);
         const uint8_t *text = a.utf8 + b0;
-        KGPU_GTICK(g_t0);
 
         // ---- slab A: per-char arrays (C <= B) --------------------------------
         const uint64_t na = (uint64_t)B + 4;
@@ -119,89 +102,8 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         uint8_t *mnch = mcnt + na;             // [na][GMAXM] match length in chars
 
         // ---- phase 0: decode ------------------------------------------------
-        // The long-sentence kernel keeps the sentence's bytes in LDS while the lattice is built (when they take at most half of its
-        // LDS): every step of a double-array walk reads one text byte and then the node that byte selects -- two dependent loads; from
-        // LDS the first one costs an LDS access instead of a trip through the vector memory path.
-        uint32_t toff = 0;
         const bool ct = d.da2 != nullptr;  // character-level trie (kgpu_chartrie.cpp): the walks read character codes, not bytes; cp16[] then holds the codes
-        if constexpr (LDS_SWEEP) { const uint32_t tb = (B + 4 + 15) & ~15u; if (!ct && 2 * tb <= lds_bytes) toff = tb; }
         uint32_t C = 0, bad = 0, lensum = 0;
-        if constexpr (LDS_SWEEP) {
-            // 256 bytes a round, through LDS (in place when the text stays there, else a scratch block at its start): the continuation bytes are
-            // LDS reads, the next round's text is in flight while this one is decoded, and the round's four category loads are issued together
-            // (unconditional, clamped addresses: a load under a lane mask is waited for on the spot) -- one memory round trip per 256 bytes
-            // instead of up to five per 64 (this pass was the largest part of "decode + count", itself 28 % of a 325-character sentence).
-            uint32_t pf[5];
-            auto fetch = [&](uint32_t k0) {
-#pragma unroll
-                for (int u = 0; u < 5; ++u) {
-                    const uint32_t k = k0 + 64u * (uint32_t)u + (u < 4 ? lane : (lane & 3u));
-                    pf[u] = text[min(k, B - 1u)];
-                }
-            };
-            if (B) fetch(0);
-            for (uint32_t k0 = 0; k0 < B; k0 += 256) {
-                uint8_t *blk = lds + (toff ? k0 : 0u);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int u = 0; u < 4; ++u) blk[64 * u + lane] = (uint8_t)(k0 + 64u * (uint32_t)u + lane < B ? pf[u] : 0x80u);
-                if (lane < 3) blk[256 + lane] = (uint8_t)(k0 + 256u + lane < B ? pf[4] : 0x80u);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-                fetch(k0 + 256);
-                uint32_t ci[4], kk[4], cpx[4];
-                bool st[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t r = 64u * (uint32_t)u + lane, k = k0 + r;
-                    const uint32_t b = blk[r];
-                    const bool start = k < B && (b & 0xC0) != 0x80;
-                    const uint64_t m = __ballot(start);
-                    ci[u] = C + __popcll(m & ((1ull << lane) - 1));
-                    st[u] = start; kk[u] = k; cpx[u] = 0;
-                    if (start) {
-                        uint32_t l, cp;
-                        if (b < 0x80) { l = 1; cp = b; }
-                        else if (b >= 0xC2 && b <= 0xDF) { l = 2; cp = b & 0x1F; }
-                        else if ((b & 0xF0) == 0xE0) { l = 3; cp = b & 0x0F; }
-                        else if (b >= 0xF0 && b <= 0xF4) { l = 4; cp = b & 0x07; }
-                        else { l = 1; cp = 0; bad = 1; }
-                        if (k + l > B) { bad = 1; l = 1; }
-                        for (uint32_t j = 1; j < l; ++j) {
-                            const uint32_t bb = blk[r + j];
-                            if ((bb & 0xC0) != 0x80) bad = 1;
-                            cp = (cp << 6) | (bb & 0x3F);
-                        }
-                        if (l == 3 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) bad = 1;
-                        if (l == 4 && (cp < 0x10000 || cp > 0x10FFFF)) bad = 1;
-                        lensum += l;
-                        cpx[u] = cp;
-                    }
-                    C += __popcll(m);
-                }
-                uint32_t cv[4], cd[4];
-                if (ct) {   // category and code from the character's record; what the table cannot name (>= U+FFFF): the slow way
-                    CharRec rr[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) rr[u] = d.crec[cpx[u] < 0xFFFFu ? cpx[u] : 0u];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        cv[u] = rr[u].cat; cd[u] = rr[u].code;
-                        if (st[u] && cpx[u] >= 0xFFFFu) { cv[u] = d.cat[cpx[u] < d.cat_len ? cpx[u] : 0u]; cd[u] = d.n_nb ? ct_code_nonbmp(d, cpx[u]) : 0xFFFFu; }
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { cv[u] = d.cat[cpx[u] < d.cat_len ? cpx[u] : 0u]; cd[u] = cpx[u] < 0xFFFFu ? cpx[u] : 0xFFFFu; }  // char_category_def.rs:33-38: table[ch] if in range else table[0]
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (st[u]) {
-                        cbyte[ci[u]] = kk[u];
-                        cp16[ci[u]] = (uint16_t)cd[u];
-                        ccat[ci[u]] = (uint8_t)(bad ? 0u : cv[u]);
-                    }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-        } else
         for (uint32_t k0 = 0; k0 < B; k0 += 64) {
             uint32_t k = k0 + lane;
             uint32_t b = k < B ? text[k] : 0x80u;
@@ -239,29 +141,10 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             continue;
         }
         if (lane == 0) { cbyte[C] = B; if (ct) cp16[C] = 0xFFFFu; }
-        if constexpr (LDS_SWEEP) {
-            if (ct) {   // the codes into LDS (2 bytes per character, when they take at most half of it): every walk step reads one, then the node it selects
-                const uint32_t tc = (2 * (C + 1) + 15) & ~15u;
-                if (2 * tc <= lds_bytes) {
-                    toff = tc;
-                    __syncthreads();
-                    for (uint32_t e = lane; e <= C; e += 64) ((uint16_t *)lds)[e] = cp16[e];
-                }
-            }
-        }
-        // Per-end-position counters / fill cursors: in LDS when the sentence's C + 3 words fit (LDS atomics
-        // instead of one global round trip per node), else in the HBM slab.
-        uint32_t *cnt_e = boff, *fill_e = bfill;
-        bool lds_cursors = false;
-        if constexpr (LDS_SWEEP) {
-            if (toff + (uint64_t)(C + 3) * 4 > lds_bytes && (uint64_t)(C + 3) * 4 <= lds_bytes) toff = 0;  // not both: the cursors (LDS atomics per node) are worth more
-            lds_cursors = toff + (uint64_t)(C + 3) * 4 <= lds_bytes;
-            if (lds_cursors) { cnt_e = (uint32_t *)(lds + toff); fill_e = (uint32_t *)(lds + toff); }
-        }
-        const uint8_t *wtext = (toff && !ct) ? (const uint8_t *)lds : text;  // what the walks read (count phase, and the emit phase's re-walks)
-        const uint16_t *wcode = (toff && ct) ? (const uint16_t *)lds : cp16;  // ... with the character-level trie
-        auto code_at = [&](uint32_t j) -> uint32_t { return (uint32_t)wcode[min(j, C)]; };  // ([C]: none)
-        for (uint32_t e = lane; e < C + 3; e += 64) { cnt_e[e] = 0; if (!lds_cursors) bfill[e] = 0; }
+        uint32_t *cnt_e = boff, *fill_e = bfill;  // per-end-position counters / fill cursors (global atomics)
+        const uint8_t *wtext = text;
+        auto code_at = [&](uint32_t j) -> uint32_t { return (uint32_t)cp16[min(j, C)]; };  // ([C]: none)
+        for (uint32_t e = lane; e < C + 3; e += 64) { cnt_e[e] = 0; bfill[e] = 0; }
         __syncthreads();
 
         // ---- phase 1: count ----------------------------------------------------
@@ -303,7 +186,7 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             for (int x = 0; x < 2; ++x) { cpX[x] = actX[x] ? cp16[iX[x]] : 0xFFFFu; kbX[x] = actX[x] ? cbyte[iX[x]] : 0u; knX[x] = actX[x] ? cbyte[iX[x] + 1] : 0u; }
             if (ct) {
                 ct_walk2(d, actX[0], [&](uint32_t dep) { return code_at(iX[0] + dep); }, on_match(0), actX[1], [&](uint32_t dep) { return code_at(iX[1] + dep); }, on_match(1));
-                if (a.count_work) {  // the reference's byte steps (work counters)
+                if (a.count_work == 1u) {  // the reference's byte steps (work counters; not with KGPU_PROFILE_NO_T)
 #pragma unroll
                     for (int x = 0; x < 2; ++x) if (actX[x]) wT += da_walk(d, text, kbX[x], B, base_root, [](uint32_t, uint32_t, uint32_t) {});
                 }
@@ -343,15 +226,14 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
 
 #define KGPU_GSTOP(k) if (stop_after == (k)) { if (lane == 0) { a.status[s] = KGPU_SENT_TRUNCATED; a.tok_count[s] = 0; } continue; }
         KGPU_GSTOP(3)
-        KGPU_GTICK(g_t1); KGPU_GADD(0, g_t0, g_t1);
         // ---- phase 2: prefix sums ------------------------------------------------
         uint32_t ncarry = 1, bcarry = 0;  // node 0 is BOS
         for (uint32_t i0 = 0; i0 < C + 2; i0 += 64) {
             const uint32_t i = i0 + lane;
             const uint32_t v = i < C + 2 ? nb[i] : 0;
-            const uint32_t w = i < C + 2 ? (lds_cursors ? cnt_e[i] : ld_l2(&boff[i])) : 0;  // updated by LDS / L2 atomics
+            const uint32_t w = i < C + 2 ? ld_l2(&boff[i]) : 0;  // updated by L2 atomics
             const uint32_t vs = wave_incl_scan(v, lane), ws = wave_incl_scan(w, lane);
-            if (i < C + 2) { nb[i] = ncarry + vs - v; boff[i] = bcarry + ws - w; if (lds_cursors) cnt_e[i] = 0; /* becomes the fill cursor */ }
+            if (i < C + 2) { nb[i] = ncarry + vs - v; boff[i] = bcarry + ws - w; }
             ncarry += __shfl(vs, 63, 64);
             bcarry += __shfl(ws, 63, 64);
         }
@@ -368,7 +250,6 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         uint2 *nodeB = (uint2 *)(bucket + N);  // {start char, end char}
         uint32_t *pre = (uint32_t *)(nodeB + N);
 
-        KGPU_GTICK(g_t2); KGPU_GADD(1, g_t1, g_t2);
         // ---- phase 3: emit -----------------------------------------------------------
         for (uint32_t i = lane; i < C; i += 64) {
             uint32_t t = nb[i];
@@ -417,7 +298,6 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
         __syncthreads();
 
         KGPU_GSTOP(5)
-        KGPU_GTICK(g_t3); KGPU_GADD(2, g_t2, g_t3);
         // ---- phase 4: Viterbi sweep ---------------------------------------------------
         // one position through global memory (lattice.rs:116-142): lanes take targets, every lane
         // walks the whole predecessor bucket
@@ -472,234 +352,15 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             }
             __syncthreads();
         };
-        if constexpr (!LDS_SWEEP) {
-            for (uint32_t q = 0; q <= C; ++q) global_step(q);
-        } else {
-            // Blocks of up to 64 consecutive positions whose bucket entries, targets and (target,
-            // predecessor) pairs fit the LDS budget.  Per block: one round of coalesced loads, one
-            // parallel gather of the connection costs, then the serial chain at LDS latency.
-            uint32_t *posT0 = (uint32_t *)lds, *posP0 = posT0 + 64, *posP = posP0 + 64, *posEb = posP + 64;
-            const uint32_t cap = lds_bytes - 1040;  // 1024 B of position tables + 16 B of store sinks
-            for (uint32_t qa = 0; qa <= C;) {
-                KGPU_GTICK(g_b0);
-                const uint32_t ql = qa + lane;
-                const bool in = ql <= C;
-                const uint32_t t0g = in ? nb[ql] : 0, t1g = in ? nb[ql + 1] : 0;
-                const uint32_t p0g = in ? boff[ql] : 0, p1g = in ? boff[ql + 1] : 0;
-                const uint32_t T = t1g - t0g, P = p1g - p0g;
-                const uint64_t pairs64 = (uint64_t)T * P;
-                const uint32_t pairs = pairs64 > 0xFFFFFFu ? 0xFFFFFFu : (uint32_t)pairs64;
-                // LDS per position: bucket entries {dp, node, right} 10 B, targets {cost|slot, dp, pre} 12 B, pairs 2 B
-                const uint32_t need = 10 * P + 12 * T + 2 * pairs + 8;
-                const uint32_t cneed = wave_incl_scan(min(need, 0x1000000u), lane);
-                const uint32_t cP = wave_incl_scan(min(P, 0x100000u), lane), cT = wave_incl_scan(min(T, 0x100000u), lane);
-                const uint32_t cE = wave_incl_scan(pairs, lane);
-                const bool fit = in && cneed <= cap && cP < 0xFFFFu && cT < 0xFFFFu && cE < 0x1FFFFu;
-                const uint32_t nq = (uint32_t)__popcll(__ballot(fit));  // a prefix of the lanes: every sum is monotone
-                if (nq == 0) { KGPU_GT(7, global_step(qa)); ++qa; continue; }       // one position too large for the budget
-                const uint32_t tA = bcast32(t0g), pA = bcast32(p0g);
-                const uint32_t nt = (uint32_t)__shfl((int)cT, (int)nq - 1, 64), nbk = (uint32_t)__shfl((int)cP, (int)nq - 1, 64);
-                const uint32_t np = (uint32_t)__shfl((int)cE, (int)nq - 1, 64);
-                wE += (lane < nq) ? pairs : 0;  // summed over lanes at the end
-                uint32_t off = 1040;
-                uint32_t *sink = (uint32_t *)(lds + 1024);                  // [0] dp, [1] pre, [2] target dp: stores of absent lanes
-                uint32_t *dpL = (uint32_t *)(lds + off);  off += 4 * nbk;   // dp of the bucket entries ending in the block
-                uint32_t *ndL = (uint32_t *)(lds + off);  off += 4 * nbk;   // their node index (tie-break, pre)
-                uint32_t *csL = (uint32_t *)(lds + off);  off += 4 * nt;    // targets: word cost | local bucket slot << 16 (0xFFFF: outside)
-                uint32_t *dpT = (uint32_t *)(lds + off);  off += 4 * nt;    // targets: dp (written back for the outside slots)
-                uint32_t *preL = (uint32_t *)(lds + off); off += 4 * nt;    // targets: best predecessor (written back after the block:
-                                                                            // no global store, hence no vmcnt wait, inside the chain)
-                int16_t *prL = (int16_t *)(lds + off);    off += 2 * np;    // connection cost of pair (t, j) at eb(q) + ti*P + j
-                uint16_t *rtL = (uint16_t *)(lds + off);                    // right id of the bucket entries (gather only)
-                if (lane < nq) { posT0[lane] = t0g - tA; posP0[lane] = p0g - pA; posP[lane] = P; posEb[lane] = cE - pairs; }
-                for (uint32_t i = lane; i < nbk; i += 64) {
-                    const uint4 e = bucket[pA + i];
-                    dpL[i] = e.x; ndL[i] = e.z; rtL[i] = (uint16_t)e.y;
-                }
-                wave_fence();
-                KGPU_GTICK(g_b1); KGPU_GADD(3, g_b0, g_b1);
-                // targets + gather (lane = target, 4 gathers in flight; issuing the node records and sixteen gathers of four
-                // targets at once was measured and is slower: cfg 3 11.6 -> 10.1 M sentences/s)
-                for (uint32_t t = lane; t < nt; t += 64) {
-                    const uint4 na_ = nodeA[tA + t];
-                    const uint32_t z = na_.z;
-                    const uint32_t loc = (z != NONE && z >= pA && z - pA < nbk) ? z - pA : 0xFFFFu;
-                    csL[t] = (uint32_t)(uint16_t)(int16_t)(int32_t)na_.y | (loc << 16);
-                    const uint32_t q = nodeB[tA + t].x - qa;
-                    const uint32_t Pq = posP[q], p0 = posP0[q], base = posEb[q] + (t - posT0[q]) * Pq;
-                    const int16_t *col = d.conn + (size_t)d.conn_rows * (na_.x & 0xFFFFu);
-                    for (uint32_t j = 0; j < Pq; j += 4) {  // the last group of a row repeats its final entry: ceil(P / 4) dependent rounds
-                        const uint32_t j1 = min(j + 1, Pq - 1), j2 = min(j + 2, Pq - 1), j3 = min(j + 3, Pq - 1);
-                        const int16_t c0 = col[rtL[p0 + j]], c1 = col[rtL[p0 + j1]], c2 = col[rtL[p0 + j2]], c3 = col[rtL[p0 + j3]];
-                        prL[base + j] = c0; prL[base + j1] = c1; prL[base + j2] = c2; prL[base + j3] = c3;
-                    }
-                }
-                wave_fence();
-                KGPU_GTICK(g_b2); KGPU_GADD(4, g_b1, g_b2);
-                // The chain (same step as kgpu_pool.hip's, see there for the measurements behind it): descriptors in lanes,
-                // d0 = first target | first bucket slot << 16, d1 = pair offset (17 bits) | T (7) << 17 | P (6) << 24, bit 31 =
-                // not the straight-line shape.  ONE straight-line body for P <= 16 (eight lanes per target, lane j takes
-                // predecessors j and j + 8, eight targets per pass), a second instantiation for P <= 32; loads unconditional
-                // and unclamped (past the arrays: other LDS of this workgroup or zero), absent candidates deselected by a
-                // total no real one reaches; no exec-masked region: every lane of a group stores the group's result, absent
-                // groups and nodes that end beyond the block store to a sink.
-                const bool fastq = lane < nq && P <= 32 && T - 1u < 127u;
-                const uint32_t d0 = (t0g - tA) | ((p0g - pA) << 16);
-                const uint32_t d1 = (cE - pairs) | (fastq ? (T << 17) | (P << 24) : 1u << 31);
-                for (uint32_t r = 0; r < nq; ++r) {
-                    const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)r);
-                    const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)r);
-                    const uint32_t t0 = D0 & 0xFFFFu, p0 = D0 >> 16, eb = D1 & 0x1FFFFu;
-                    if (!(D1 >> 31)) {
-                        const uint32_t Tq = (D1 >> 17) & 127u, Pq = (D1 >> 24) & 63u;
-                        auto pass = [&](auto LGc, uint32_t tb) {
-                            constexpr uint32_t LG = decltype(LGc)::value, G = 1u << LG;
-                            const uint32_t j = lane & (G - 1u), ti = tb + (lane >> LG);
-                            const bool tv = ti < Tq, j0v = j < Pq, j1v = j + G < Pq;
-                            const uint32_t cs = csL[t0 + ti];
-                            const uint32_t dp0 = dpL[p0 + j], dp1 = dpL[p0 + j + G], nd0 = ndL[p0 + j], nd1 = ndL[p0 + j + G];
-                            const int16_t *mrow = prL + eb + __umul24(ti, Pq) + j;
-                            const int32_t pc0 = mrow[0], pc1 = mrow[G];
-                            __builtin_amdgcn_sched_barrier(0);  // the seven reads stay one round trip
-                            constexpr int32_t ABSENT = 0x7FFEFFFF;  // above every real total (<= INF + 32767), no overflow with a word cost added
-                            const int32_t v0 = (tv && j0v) ? (int32_t)dp0 + pc0 : ABSENT;
-                            const int32_t v1 = (tv && j1v) ? (int32_t)dp1 + pc1 : ABSENT;
-                            const int32_t vmin = gmin_i32(min(v0, v1), LG);   // LG is a constant here: the steps fold
-                            const uint32_t nmin = gmin_u32(min(v0 == vmin ? nd0 : 0xFFFFFFFFu, v1 == vmin ? nd1 : 0xFFFFFFFFu), LG);
-                            const int32_t tot = vmin + (int32_t)(int16_t)cs;
-                            const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
-                            const uint32_t dpn = (uint32_t)(ok ? tot : INF), sl = cs >> 16;
-                            *(tv ? &preL[t0 + ti] : &sink[1]) = ok ? nmin : NONE;
-                            *(tv ? &dpT[t0 + ti] : &sink[2]) = dpn;
-                            *((tv && sl != 0xFFFFu) ? &dpL[sl] : &sink[0]) = dpn;
-                        };
-                        auto pass1 = [&](uint32_t tb) {  // P <= 8 (most positions): one candidate per lane, as in kgpu_pool.hip
-                            const uint32_t j = lane & 7u, ti = tb + (lane >> 3);
-                            const bool tv = ti < Tq, j0v = j < Pq;
-                            const uint32_t cs = csL[t0 + ti];
-                            const uint32_t dp0 = dpL[p0 + j], nd0 = ndL[p0 + j];
-                            const int32_t pc0 = prL[eb + __umul24(ti, Pq) + j];
-                            __builtin_amdgcn_sched_barrier(0);
-                            const int32_t v0 = (tv && j0v) ? (int32_t)dp0 + pc0 : 0x7FFEFFFF;
-                            const int32_t vmin = gmin_i32(v0, 3);
-                            const uint32_t nmin = gmin_u32(v0 == vmin ? nd0 : 0xFFFFFFFFu, 3);
-                            const int32_t tot = vmin + (int32_t)(int16_t)cs;
-                            const bool ok = tot < INF;
-                            const uint32_t dpn = (uint32_t)(ok ? tot : INF), sl = cs >> 16;
-                            *(tv ? &preL[t0 + ti] : &sink[1]) = ok ? nmin : NONE;
-                            *(tv ? &dpT[t0 + ti] : &sink[2]) = dpn;
-                            *((tv && sl != 0xFFFFu) ? &dpL[sl] : &sink[0]) = dpn;
-                        };
-                        if (Pq <= 8) {
-                            pass1(0u);
-                            if (Tq > 8) for (uint32_t tb = 8; tb < Tq; tb += 8) pass1(tb);
-                        } else if (Pq <= 16) {
-                            pass(std::integral_constant<uint32_t, 3>{}, 0u);
-                            if (Tq > 8) for (uint32_t tb = 8; tb < Tq; tb += 8) pass(std::integral_constant<uint32_t, 3>{}, tb);
-                        } else {
-                            for (uint32_t tb = 0; tb < Tq; tb += 4) pass(std::integral_constant<uint32_t, 4>{}, tb);
-                        }
-                        __builtin_amdgcn_wave_barrier();  // no fence: one wavefront's DS instructions execute in issue order
-                        continue;
-                    }
-                    const uint32_t Tq = (uint32_t)__builtin_amdgcn_readlane((int)T, (int)r);
-                    const uint32_t Pq = (uint32_t)__builtin_amdgcn_readlane((int)P, (int)r);
-                    if (Pq == 0) {  // nothing ends here: every target stays at INF with no predecessor
-                        for (uint32_t t = t0 + lane; t < t0 + Tq; t += 64) {
-                            preL[t] = NONE;
-                            dpT[t] = (uint32_t)INF;
-                            const uint32_t sl = csL[t] >> 16;
-                            if (sl != 0xFFFFu) dpL[sl] = (uint32_t)INF;
-                        }
-                    } else if (Tq) {
-                        uint32_t lg = Pq > 1 ? 32 - __clz(Pq - 1) : 0;  // lanes per target: 2^lg >= min(P, 64)
-                        if (lg > 6) lg = 6;
-                        const uint32_t j = lane & ((1u << lg) - 1), tl = lane >> lg, TG = 64u >> lg;
-                        for (uint32_t tbase = 0; tbase < Tq; tbase += TG) {
-                            const uint32_t ti = tbase + tl;
-                            const bool tv = ti < Tq;
-                            const uint32_t tt = t0 + (tv ? ti : 0);
-                            const uint32_t cs = csL[tt];
-                            // strict-'<' first minimum (lattice.rs:125-139): smallest total, then smallest node index
-                            int32_t best = 0x7FFFFFFF;
-                            uint32_t bnode = 0xFFFFFFFFu;
-                            for (uint32_t jc = 0; jc < Pq; jc += 64) {  // one pass unless P > 64
-                                const uint32_t jj = jc + j;
-                                int32_t v = 0x7FFFFFFF;
-                                uint32_t nd = 0xFFFFFFFFu;
-                                if (tv && jj < Pq) {
-                                    v = (int32_t)dpL[p0 + jj] + (int32_t)prL[eb + ti * Pq + jj];
-                                    nd = ndL[p0 + jj];
-                                }
-                                const int32_t vmin = gmin_i32(v, lg);
-                                const uint32_t nmin = gmin_u32(v == vmin ? nd : 0xFFFFFFFFu, lg);
-                                if (vmin < best || (vmin == best && nmin < bnode)) { best = vmin; bnode = nmin; }
-                            }
-                            if (tv && j == 0) {
-                                const int32_t tot = best + (int32_t)(int16_t)cs;
-                                const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
-                                const uint32_t dpn = (uint32_t)(ok ? tot : INF);
-                                preL[tt] = ok ? bnode : NONE;
-                                dpT[tt] = dpn;
-                                const uint32_t sl = cs >> 16;
-                                if (sl != 0xFFFFu) dpL[sl] = dpn;
-                            }
-                        }
-                    }
-                    wave_fence();
-                }
-                wave_fence();
-                KGPU_GTICK(g_b3); KGPU_GADD(5, g_b2, g_b3);
-                // dp of the nodes that end beyond the block goes back to their HBM bucket entries
-                for (uint32_t t = lane; t < nt; t += 64) {
-                    pre[tA + t] = preL[t];
-                    if ((csL[t] >> 16) == 0xFFFFu) {
-                        const uint32_t z = nodeA[tA + t].z;
-                        if (z != NONE) bucket[z].x = dpT[t];
-                    }
-                }
-                __syncthreads();  // single wavefront: a fence that also drains the global stores before the next block reads
-                KGPU_GTICK(g_b4); KGPU_GADD(6, g_b3, g_b4);
-#ifdef KGPU_STEP_TIMING
-                gt[9] += 1;
-#endif
-                qa += nq;
-            }
-            wE = wave_sum(wE);
-        }
+        for (uint32_t q = 0; q <= C; ++q) global_step(q);
+        wE = wave_sum(wE);
 
         KGPU_GSTOP(7)
-        KGPU_GTICK(g_t4);
         // ---- phase 5: backtrace + tokens -----------------------------------------------
         uint32_t K = 0;
-        if constexpr (!LDS_SWEEP) {
-            if (lane == 0) {
-                uint32_t pos = N - 1, pr;
-                while ((pr = pre[pos]) != NONE && K <= C) { path[K++] = pos; pos = pr; }  // K <= C + 1 always; bound the walk anyway
-            }
-        } else {
-            // blocked: a predecessor always has a smaller node index, so the chase runs through windows of
-            // pre[] staged in LDS (one coalesced load per window instead of one global round trip per token)
-            uint32_t *win = (uint32_t *)lds;
-            const uint32_t Wn = lds_bytes / 4;
-            uint32_t pos = N - 1;
-            for (bool done = false; !done;) {
-                const uint32_t wlo = pos >= Wn - 1 ? pos - (Wn - 1) : 0;
-                for (uint32_t i = wlo + lane; i <= pos; i += 64) win[i - wlo] = pre[i];
-                wave_fence();
-                uint32_t npos = pos, nK = K, fin = 0;
-                if (lane == 0) {
-                    for (;;) {
-                        const uint32_t pr = win[npos - wlo];
-                        if (pr == NONE || nK > C) { fin = 1; break; }
-                        path[nK++] = npos;
-                        npos = pr;
-                        if (npos < wlo) break;
-                    }
-                }
-                pos = bcast32(npos); K = bcast32(nK); done = bcast32(fin) != 0;
-                wave_fence();
-            }
+        if (lane == 0) {
+            uint32_t pos = N - 1, pr;
+            while ((pr = pre[pos]) != NONE && K <= C) { path[K++] = pos; pos = pr; }  // K <= C + 1 always; bound the walk anyway
         }
         K = bcast32(K);
         // staging slot of the sentence: K <= C + 1 <= B + 1 tokens always fit at b0 + s
@@ -724,7 +385,6 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             }
         }
         if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; }
-        KGPU_GTICK(g_t5); KGPU_GADD(8, g_t4, g_t5);
         if (a.dump_lattice && lane == 0) {  // kgpu_lattice_dump: the host reads the lattice straight out of the two slabs
             a.ctl->dump[0] = (unsigned long long)(sa.ptr - a.arena); a.ctl->dump[1] = (unsigned long long)(sn.ptr - a.arena);
             a.ctl->dump[2] = B; a.ctl->dump[3] = C; a.ctl->dump[4] = N; a.ctl->dump[5] = 1;
@@ -737,13 +397,6 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
     }
     if (a.count_work && lane == 0)
         for (int k = 0; k < 7; ++k) atomicAdd(&a.ctl->work[k], (unsigned long long)accW[k]);
-#ifdef KGPU_STEP_TIMING
-    if (LDS_SWEEP && a.stat_slots) {  // the workgroup's own slot (summed on the host): words 16.. = Control::phase
-        uint64_t v = 0;
-        for (int k = 0; k < 10; ++k) if (lane == 16u + k) v = gt[k];
-        if (lane >= 16 && lane < 26) a.stat_slots[((uint64_t)blockIdx.x & (STAT_SLOTS - 1)) * STAT_WORDS + lane] += v;
-    }
-#endif
 }
 
 // Exclusive scan of per-sentence token counts -> tok_offsets (single workgroup;
@@ -909,11 +562,26 @@ int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const WorkIO &io
                          uint32_t max_pages, int n_workgroups, uint32_t stop_after, void *stream);  // kgpu_pool.hip
 int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
 
-// Launch chain: pool kernel(s), then the general (HBM scratch) kernel.  Every launch is a
-// persistent grid over its work list (the first one: the identity over [0, n)).
-int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, uint32_t min_bytes, int n_workgroups, void *stream);  // kgpu_window.hip
+// Launch chain: the LDS page-pool kernel(s) -> the windowed kernel (whatever the pools route away: long sentences, lattices too dense for a
+// pool) -> the general kernel (what the windowed kernel hands back: the last resort).  Every launch is a persistent grid over its work list
+// (the first one: the identity over [0, n)) and pushes what it does not serve onto the next launch's list.
+int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, void *stream);  // kgpu_window.hip
 
-int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, bool long_now, uint32_t stop_after, void *stream,
+static int launch_window_over(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, const uint32_t *in_list, const unsigned int *in_count, int li, void *stream) {
+    WorkIO io{in_list, in_count, a.ovf[li], &a.ctl->ovf_count[li], nullptr};
+    uint64_t wg = plan.window_workgroups;
+    if (!in_list && a.n < wg) wg = a.n;
+    return launch_tokenize_window(d, a, io, plan.window_lds_bytes, (int)(wg ? wg : 1), stream);
+}
+static int launch_general_over(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, const uint32_t *in_list, const unsigned int *in_count, uint32_t stop_after, void *stream) {
+    WorkIO io{in_list, in_count, nullptr, nullptr, nullptr};
+    uint64_t wg = plan.general_workgroups;
+    if (!in_list && a.n < wg) wg = a.n;
+    hipLaunchKernelGGL(k_tokenize_general, dim3((unsigned)(wg ? wg : 1)), dim3(64), 0, (hipStream_t)stream, d, a, io, stop_after);
+    return (int)hipGetLastError();
+}
+
+int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, uint32_t stop_after, void *stream,
                     void *event_after_first, bool window_now, bool tail_now) {
     Control *ctl = a.ctl;
     const uint32_t *in_list = nullptr;
@@ -932,60 +600,30 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
     }
     if (event_after_first && (plan.n_pools == 0 || n_pools_now == 0) && hipEventRecord((hipEvent_t)event_after_first, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
     if (window_now && plan.window_lds_bytes && stop_after == 0) {
-        // windowed lattice in LDS for the very long sentences (WINDOW_MIN_BYTES and more); the shorter ones of its list, and what it cannot
-        // hold, go on to the next launch (the HBM-lattice kernel, or the last resort)
-        WorkIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], nullptr};
-        uint64_t wg = plan.window_workgroups;
-        if (!in_list && a.n < wg) wg = a.n;
-        int e = launch_tokenize_window(d, a, io, plan.window_lds_bytes, in_list ? WINDOW_MIN_BYTES : 0u /* no pool kernel in front: everything is its to serve */,
-                                       (int)(wg ? wg : 1), stream);
+        int e = launch_window_over(d, a, plan, in_list, in_count, li, stream);
         if (e) return e;
         in_list = a.ovf[li];
         in_count = &ctl->ovf_count[li];
         ++li;
     }
-    if (long_now && plan.long_lds_bytes) {  // HBM lattice + LDS-blocked sweep; takes its whole list, leaves none
-        WorkIO io{in_list, in_count, a.ovf[li], &ctl->ovf_count[li], nullptr};
-        uint64_t wg = plan.long_workgroups;
-        if (!in_list && a.n < wg) wg = a.n;
-        if (plan.long_lds_bytes > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_general<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.long_lds_bytes);
-            if (e != hipSuccess) return (int)e;
-        }
-        hipLaunchKernelGGL(k_tokenize_general<true>, dim3((unsigned)(wg ? wg : 1)), dim3(64), plan.long_lds_bytes, (hipStream_t)stream, d, a, io,
-                           plan.long_lds_bytes, stop_after);
-        // it serves every sentence of its list (scratch exhaustion is reported through the control block and retried by
-        // the host): a last-resort launch behind it would find nothing, and on a chip full of long-running wavefronts its
-        // few hundred empty workgroups still take a long while to get through (290 us per batch on cfg 3, a fifth of the chain)
-        return (int)hipGetLastError();
-    }
-    // No recent batch left a sentence for the tail of the chain: it is left out (an empty launch still costs its 5.5 us on the stream, 4 % of a
-    // cfg 2 batch's chain); the host finds a sentence that needed it in the last list's count and runs the batch again with the tail.
+    // No recent batch left a sentence for the rest of the chain: it is left out (an empty launch still costs its 5.5 us on the stream, 4 % of a
+    // cfg 2 batch's chain -- and far more behind a chip full of long-running wavefronts); the host finds a sentence that needed it in the last
+    // list's count and launches what is missing over that list (launch_tail_only).
     if (!tail_now && in_list) return (int)hipGetLastError();
-    WorkIO io{in_list, in_count, nullptr, nullptr, nullptr};
-    uint64_t wg = plan.general_workgroups;
-    if (!in_list && a.n < wg) wg = a.n;
-    hipLaunchKernelGGL(k_tokenize_general<false>, dim3((unsigned)(wg ? wg : 1)), dim3(64), 0, (hipStream_t)stream, d, a, io, 0u, stop_after);
-    return (int)hipGetLastError();
+    return launch_general_over(d, a, plan, in_list, in_count, stop_after, stream);
 }
 
-// The tail of a chain that was launched without it: the HBM-lattice kernel over work list `li` (kgpu_api.cpp: enqueue_tail).
-int launch_tail_only(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int li, void *stream) {
+// What a chain that ended on work list `li` left out (kgpu_api.cpp: enqueue_tail): the windowed kernel over that list unless it was in the chain,
+// then the general kernel over what is left.
+int launch_tail_only(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int li, bool window_was_in_chain, void *stream) {
     Control *ctl = a.ctl;
     if (li < 0 || li > 2) return (int)hipErrorInvalidValue;
-    if (plan.long_lds_bytes) {
-        WorkIO io{a.ovf[li], &ctl->ovf_count[li], a.ovf[li + 1], &ctl->ovf_count[li + 1], nullptr};
-        if (plan.long_lds_bytes > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_general<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.long_lds_bytes);
-            if (e != hipSuccess) return (int)e;
-        }
-        hipLaunchKernelGGL(k_tokenize_general<true>, dim3((unsigned)(plan.long_workgroups ? plan.long_workgroups : 1)), dim3(64), plan.long_lds_bytes, (hipStream_t)stream, d, a, io,
-                           plan.long_lds_bytes, 0u);
-    } else {
-        WorkIO io{a.ovf[li], &ctl->ovf_count[li], nullptr, nullptr, nullptr};
-        hipLaunchKernelGGL(k_tokenize_general<false>, dim3((unsigned)(plan.general_workgroups ? plan.general_workgroups : 1)), dim3(64), 0, (hipStream_t)stream, d, a, io, 0u, 0u);
+    if (!window_was_in_chain && plan.window_lds_bytes) {
+        int e = launch_window_over(d, a, plan, a.ovf[li], &ctl->ovf_count[li], li + 1, stream);
+        if (e) return e;
+        ++li;
     }
-    return (int)hipGetLastError();
+    return launch_general_over(d, a, plan, a.ovf[li], &ctl->ovf_count[li], 0u, stream);
 }
 
 int launch_small_call(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, void *stream) {
@@ -997,7 +635,7 @@ int launch_small_call(const DictView &d, const BatchArgs &a, const LaunchPlan &p
 
 int launch_general_only(const DictView &d, const BatchArgs &a, void *stream) {
     WorkIO io{nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(k_tokenize_general<false>, dim3(1), dim3(64), 0, (hipStream_t)stream, d, a, io, 0u, 0u);
+    hipLaunchKernelGGL(k_tokenize_general, dim3(1), dim3(64), 0, (hipStream_t)stream, d, a, io, 0u);
     return (int)hipGetLastError();
 }
 
@@ -1026,28 +664,12 @@ int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream) {
     return (int)hipGetLastError();
 }
 
-int long_workgroups_per_cu(uint32_t lds_bytes) {  // resident workgroups of the long-sentence kernel per CU at this LDS size
-    if (lds_bytes > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)k_tokenize_general<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return 0;
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_general<true>, 64, (size_t)lds_bytes) != hipSuccess) return 0;
-    return n;
-}
-
 LaunchPlan default_launch_plan(int device) {
     hipDeviceProp_t p;
     int cus = 256;
     if (hipGetDeviceProperties(&p, device) == hipSuccess) cus = p.multiProcessorCount;
     LaunchPlan t{};
     t.general_workgroups = cus * 2;  // the last resort is rarely needed: few workgroups, so that an empty launch drains quickly on a busy chip
-    // long-sentence kernel (HBM lattice, LDS-blocked sweep): KGPU_LONG="<KiB>" per single-wavefront workgroup, "0" = off
-    {
-        const char *e = getenv("KGPU_LONG");
-        int kib = e ? atoi(e) : 10;   // 10 KB: 16 workgroups per CU (cfg 3 in batches of 16384: 16.4-17.2 M sentences/s; 12 KB: 15.7-16.1; 8 KB: 16.9 but
-        if (kib < 0 || kib > 160) kib = 10;  // cfg 5's per-position cursors no longer fit: 0.43 instead of 0.83 M documents/s; 16 KB: 14.0)
-        t.long_lds_bytes = (uint32_t)kib * 1024;
-        t.long_workgroups = kib ? cus * (160 / kib) : 0;
-    }
     // Default: four 40 KB pools per CU with 4 wavefronts each (16 sentences in flight per CU, any mix of
     // sizes).  A workgroup holds its LDS until its last wavefront is through, and the next launch's workgroups
     // start only then: four-wavefront workgroups drain sooner at the tail of a 4096-sentence batch than eight-
@@ -1088,7 +710,7 @@ LaunchPlan default_launch_plan(int device) {
             if (*q == ',') ++q;
         }
     }
-    // windowed long-sentence kernel: KGPU_WINDOW="<KiB>" of LDS per single-wavefront workgroup, "0" = off (the HBM-lattice kernel serves every long sentence)
+    // windowed kernel (everything the pools route away): KGPU_WINDOW="<KiB>" of LDS per single-wavefront workgroup, "0" = off (the general kernel then serves it all)
     {
         const char *e = getenv("KGPU_WINDOW");
         int kib = e ? atoi(e) : 12;   // 12 KB: 13 workgroups per CU (cfg 5: 1.08 M documents/s; 16 KB: 0.76; 10 KB: windows outgrow the LDS too often)

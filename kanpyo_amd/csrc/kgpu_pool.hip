@@ -227,7 +227,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         const uint64_t b0 = a.offsets[s];
         const uint64_t Bl = a.offsets[s + 1] - b0;
         const uint32_t pool_cap = page * POOL_PAGES;
-        if (Bl >= WINDOW_MIN_BYTES && lane == 0) atomicAdd(&a.ctl->very_long, 1u);  // (always beyond the routing limits below: max_pages <= 64 pages of <= 2.5 KB... of lattice, not text)
         if (Bl + 64 > pool_cap || Bl > 0xFFF0) { defer_s(s); continue; }
         const uint32_t B = (uint32_t)Bl;
         const uint8_t *gtext = a.utf8 + b0;
@@ -385,7 +384,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                     if (i + 1 < C) ncat = ccat[i + 1];
                     if (active) {
                         ct_walk(d, p0, bp0, lf0, [&](uint32_t dep) -> uint32_t { return i + dep < C ? (uint32_t)cp16[i + dep] : 0xFFFFu; }, on_match);
-                        if constexpr (PROF) wT += da_walk_first(d, text, cpi, cbyte[i], cbyte[i + 1], B, base_root, [](uint32_t, uint32_t, uint32_t) {});  // the reference's byte steps (work counters)
+                        if constexpr (PROF) if (a.count_work == 1u) wT += da_walk_first(d, text, cpi, cbyte[i], cbyte[i + 1], B, base_root, [](uint32_t, uint32_t, uint32_t) {});  // the reference's byte steps (work counters)
                         mcnt[i] = (uint8_t)(m < MAXM ? m : MAXM);
                     }
                 } else {

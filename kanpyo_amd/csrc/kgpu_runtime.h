@@ -78,8 +78,8 @@ struct kgpu_dict {
     std::atomic<int> big_pool_batches{0};
     // Same for the long-sentence kernel (its workgroups hold 32 KB of LDS each): issued while recent
     // batches still had sentences left after the pools.
-    std::atomic<int> window_batches{64};  // same for the windowed kernel: armed while recent batches held sentences of WINDOW_MIN_BYTES or more (Control::very_long)
-    std::atomic<int> long_batches{64};  // starts armed: a corpus of long sentences does not spend its first batches in the last-resort kernel (3.8 ms per batch on cfg 3)
+    std::atomic<int> window_batches{64};  // the windowed kernel: in the chain while recent batches left the pools sentences (starts armed)
+    std::atomic<int> tail_batches{0};     // the general kernel behind it: while recent batches left the windowed kernel (or, without one, the pools) sentences
     // Streams handed round-robin to contexts created without one.  HIP multiplexes streams onto three
     // hardware queues: a 4th stream queues behind the 1st and unbalances them (measured -25 %), so any
     // number of contexts shares three streams; each context waits on its own completion event.
@@ -101,13 +101,14 @@ struct kgpu_ctx {
     bool ctl_dirty = true;     // d_ctl must be zeroed by the host (first launch, or after a failed enqueue)
     uint32_t launch_seq = 0;
     int last_pools = 0;        // pool launches issued for the pending batch
-    bool last_long = false;    // ... and whether the long-sentence kernel was
     bool last_window = false;  // ... and whether the windowed kernel was
-    bool force_legacy_long = false;  // the pending batch is a rerun: the windowed kernel handed a sentence back
+    bool no_window = false;    // the pending batch is a rerun without the windowed kernel (it had flagged Control::window_fail)
     bool last_tail = true;     // ... whether the last-resort launch closed the chain (left out while no recent batch needed the tail)
     bool tail_pass = false;    // the pending launches are the tail of the batch's chain alone (it had been left out and a sentence needed it)
     Control tail_saved{};      // ... what the first pass had published
     unsigned tail_count = 0;   // ... the length of the work list the tail serves (source of an asynchronous copy: lives here)
+    int tail_li = 0;           // ... that list's index
+    bool tail_had_window = false;  // ... whether the first pass had the windowed kernel in its chain
     uint32_t event_every = 1;  // KGPU_PROFILE_SAMPLED: HIP events on every 4th launch only
     DevBuf arena, stage, tok_count;
     // host-buffer path staging
@@ -127,6 +128,7 @@ struct kgpu_ctx {
     // profiling
     bool profiling = false;   // KGPU_PROFILE_EVENTS
     bool count_work = false;  // KGPU_PROFILE_WORK
+    bool count_no_t = false;  // KGPU_PROFILE_NO_T
     uint32_t stop_after = 0;  // kgpu_ctx_set_ablation: measurement mode, 0 = off
     kgpu_work work{};
     uint64_t phase[10] = {0};

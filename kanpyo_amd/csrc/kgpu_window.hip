@@ -12,16 +12,16 @@
 //     characters ahead (src/lattice.rs:66-84) -- go to a FIFO in HBM: their end positions never decrease, so a window takes
 //     what it needs from the head.  A position whose bucket is mostly such entries (the end of a 1024-character run: thousands)
 //     is relaxed by streaming them from the FIFO, 64 per step.
-// The HBM-lattice kernel (k_tokenize_general<true>, kgpu_kernels.hip) keeps every per-character and per-node array in HBM
-// (44 bytes per node, ~70 per byte, read back several times); LDS-resident lattices (kgpu_pool.hip) do not scale to long
-// sentences (LDS x time grows with the square of the length: DESIGN.md section 8).  This kernel's LDS is independent of the
-// length and its HBM traffic is one write per node.
+// LDS-resident lattices (kgpu_pool.hip) do not scale to long sentences (LDS x time grows with the square of the length: DESIGN.md
+// section 8); this kernel's LDS is independent of the length and its HBM traffic is one write per node.  It serves everything the pool
+// kernel routes away -- from ~150 characters up to any length.  (Rounds 2-3 had a second long-sentence kernel that kept the whole lattice in
+// HBM and staged blocks of it in LDS for the sweep: 44 bytes per node, ~70 per byte, read back several times.  On 190-512-character
+// sentences the two were level, on 2048-character documents this one is 1.6x faster: round 4 removed the other.)
 //
-// What it cannot hold (more than 8 dictionary prefixes at one position, a window whose lattice outgrows the LDS budget even four
+// What it cannot hold (more than 8 + 48 dictionary prefixes in a window's overflow area, a window whose lattice outgrows the LDS budget even four
 // positions long, a FIFO-order violation by a dictionary word longer than a window, node indices beyond the 16-bit window of the tie-break)
-// it pushes onto the next launch's work list (the HBM-lattice kernel, or the last resort), like the sentences of its list that are shorter
-// than `min_bytes`: the HBM-lattice kernel serves those better.  Without a list to hand on to (not in the chain as built) it
-// flags Control::window_fail and the host reruns the batch.
+// it pushes onto the next launch's work list: the general kernel (kgpu_kernels.hip), the last resort.  Without a list to hand on to it
+// flags Control::window_fail and the host reruns the batch through the general kernel.
 #include <type_traits>
 
 #include "kgpu_device.h"
@@ -39,7 +39,8 @@ constexpr uint32_t WIN = KGPU_WIN;         // start positions per window
 static_assert(WIN >= 8 && WIN <= 63, "lane = position, and lane WIN holds the totals of the scans");
 constexpr uint32_t REL = 2 * WIN + 1;      // bucket positions a window holds: relative ends 0 .. 2 WIN
 constexpr uint32_t NEARLEN = WIN;           // a node up to this many characters long keeps its bucket entry in LDS (relative end <= 2 WIN - 1); longer ones go to the FIFO
-constexpr uint32_t WMAXM = 8;              // trie matches parked per start position
+constexpr uint32_t WMAXM = 8;              // trie matches parked per start position ...
+constexpr uint32_t XMAX = 48;              // ... and this many more per window, shared (a position with more than eight dictionary prefixes parks the rest here)
 constexpr uint32_t LOOKB = 192;            // text bytes staged beyond the window's own characters (a walk that runs past them reads HBM)
 constexpr uint32_t TEXTB = 4 * WIN + LOOKB;
 constexpr uint32_t LCODE = 96;            // character codes staged per window (char-level trie): the window's own and what the walks run into; beyond, the slab
@@ -53,7 +54,7 @@ constexpr uint32_t NONE16 = 0xFFFFu;
 constexpr uint32_t PAIR_MIN = 1024;        // bytes of pair table a window wants beyond its largest position
 
 struct Far { uint32_t end; int32_t dp; uint32_t right; uint32_t node; };          // a bucket entry that outlives its window (16 B)
-struct NodeRec { uint32_t pre; int32_t sid; uint32_t start; uint32_t bstart; };   // what the backtrace and the tokens need (16 B)
+struct NodeRec { int32_t sid; uint32_t start; };   // what the tokens need (8 B); the best predecessor lives in a dense array of its own (the backtrace reads every node's)
 
 template <int CTRL>
 __device__ __forceinline__ int32_t w_dpp(int32_t x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
@@ -129,9 +130,12 @@ __device__ __forceinline__ uint32_t win_walk(const DictView &d, BY &&byte, uint3
 }  // namespace
 
 // PROF: device-side work counters + per-phase shader clocks (KGPU_PROFILE_WORK) -- a separate instantiation: the accumulators cost ~40 SGPRs
-struct WinArgs { DictView d; BatchArgs a; WorkIO io; uint32_t lds_bytes, min_bytes; };
+struct WinArgs { DictView d; BatchArgs a; WorkIO io; uint32_t lds_bytes; };
 template <bool PROF>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_tokenize_window(WinArgs) {
+#ifndef KGPU_WIN_WPE
+#define KGPU_WIN_WPE 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE))) void k_tokenize_window(WinArgs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     // The arguments stay in the kernarg segment; every phase reads the fields it uses from there (KW_ARGS(): scalar loads behind a pointer
     // made opaque by an empty asm) -- as by-value parameters the ~90 dwords are live from entry to exit and spill (kgpu_pool.hip does the same).
@@ -140,10 +144,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
     DictView d; BatchArgs a; WorkIO io;
 #define KW_ARGS() do { KArgs kq_ = kargs; asm volatile("" : "+s"(kq_)); \
         d.da = kq_->d.da; d.da_len = kq_->d.da_len; d.leaf_dup = kq_->d.leaf_dup; d.first = kq_->d.first; d.morph = kq_->d.morph; d.n_morph = kq_->d.n_morph; d.unk_morph = kq_->d.unk_morph; d.n_unk_morph = kq_->d.n_unk_morph; d.conn = kq_->d.conn; d.conn_rows = kq_->d.conn_rows; d.bos_right = kq_->d.bos_right; d.eos_left = kq_->d.eos_left; d.cat = kq_->d.cat; d.cat_len = kq_->d.cat_len; d.cinfo = kq_->d.cinfo; d.conn_tiled = kq_->d.conn_tiled; d.conn_rt64 = kq_->d.conn_rt64; d.da2 = kq_->d.da2; d.da2_len = kq_->d.da2_len; d.n_nb = kq_->d.n_nb; d.crec = kq_->d.crec; d.nb_cp = kq_->d.nb_cp; d.nb_code = kq_->d.nb_code; \
-        a.utf8 = kq_->a.utf8; a.offsets = kq_->a.offsets; a.n = kq_->a.n; a.ctl = kq_->a.ctl; a.arena = kq_->a.arena; a.arena_bytes = kq_->a.arena_bytes; a.stage = kq_->a.stage; a.tok_count = kq_->a.tok_count; a.status = kq_->a.status; \
+        a.utf8 = kq_->a.utf8; a.offsets = kq_->a.offsets; a.n = kq_->a.n; a.ctl = kq_->a.ctl; a.arena = kq_->a.arena; a.arena_bytes = kq_->a.arena_bytes; a.stage = kq_->a.stage; a.tok_count = kq_->a.tok_count; a.status = kq_->a.status; a.count_work = kq_->a.count_work; \
         io.in_list = kq_->io.in_list; io.in_count = kq_->io.in_count; io.out_list = kq_->io.out_list; io.out_count = kq_->io.out_count; } while (0)
     KW_ARGS();
-    const uint32_t lds_bytes = kargs->lds_bytes, min_bytes = kargs->min_bytes;
+    const uint32_t lds_bytes = kargs->lds_bytes;
     const uint32_t lane = threadIdx.x;
     const int32_t base_root = d.da[1].base;
     const bool tiled = d.conn_tiled != nullptr;
@@ -170,7 +174,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
     uint16_t *rlenw = (uint16_t *)(lds + off0);  off0 += 2 * (WIN + 2);
     uint16_t *uspan = (uint16_t *)(lds + off0);  off0 += 2 * (WIN + 2);
     uint8_t *catw = lds + off0;                  off0 += align_up(WIN + 2, 4);
-    uint8_t *mcnt = lds + off0;                  off0 += align_up(WIN + 2, 4);
+    uint8_t *mcnt = lds + off0;                  off0 += align_up(WIN + 2, 4);   // dictionary prefixes at the position (all of them: beyond WMAXM in xbuf)
+    uint32_t *xcnt = (uint32_t *)(lds + off0);   off0 += 4;
+    uint2 *xbuf = (uint2 *)(lds + align_up(off0, 8)); off0 = align_up(off0, 8) + 8 * XMAX;   // {position | chars << 8, id | records << 21 ... as parked}: {pos | nch << 8 | nrec << 16, id}
     off0 = align_up(off0, 16);
     uint32_t nchunks_have = 0, fchunks_have = 0;   // wave-uniform; the tables persist in LDS
     const uint32_t MS = (d.leaf_dup && d.n_unk_morph < (1u << 21)) ? 4u : 8u;
@@ -200,7 +206,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
         }
         return true;
     };
-    auto node_rec = [&](uint32_t g) { return (NodeRec *)(a.arena + ((uint64_t)nchunk[g >> NCH_LOG] << 8)) + (g & ((1u << NCH_LOG) - 1)); };
+    // a node chunk: [pre: u32 x 8192 | NodeRec x 8192] = 96 KB
+    auto node_pre = [&](uint32_t g) { return (uint32_t *)(a.arena + ((uint64_t)nchunk[g >> NCH_LOG] << 8)) + (g & ((1u << NCH_LOG) - 1)); };
+    auto node_rec = [&](uint32_t g) { return (NodeRec *)(a.arena + ((uint64_t)nchunk[g >> NCH_LOG] << 8) + (4u << NCH_LOG)) + (g & ((1u << NCH_LOG) - 1)); };
     auto far_rec = [&](uint32_t f) { return (Far *)(a.arena + ((uint64_t)fchunk[(f >> FCH_LOG) % FCHUNKS] << 8)) + (f & ((1u << FCH_LOG) - 1)); };
 
     for (uint32_t iter = 0;; ++iter) {
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
         const uint32_t B = (uint32_t)(a.offsets[s + 1] - b0);
         const uint8_t *text = a.utf8 + b0;
         uint64_t tlast = PROF ? __builtin_amdgcn_s_memtime() : 0;
-        if (cfg_bad || (io.out_list && B < min_bytes)) { fail(s); continue; }  // short long sentences: the HBM-lattice kernel serves them better
+        if (cfg_bad) { fail(s); continue; }
 
         // ---- slab: one 8-byte record per character in HBM (written by the two prepasses, read once per window), then the backtrace's path ----
         //   .x = byte offset (24 bits) | category << 24     .y = BMP code point (0xFFFF: not BMP) | same-category run length from here << 16
@@ -395,6 +403,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             }
             for (uint32_t e = lane; e < REL + 2; e += 64) { boff[e] = 0; bfill[e] = 0; }
             if (lane < WIN + 2) { fcnt[lane] = 0; wideN[lane] = 0; }
+            if (lane == 0) *xcnt = 0;
             wave_sync();
             const uint32_t wbyte_next = cbw[nwc];
             auto byte = [&](uint32_t k) -> uint32_t { const uint32_t r = k - tb0; return r < tlen ? ltext[r + tmis] : text[k]; };
@@ -440,6 +449,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     if (m < WMAXM && nch < 256) {
                         if (MS == 4) mbuf[lane * WMAXM + m] = id | (nch << 21) | ((nrec < 8 ? nrec : 0u) << 29);
                         else *(uint2 *)(mbuf + 2 * (lane * WMAXM + m)) = make_uint2(id, nch | (nrec << 8));
+                    } else if (nch < 256 && m < 255 && nrec < 65536) {   // the ninth prefix and beyond: the window's shared overflow area (a lane's entries keep their order)
+                        const uint32_t k = atomicAdd(xcnt, 1u);
+                        if (k < XMAX) xbuf[k] = make_uint2(lane | (nch << 8) | (nrec << 16), id); else ovf = 1;
                     } else ovf = 1;
                     ++m;
                     cnt += nrec;
@@ -448,10 +460,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 if (ct) {
                     const uint16_t *lcode = (const uint16_t *)ltext;
                     ct_walk(d, 1, d.da2[1].base, 0, [&](uint32_t dep) -> uint32_t { const uint32_t j = lane + dep; return j < LCODE ? (uint32_t)lcode[j] : (uint32_t)code16[min(w0 + j, C)]; }, on_match, 0u);
-                    if constexpr (PROF) wTw += da_walk(d, text, cbw[lane], B, base_root, [](uint32_t, uint32_t, uint32_t) {});  // the reference's byte steps (work counters)
+                    if constexpr (PROF) if (!(a.count_work & 2u)) wTw += da_walk(d, text, cbw[lane], B, base_root, [](uint32_t, uint32_t, uint32_t) {});  // the reference's byte steps (work counters; not in phase-timing runs)
                 } else
                 wTw += win_walk(d, byte, cp16w[lane], cbw[lane], cbw[lane + 1], B, base_root, on_match);
-                mcnt[lane] = (uint8_t)(m < WMAXM ? m : WMAXM);
+                mcnt[lane] = (uint8_t)m;
                 const CatInfo ci = d.cinfo[catw[lane]];
                 uint32_t span = 0;
                 if ((cnt == 0 || (ci.flags & CAT_INVOKE)) && (ci.flags & CAT_HAS_UNK) && ci.unk_count) {  // lattice.rs:54,87-92
@@ -529,7 +541,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             // -- emit 3a (lane = start position, LDS only): the node list in insertion order; nLeft = relative end, or 0x8000 | far-out slot
             if (lane < nwc) {
                 uint32_t t = nb[lane], fslot = fbase[lane];
-                const uint32_t nm = mcnt[lane], span = uspan[lane];
+                const uint32_t nm_all = mcnt[lane], nm = min(nm_all, WMAXM), span = uspan[lane];
                 uint32_t ufirst = 0, ucnt = 0;
                 if (span) {
                     if (nm < WMAXM) {
@@ -555,6 +567,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                         id = w.x; nch = w.y & 255u; nrec = w.y >> 8;
                     }
                     for (uint32_t r = 0; r < nrec; ++r) put((int32_t)(id + r), lane + nch);
+                }
+                if (nm_all > WMAXM) {   // the longer prefixes, from the overflow area, in the order the walk found them (ascending length: trie/da.rs:155-182)
+                    const uint32_t nx = min(*xcnt, XMAX);
+                    for (uint32_t k = 0; k < nx; ++k) {
+                        const uint2 w = xbuf[k];
+                        if ((w.x & 255u) != lane) continue;
+                        const uint32_t nch = (w.x >> 8) & 255u, nrec = w.x >> 16;
+                        for (uint32_t r = 0; r < nrec; ++r) put((int32_t)(w.y + r), lane + nch);
+                    }
                 }
                 if (span) for (uint32_t r = 0; r < ucnt; ++r) put(-(int32_t)(ufirst + r), lane + span);
             }
@@ -651,13 +672,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                         const uint32_t dp0 = boff[ql], deb = eb_l - eb0;
                         dT = nb1 - dt0;
                         dP = boff[ql + 1] - dp0;
-                        const bool fastq = dP <= 32 && dT - 1u < 127u && wideN[ql] == 0;
+                        const uint32_t wn_l = wideN[ql];
+                        const bool fastq = dP <= 32 && dT - 1u < 127u && wn_l == 0;
                         d0 = (a_ncs + 4 * dt0) | (fastq ? (dT << 18) | (dP << 25) : 1u << 31);
                         d1 = a_bk + 8 * dp0;
                         d2 = a_mp + 2 * deb;
+                        if (dP == 0 && wn_l == 0) {   // nothing ends here (lattice.rs:121-140 with an empty edges[pos]): its targets stay at INF (set by emit) with no
+                            d0 = 0;                    // predecessor -- no step on the chain for this position
+                            for (uint32_t k = 0; k < dT; ++k) pre[dt0 + k] = (uint16_t)NONE16;
+                        }
                     }
                     for (uint32_t r = 0; r < nq; ++r) {
                         const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)r);
+                        if (D0 == 0) continue;
                         const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)r);
                         const uint32_t D2 = (uint32_t)__builtin_amdgcn_readlane((int)d2, (int)r);
                         if (!(D0 >> 31)) {
@@ -780,16 +807,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 
             KW_ARGS();
             // -- flush: node records to HBM, far-out entries to the FIFO, the buckets beyond the window to the carry list
-            if (!chunk_get(nchunk, nchunks_have, (gw + N - 1) >> NCH_LOG, sizeof(NodeRec) << NCH_LOG)) { failed = true; why = 3; break; }
+            if (!chunk_get(nchunk, nchunks_have, (gw + N - 1) >> NCH_LOG, (4u + (uint32_t)sizeof(NodeRec)) << NCH_LOG)) { failed = true; why = 3; break; }
             for (uint32_t t = lane; t < N; t += 64) {
                 const uint32_t p = pre[t], st = nStart[t];
+                const uint32_t gp = p == NONE16 ? NONE : rb + p;
                 NodeRec rec;
-                rec.pre = p == NONE16 ? NONE : rb + p;
                 rec.sid = nSid[t];
                 rec.start = w0 + st;
-                rec.bstart = st <= nwc ? cbw[st] : B;
+                *node_pre(gw + t) = gp;
                 *node_rec(gw + t) = rec;
-                if (rec.sid == 0 && w0 + st == C) eos_pre = rec.pre;  // (only EOS has sid 0: BOS is never a target)
+                if (rec.sid == 0 && w0 + st == C) eos_pre = gp;  // (only EOS has sid 0: BOS is never a target)
             }
             if (nw > nwc) eos_pre = bcast32((uint32_t)__shfl((int)eos_pre, (int)((N - 1) & 63u), 64));  // the lane that wrote node N - 1
             if (NF) {
@@ -848,29 +875,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
         const uint32_t Ntot = gw;  // BOS + every node; EOS is node Ntot - 1
         uint32_t K = 0;
         {
+            // `pre` of a range of nodes staged in LDS, lane 0 chases the chain through it; the path it finds is parked in LDS too (PATHL entries at the
+            // top) and written out PATHL at a time by all lanes -- a global store inside the one-lane loop made every step wait for its issue
             uint32_t *win = (uint32_t *)(lds + off0);
-            const uint32_t Wn = (lds_bytes - off0) / 4;
-            uint32_t pos = Ntot - 1, pr_first = eos_pre;
-            bool done = pr_first == NONE;  // EOS unreachable: empty Vec (lattice.rs:144-153)
-            if (!done && lane == 0) path[0] = pos;
-            if (!done) { K = 1; pos = pr_first; }
+            const uint32_t Wall = (lds_bytes - off0) / 4, PATHL = min(512u, Wall / 4), Wn = Wall - PATHL;
+            uint32_t *lpath = win + Wn;
+            uint32_t pos = Ntot - 1, nl = 0;
+            bool done = eos_pre == NONE;  // EOS unreachable: empty Vec (lattice.rs:144-153)
+            if (!done) { if (lane == 0) lpath[0] = pos; nl = 1; pos = eos_pre; }
             while (!done) {
                 // pos: the node whose record is needed next (a predecessor always has a smaller index)
                 const uint32_t wlo = pos >= Wn - 1 ? pos - (Wn - 1) : 0;
-                for (uint32_t i = wlo + lane; i <= pos; i += 64) win[i - wlo] = i ? node_rec(i)->pre : NONE;
+                for (uint32_t i = wlo + lane; i <= pos; i += 64) win[i - wlo] = i ? *node_pre(i) : NONE;
                 wave_sync();
-                uint32_t npos = pos, nK = K, fin2 = 0;
-                if (lane == 0) {
-                    for (;;) {
-                        const uint32_t pr = win[npos - wlo];
-                        if (pr == NONE || nK > C) { fin2 = 1; break; }  // the chain's first node (normally BOS) is dropped
-                        path[nK++] = npos;
-                        npos = pr;
-                        if (npos < wlo) break;
+                for (;;) {
+                    uint32_t npos = pos, nnl = nl, fin2 = 0;
+                    if (lane == 0) {
+                        for (;;) {
+                            const uint32_t pr = win[npos - wlo];
+                            if (pr == NONE || K + nnl > C) { fin2 = 1; break; }  // the chain's first node (normally BOS) is dropped
+                            lpath[nnl++] = npos;
+                            npos = pr;
+                            if (npos < wlo || nnl == PATHL) break;
+                        }
                     }
+                    pos = bcast32(npos); nl = bcast32(nnl); done = bcast32(fin2) != 0;
+                    wave_sync();
+                    if (nl == PATHL || done) {
+                        for (uint32_t k = lane; k < nl; k += 64) path[K + k] = lpath[k];
+                        K += nl; nl = 0;
+                        wave_sync();
+                    }
+                    if (done || pos < wlo) break;
                 }
-                pos = bcast32(npos); K = bcast32(nK); done = bcast32(fin2) != 0;
-                wave_sync();
             }
         }
         K = bcast32(K);
@@ -880,11 +917,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             const NodeRec r = *node_rec(path[K - 1 - k]);
             kgpu_token tk;
             if (r.sid == 0) { tk.id = 0; tk.cls = KGPU_CLASS_DUMMY; tk.position = B; tk.start = C; tk.end = C + 3; tk.byte_len = 0; }
-            else {
+            else {   // a word ends where its successor starts; the byte offsets come from the per-character records of the decode pass ([C] = {B, 0})
                 const NodeRec nx = *node_rec(path[K - 2 - k]);
+                const uint32_t b0s = crec[r.start].x & 0xFFFFFFu, b1s = crec[nx.start].x & 0xFFFFFFu;
                 tk.id = r.sid > 0 ? r.sid : -r.sid;
                 tk.cls = r.sid > 0 ? KGPU_CLASS_KNOWN : KGPU_CLASS_UNKNOWN;
-                tk.position = r.bstart; tk.start = r.start; tk.end = nx.start; tk.byte_len = nx.bstart - r.bstart;
+                tk.position = b0s; tk.start = r.start; tk.end = nx.start; tk.byte_len = b1s - b0s;
             }
             a.stage[ts + k] = tk;
         }
@@ -910,14 +948,14 @@ int window_workgroups_per_cu(uint32_t lds_bytes) {
     return n;
 }
 
-int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, uint32_t min_bytes, int n_workgroups, void *stream) {
+int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, void *stream) {
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_window<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_tokenize_window<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    if (a.count_work) hipLaunchKernelGGL(k_tokenize_window<true>, dim3((unsigned)n_workgroups), dim3(64), lds_bytes, (hipStream_t)stream, WinArgs{d, a, io, lds_bytes, min_bytes});
-    else hipLaunchKernelGGL(k_tokenize_window<false>, dim3((unsigned)n_workgroups), dim3(64), lds_bytes, (hipStream_t)stream, WinArgs{d, a, io, lds_bytes, min_bytes});
+    if (a.count_work) hipLaunchKernelGGL(k_tokenize_window<true>, dim3((unsigned)n_workgroups), dim3(64), lds_bytes, (hipStream_t)stream, WinArgs{d, a, io, lds_bytes});
+    else hipLaunchKernelGGL(k_tokenize_window<false>, dim3((unsigned)n_workgroups), dim3(64), lds_bytes, (hipStream_t)stream, WinArgs{d, a, io, lds_bytes});
     return (int)hipGetLastError();
 }
 

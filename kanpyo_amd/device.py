@@ -10,7 +10,7 @@ import ctypes as C
 
 from . import _lib
 
-PROFILE_OFF, PROFILE_EVENTS, PROFILE_WORK, PROFILE_SAMPLED = 0, 1, 2, 4
+PROFILE_OFF, PROFILE_EVENTS, PROFILE_WORK, PROFILE_SAMPLED, PROFILE_NO_T = 0, 1, 2, 4, 8
 STAGE_ALL, STAGE_LATTICE, STAGE_GATHER, STAGE_VITERBI = 0, 5, 6, 7  # kgpu_ctx_set_ablation
 
 

@@ -19,3 +19,10 @@ for t in threads:
     launches = rt["small_calls"] - rt["combined_calls"] + rt["combined_launches"]
     print(f"threads {t:4d} n {npc}: {r['sentences_per_s']/1e3:8.1f} k sentences/s  p50 {r['p50_us']:7.1f} us  p99 {r['p99_us']:8.1f}  mean {r['mean_us']:7.1f}  "
           f"sentences/launch {r['sentences']/max(launches,1):6.1f}  fallbacks {rt['small_fallbacks']}", flush=True)
+    if os.environ.get("KGPU_SMALL_TRACE"):
+        import ctypes as C
+        from kanpyo_amd import _lib
+        st = (C.c_uint64 * 8)()
+        _lib.lib().kgpu_debug_small_trace(st)
+        L = max(st[0], 1)
+        print(f"      per launch (us): prep {st[1]/L/1e3:.1f}  launch call {st[2]/L/1e3:.1f}  poll {st[3]/L/1e3:.1f}  hand-out {st[4]/L/1e3:.1f}  ({st[0]} launches, {st[5]/L:.1f} sentences each)", flush=True)

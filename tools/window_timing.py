@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """Where the windowed long-sentence kernel's time goes (shader clocks per character, PROFILE_WORK run): python tools/window_timing.py cfg5|cfg3 n [Q]"""
 import os, sys, time
-os.environ.setdefault("KGPU_WINDOW", "16")
+os.environ.setdefault("KGPU_WINDOW", "12")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from kanpyo_amd import Tokenizer, synth
-from kanpyo_amd.device import PROFILE_WORK, PROFILE_OFF, DeviceContext
+from kanpyo_amd.device import PROFILE_WORK, PROFILE_OFF, PROFILE_NO_T, DeviceContext
 from kanpyo_amd.tokenizer import pack_sentences
 kind = sys.argv[1] if len(sys.argv) > 1 else "cfg5"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -28,7 +28,7 @@ go(2)
 torch.cuda.synchronize(); t0 = time.perf_counter(); go(3); dt = (time.perf_counter() - t0) / (3 * Q)
 chars = sum(map(len, sents))
 print(f"{kind}: {n} sentences of {chars / n:.0f} chars, window LDS {os.environ['KGPU_WINDOW']} KB, {Q} in flight: {n / dt:,.0f} sentences/s, {chars / dt / 1e6:.0f} Mchar/s; reruns {sum(c.profile()['window_reruns'] for c in ctxs)}")
-for c in ctxs: c.set_profiling(PROFILE_WORK); c.phase_cycles(reset=True); c.work(reset=True)
+for c in ctxs: c.set_profiling(PROFILE_WORK | PROFILE_NO_T); c.phase_cycles(reset=True); c.work(reset=True)
 go(1)
 ph = np.zeros(10); w = {}
 for c in ctxs:
