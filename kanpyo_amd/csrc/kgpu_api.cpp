@@ -15,6 +15,7 @@
 #include <functional>
 #include <thread>
 #include <pthread.h>
+#include <sched.h>
 #include <linux/futex.h>
 #include <sys/syscall.h>
 #include <climits>
@@ -1228,6 +1229,8 @@ static int small_call(kgpu_dict *d, kgpu_ctx *c, SmallReq *const *reqs, size_t n
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
+        // many callers inside the entry point: most of them need a CPU to assemble or pick up their results -- this thread's poll lets them have it
+        if ((spin & 63) == 63 && d->combiner_callers() > 8) sched_yield();
     }
     const uint64_t tt3 = trace ? now_ns() : 0;
     struct TraceOut { bool on; uint64_t t0, t1, t2, t3, n; ~TraceOut() { if (on) { const uint64_t t4 = now_ns(); g_st[0] += 1; g_st[1] += t1 - t0; g_st[2] += t2 - t1; g_st[3] += t3 - t2; g_st[4] += t4 - t3; g_st[5] += n; } } } trace_out{trace, tt0, tt1, tt2, tt3, n};
@@ -1278,6 +1281,7 @@ struct Combiner {
     std::atomic<int> callers{0};     // threads inside the small-call entry
     std::atomic<int> in_flight{0};   // launches between close and completion
 };
+int kgpu_dict::combiner_callers() const { return combiner ? combiner->callers.load(std::memory_order_relaxed) : 0; }
 static Combiner *combiner_new() { return new Combiner(); }
 static void combiner_delete(Combiner *c) { delete c; }
 static Combiner &combiner_of(kgpu_dict *d) { return *d->combiner; }

@@ -684,7 +684,7 @@ LaunchPlan default_launch_plan(int device) {
     t.n_pools = 0;
     {
         const char *e = getenv("KGPU_POOL");
-        const char *q = e ? e : "40:4:40";
+        const char *q = e ? e : "40:4:48";
         while (*q && t.n_pools < 2) {
             int kib = atoi(q), w = 8, mp = 64;
             const char *c = q;

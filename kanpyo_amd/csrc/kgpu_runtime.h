@@ -62,6 +62,7 @@ struct Combiner;  // kgpu_api.cpp: concurrent small calls sharing a launch
 struct kgpu_dict {
     int device = 0;
     Combiner *combiner = nullptr;
+    int combiner_callers() const;  // threads inside the small-call entry point right now
     DictView view{};
     kgpu_dict_info info{};
     std::vector<void *> allocs;
