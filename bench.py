@@ -977,6 +977,31 @@ def main():
                     extra.append(measure_config(tok, dev, wl_x, n_chars, passes, args.queue, 0, lab, orc=extras_orc))
             except Exception as e:
                 print(f"{kind} leg failed: {e}", file=sys.stderr)
+        # ---- a real Kanpyo dictionary, when one is on the box (KANPYO_DICT=/path/ipa.dict, optional KANPYO_SENTENCES=/path/text): parity + rate on it.
+        # The dictionary cannot be obtained in the build environment (reference README.md:74-82: fetched from GitHub Releases), so this line is
+        # normally absent; tests/test_real_dict.py is the matching parity test.
+        real = os.environ.get("KANPYO_DICT")
+        if real and os.path.exists(real):
+            try:
+                from kanpyo_amd.dictfile import load_dict
+
+                df = load_dict(real)
+                tok_r = Tokenizer(df.dict, device=local_rank)
+                sp = os.environ.get("KANPYO_SENTENCES")
+                if sp and os.path.exists(sp):
+                    with open(sp, encoding="utf-8") as f:
+                        rs = [ln.rstrip() for ln in f.read().split("\n") if ln.strip()]
+                else:  # no text given: the synthetic cfg 2 corpus (its words are not this dictionary's: an unknown-word-heavy load)
+                    rs = corpora[0]
+                rs = (rs * (N_SENT // max(len(rs), 1) + 1))[:N_SENT]
+                ur, orr = pack_sentences(rs)
+                orc_r = _orc.OracleTokenizer.from_dict(df.dict) if extras_orc is not None else None
+                line = measure_config(tok_r, dev, PackedWorkload(ur, orr, batch=BATCH), sum(map(len, rs)), 10, args.queue, 0,
+                                      f"real dictionary {os.path.basename(real)} ({df.dict.n_morphs} records), {len(rs)} sentences, batch 4096", orc=orc_r)
+                extra.append(line)
+                tok_r.close()
+            except Exception as e:
+                print(f"real-dictionary leg failed: {e}", file=sys.stderr)
         result["extra"] = extra
         import shutil
 

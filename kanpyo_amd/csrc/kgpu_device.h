@@ -1,5 +1,6 @@
-// kanpyo_amd/csrc/kgpu_device.h -- device-side helpers shared by the tokenize
-// kernels (general: kgpu_kernels.hip, LDS-resident: kgpu_lds.hip).
+// kanpyo_amd/csrc/kgpu_device.h -- device-side code shared by the tokenize kernels (LDS-resident: kgpu_pool.hip, windowed: kgpu_window.hip,
+// general: kgpu_kernels.hip): the trie walks, UTF-8 decoding, and -- once, for both LDS kernels -- the Viterbi sweep step, its DPP minima and the
+// connection-cost gather.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -257,6 +258,178 @@ __device__ __forceinline__ uint32_t utf8_cp_at(const uint8_t *t) {  // valid UTF
     if (b < 0xF0) return ((b & 0x0Fu) << 12) | ((t[1] & 0x3Fu) << 6) | (t[2] & 0x3Fu);
     return ((b & 0x07u) << 18) | ((t[1] & 0x3Fu) << 12) | ((t[2] & 0x3Fu) << 6) | (t[3] & 0x3Fu);
 }
+
+// ---- UTF-8: one lead byte decoded and validated (what Rust's &str guarantees, checked at the C boundary: src/tokenizer.rs:16).  b: the byte at k (a
+// lead byte: not 10xxxxxx), B: sentence length, byte_at(k): the sentence's bytes.  Returns the sequence length (1 where the sequence is bad, so that
+// the sum of lengths still walks the text) and sets cp / bad.  Overlong forms, surrogates, code points beyond U+10FFFF and truncated sequences are bad.
+template <class BY>
+__device__ __forceinline__ uint32_t utf8_decode_lead(uint32_t b, uint32_t k, uint32_t B, BY &&byte_at, uint32_t &cp, uint32_t &bad) {
+    uint32_t l;
+    if (b < 0x80) { l = 1; cp = b; }
+    else if (b >= 0xC2 && b <= 0xDF) { l = 2; cp = b & 0x1F; }
+    else if ((b & 0xF0) == 0xE0) { l = 3; cp = b & 0x0F; }
+    else if (b >= 0xF0 && b <= 0xF4) { l = 4; cp = b & 0x07; }
+    else { l = 1; cp = 0; bad = 1; }
+    if (k + l > B) { bad = 1; l = 1; }
+    for (uint32_t j = 1; j < l; ++j) {
+        const uint32_t bb = byte_at(k + j);
+        if ((bb & 0xC0) != 0x80) bad = 1;
+        cp = (cp << 6) | (bb & 0x3F);
+    }
+    if (l == 3 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) bad = 1;
+    if (l == 4 && (cp < 0x10000 || cp > 0x10FFFF)) bad = 1;
+    return l;
+}
+
+// ---- LDS access by absolute 32-bit LDS address (the sweep keeps ready-made addresses in its descriptors; going through `array + offset` makes the
+// compiler add the array's link-time base -- zero -- to every address, on the VALU)
+#define KGPU_LDS(T) __attribute__((address_space(3))) T
+template <class T> __device__ __forceinline__ T lds_ld(uint32_t addr) { return *(const KGPU_LDS(T) *)(uintptr_t)addr; }
+template <class T> __device__ __forceinline__ void lds_st(uint32_t addr, T v) { *(KGPU_LDS(T) *)(uintptr_t)addr = v; }
+__device__ __forceinline__ uint2 lds_ld2(uint32_t addr) { const uint64_t v = lds_ld<uint64_t>(addr); return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); }
+
+// Wavefront-level ordering point.  LDS executes one wavefront's instructions in issue order, so data written by one lane is visible to the others at
+// the next instruction; this only stops the compiler from moving LDS accesses across it (no s_barrier: the wavefronts of a workgroup are
+// independent, and no vmcnt wait: global loads in flight stay in flight).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- group minima on the DPP network over aligned groups of 2^LG lanes (LG <= 4): one DPP-fused v_min per step, every lane gets the result.
+// (Exec is full wherever these run -- wave-uniform control flow -- so bound_ctrl never substitutes a zero.)
+template <int CTRL>
+__device__ __forceinline__ int32_t dpp_i32(int32_t x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+template <uint32_t LG>
+__device__ __forceinline__ int32_t group_min_i32(int32_t v) {
+    if constexpr (LG >= 1) v = min(v, dpp_i32<0xB1>(v));   // quad_perm [1,0,3,2]
+    if constexpr (LG >= 2) v = min(v, dpp_i32<0x4E>(v));   // quad_perm [2,3,0,1]
+    if constexpr (LG >= 3) v = min(v, dpp_i32<0x141>(v));  // row_half_mirror
+    if constexpr (LG >= 4) v = min(v, dpp_i32<0x140>(v));  // row_mirror
+    return v;
+}
+template <uint32_t LG>
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t v) {
+    if constexpr (LG >= 1) v = min(v, (uint32_t)dpp_i32<0xB1>((int32_t)v));
+    if constexpr (LG >= 2) v = min(v, (uint32_t)dpp_i32<0x4E>((int32_t)v));
+    if constexpr (LG >= 3) v = min(v, (uint32_t)dpp_i32<0x141>((int32_t)v));
+    if constexpr (LG >= 4) v = min(v, (uint32_t)dpp_i32<0x140>((int32_t)v));
+    return v;
+}
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v) {  // over the 64 lanes, every lane gets it
+    v = group_min_i32<4>(v);
+    v = min(v, __shfl_xor(v, 16, 64));
+    return min(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = group_min_u32<4>(v);
+    v = min(v, (uint32_t)__shfl_xor((int32_t)v, 16, 64));
+    return min(v, (uint32_t)__shfl_xor((int32_t)v, 32, 64));
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t k) {  // over the 64 lanes, every lane gets it
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t oh = (uint32_t)__shfl_xor((int)(uint32_t)(k >> 32), d, 64), ol = (uint32_t)__shfl_xor((int)(uint32_t)k, d, 64);
+        const uint64_t o = ((uint64_t)oh << 32) | ol;
+        k = o < k ? o : k;
+    }
+    return k;
+}
+
+// ---- THE Viterbi sweep step of the LDS kernels (kgpu_pool.hip, kgpu_window.hip): one start position, lattice.rs:116-142.
+// What a step costs is its dependent chain and its taken branches, not its arithmetic (measured on one wavefront alone: LDS write -> read 86 cycles,
+// three dependent DPP minima 43, a taken branch 32, an exec-masked block 64, descriptor read-out + scalar dispatch 52 -- tools/ubench).  So:
+//  * per-position descriptors are ready-made LDS byte addresses: D0 = address of nCS[t0] (18 bits) | T (7) << 18 | P (6) << 25 (bit 31 set / D0 == 0:
+//    not for this routine), D1 = address of the position's bucket bk[p0] (entries {dp, right | node << 16}), D2 = address of its pair costs (pair
+//    (ti, j) at ti * P + j, int16); a_ncs / a_pre / a_bk: the arrays' own addresses (pre[] is parallel to nCS[], half as wide);
+//  * three straight-line bodies chosen by ONE scalar compare chain: P <= 8 (pair (ti, j) on lane ti * 8 + j, eight targets per pass), P <= 16 (the same
+//    lanes take predecessors j and j + 8), P <= 32 (16 lanes per target, four targets per pass);
+//  * every load is unconditional and unclamped (an index past the arrays reads someone else's LDS or zero and is deselected afterwards); an absent
+//    candidate is a total no real one reaches (real <= INF + 32767) that still cannot overflow when the word cost is added -- so P = 0 needs no case;
+//  * no exec-masked region and no sinks: target groups past T redo target T - 1 -- same loads, same result, same stores to the same addresses;
+//  * two DPP group minima: the total, then -- strict '<' over ascending insertion order (lattice.rs:125,136) -- the WHOLE second bucket word among the
+//    ties: the node index is its upper half, so the minimum picks the smallest node, and a half-word store writes it;
+//  * tot < INF after the add = .min(INF) then strict '<' (lattice.rs:135-136); no fence: one wavefront's DS instructions execute in issue order.
+template <uint32_t LG>
+__device__ __forceinline__ void sweep_pass2(uint32_t lane, uint32_t tb, uint32_t T, uint32_t P, uint32_t acs, uint32_t apre, uint32_t a_bk, uint32_t D1, uint32_t D2) {
+    constexpr uint32_t G = 1u << LG;
+    const uint32_t j = lane & (G - 1u), ti = min(tb + (lane >> LG), T - 1u);
+    const bool j0v = j < P, j1v = j + G < P;
+    const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
+    const uint2 e0 = lds_ld2(D1 + 8 * j), e1 = lds_ld2(D1 + 8 * j + 8 * G);
+    const uint32_t am = D2 + 2 * (__umul24(ti, P) + j);
+    const int32_t pc0 = lds_ld<int16_t>(am), pc1 = lds_ld<int16_t>(am + 2 * G);
+    __builtin_amdgcn_sched_barrier(0);  // the five reads stay one round trip
+    constexpr int32_t ABSENT = 0x7FFEFFFF;
+    const int32_t v0 = j0v ? (int32_t)e0.x + pc0 : ABSENT;
+    const int32_t v1 = j1v ? (int32_t)e1.x + pc1 : ABSENT;
+    const int32_t vmin = group_min_i32<LG>(min(v0, v1));
+    const uint32_t n0 = v0 == vmin ? e0.y : 0xFFFFFFFFu, n1 = v1 == vmin ? e1.y : 0xFFFFFFFFu;
+    const uint32_t nmin = group_min_u32<LG>(min(n0, n1));
+    const int32_t tot = vmin + (int32_t)(int16_t)cs;
+    const bool ok = tot < INF;
+    lds_st<uint16_t>(apre + 2 * ti, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
+    lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
+}
+__device__ __forceinline__ void sweep_pass1(uint32_t lane, uint32_t tb, uint32_t T, uint32_t P, uint32_t acs, uint32_t apre, uint32_t a_bk, uint32_t D1, uint32_t D2) {
+    const uint32_t j = lane & 7u, ti = min(tb + (lane >> 3), T - 1u);   // P <= 8 (87 % of the positions on the cfg 2 corpus): one candidate per lane
+    const bool j0v = j < P;
+    const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
+    const uint2 e0 = lds_ld2(D1 + 8 * j);
+    const int32_t pc0 = lds_ld<int16_t>(D2 + 2 * (__umul24(ti, P) + j));
+    __builtin_amdgcn_sched_barrier(0);
+    const int32_t v0 = j0v ? (int32_t)e0.x + pc0 : 0x7FFEFFFF;
+    const int32_t vmin = group_min_i32<3>(v0);
+    const uint32_t nmin = group_min_u32<3>(v0 == vmin ? e0.y : 0xFFFFFFFFu);
+    const int32_t tot = vmin + (int32_t)(int16_t)cs;
+    const bool ok = tot < INF;
+    lds_st<uint16_t>(apre + 2 * ti, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
+    lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
+}
+// One position with 1 <= T <= 127 targets and P <= 32 predecessors, described by (D0, D1, D2) as above.
+__device__ __forceinline__ void sweep_position_fast(uint32_t lane, uint32_t D0, uint32_t D1, uint32_t D2, uint32_t a_ncs, uint32_t a_pre, uint32_t a_bk) {
+    const uint32_t acs = D0 & 0x3FFFFu, T = (D0 >> 18) & 127u, P = D0 >> 25;
+    const uint32_t apre = a_pre + ((acs - a_ncs) >> 1);  // pre[t0]
+    if (P <= 8) {
+        sweep_pass1(lane, 0u, T, P, acs, apre, a_bk, D1, D2);
+        if (T > 8) for (uint32_t tb = 8; tb < T; tb += 8) sweep_pass1(lane, tb, T, P, acs, apre, a_bk, D1, D2);
+    } else if (P <= 16) {
+        sweep_pass2<3>(lane, 0u, T, P, acs, apre, a_bk, D1, D2);
+        if (T > 8) for (uint32_t tb = 8; tb < T; tb += 8) sweep_pass2<3>(lane, tb, T, P, acs, apre, a_bk, D1, D2);
+    } else {
+        for (uint32_t tb = 0; tb < T; tb += 4) sweep_pass2<4>(lane, tb, T, P, acs, apre, a_bk, D1, D2);
+    }
+}
+// The three descriptor words of a position for sweep_position_fast (fast = 1 <= T <= 127 and P <= 32 and nothing else in the way; else bit 31).
+__device__ __forceinline__ uint32_t sweep_desc0(uint32_t a_ncs, uint32_t t0, uint32_t T, uint32_t P, bool fast) {
+    return (a_ncs + 4 * t0) | (fast ? (T << 18) | (P << 25) : 1u << 31);
+}
+
+// ---- the connection-cost gather of one target (connection.rs:12-14): M[right(j)][left(t)] for the P predecessors of its position into the LDS pair
+// table, eight independent gathers in flight per lane (two groups of four, the second only where the row goes on; the last group of a row padded
+// with a repeat of its final entry: ceil(P / 8) dependent rounds).  bk: the position's bucket (its .y carries the right id -- as a tile offset with
+// the tiled matrix), col: the target's row (tiled: its 8-row strip), out: the target's row of the pair table.
+__device__ __forceinline__ void gather_target_row(const uint2 *bk, uint32_t P, const int16_t *col, int16_t *out) {
+    for (uint32_t j = 0; j < P; j += 8) {
+        const uint32_t j1 = min(j + 1, P - 1), j2 = min(j + 2, P - 1), j3 = min(j + 3, P - 1);
+        const bool more = j + 4 < P;
+        const uint32_t j4 = j + 4, j5 = min(j + 5, P - 1), j6 = min(j + 6, P - 1), j7 = min(j + 7, P - 1);
+        const uint32_t r0 = bk[j].y & 0xFFFFu, r1 = bk[j1].y & 0xFFFFu, r2 = bk[j2].y & 0xFFFFu, r3 = bk[j3].y & 0xFFFFu;
+        uint32_t r4 = 0, r5 = 0, r6 = 0, r7 = 0;
+        if (more) { r4 = bk[j4].y & 0xFFFFu; r5 = bk[j5].y & 0xFFFFu; r6 = bk[j6].y & 0xFFFFu; r7 = bk[j7].y & 0xFFFFu; }
+        const int16_t c0 = col[r0], c1 = col[r1], c2 = col[r2], c3 = col[r3];
+        int16_t c4 = 0, c5 = 0, c6 = 0, c7 = 0;
+        if (more) { c4 = col[r4]; c5 = col[r5]; c6 = col[r6]; c7 = col[r7]; }
+        out[j] = c0; out[j1] = c1; out[j2] = c2; out[j3] = c3;
+        if (more) { out[j4] = c4; out[j5] = c5; out[j6] = c6; out[j7] = c7; }
+    }
+}
+// The row of the (frequency-ranked) connection matrix a target with left id L reads: the tiled copy's 8-row strip when there is one.
+__device__ __forceinline__ const int16_t *conn_row(const DictView &d, uint32_t L) {
+    return d.conn_tiled ? d.conn_tiled + ((size_t)(L >> 3) * d.conn_rt64 + (L & 7u) * 8u) : d.conn + (size_t)d.conn_rows * L;
+}
+// ... and the form in which a bucket carries a right id r: as is, or as its tile offset (r >> 3) * 64 + (r & 7), which the gather adds as is.
+__device__ __forceinline__ uint32_t conn_rword(const DictView &d, uint32_t r) { return d.conn_tiled ? ((r >> 3) << 6) | (r & 7u) : r; }
 
 // Work-list plumbing shared by the kernels of a launch chain: launch k takes its sentence ids
 // from list `in_list` (nullptr = identity over [0, n)) and pushes the ones it does not

@@ -41,32 +41,6 @@ namespace {
 
 constexpr uint32_t GMAXM = 8;  // trie matches parked per start position by the count walk
 
-// ---- 32/64-bit group minima over aligned groups of 2^lg lanes (lg wave-uniform, exec full) ----
-template <int CTRL>
-__device__ __forceinline__ int32_t g_dpp(int32_t x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
-__device__ __forceinline__ int32_t gmin_i32(int32_t v, uint32_t lg) {
-    if (lg >= 1) v = min(v, g_dpp<0xB1>(v));   // quad_perm [1,0,3,2]
-    if (lg >= 2) v = min(v, g_dpp<0x4E>(v));   // quad_perm [2,3,0,1]
-    if (lg >= 3) v = min(v, g_dpp<0x141>(v));  // row_half_mirror
-    if (lg >= 4) v = min(v, g_dpp<0x140>(v));  // row_mirror
-    if (lg >= 5) v = min(v, __shfl_xor(v, 16, 64));
-    if (lg >= 6) v = min(v, __shfl_xor(v, 32, 64));
-    return v;
-}
-__device__ __forceinline__ uint32_t gmin_u32(uint32_t v, uint32_t lg) {
-    if (lg >= 1) v = min(v, (uint32_t)g_dpp<0xB1>((int32_t)v));
-    if (lg >= 2) v = min(v, (uint32_t)g_dpp<0x4E>((int32_t)v));
-    if (lg >= 3) v = min(v, (uint32_t)g_dpp<0x141>((int32_t)v));
-    if (lg >= 4) v = min(v, (uint32_t)g_dpp<0x140>((int32_t)v));
-    if (lg >= 5) v = min(v, (uint32_t)__shfl_xor((int32_t)v, 16, 64));
-    if (lg >= 6) v = min(v, (uint32_t)__shfl_xor((int32_t)v, 32, 64));
-    return v;
-}
-__device__ __forceinline__ void wave_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
 }  // namespace
 
 __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a, WorkIO io, uint32_t stop_after /* ablation timing only */) {
@@ -111,20 +85,8 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
             uint64_t m = __ballot(start);
             uint32_t ci = C + __popcll(m & ((1ull << lane) - 1));
             if (start) {
-                uint32_t l, cp;
-                if (b < 0x80) { l = 1; cp = b; }
-                else if (b >= 0xC2 && b <= 0xDF) { l = 2; cp = b & 0x1F; }
-                else if ((b & 0xF0) == 0xE0) { l = 3; cp = b & 0x0F; }
-                else if (b >= 0xF0 && b <= 0xF4) { l = 4; cp = b & 0x07; }
-                else { l = 1; cp = 0; bad = 1; }
-                if (k + l > B) { bad = 1; l = 1; }
-                for (uint32_t j = 1; j < l; ++j) {
-                    uint32_t bb = text[k + j];
-                    if ((bb & 0xC0) != 0x80) bad = 1;
-                    cp = (cp << 6) | (bb & 0x3F);
-                }
-                if (l == 3 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) bad = 1;
-                if (l == 4 && (cp < 0x10000 || cp > 0x10FFFF)) bad = 1;
+                uint32_t cp;
+                const uint32_t l = utf8_decode_lead(b, k, B, [&](uint32_t kk) -> uint32_t { return text[kk]; }, cp, bad);
                 lensum += l;
                 cbyte[ci] = k;
                 uint32_t code = cp < 0xFFFFu ? cp : 0xFFFFu;
@@ -317,8 +279,8 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
                         const int32_t v = (int32_t)e.x + (int32_t)col[e.y];
                         if (v < best || (v == best && e.z < bidx)) { best = v; bidx = e.z; }
                     }
-                    const int32_t vmin = gmin_i32(best, 6);
-                    const uint32_t nmin = gmin_u32(best == vmin ? bidx : NONE, 6);
+                    const int32_t vmin = wave_min_i32(best);
+                    const uint32_t nmin = wave_min_u32(best == vmin ? bidx : NONE);
                     if (lane == 0) {
                         const int32_t tot = vmin + (int32_t)na_.y;  // min(.., INF) then strict '<' INF
                         const bool ok = tot < INF;

@@ -68,26 +68,6 @@ __device__ __forceinline__ uint64_t dpp_min_step(uint64_t k) {
     const uint64_t o = ((uint64_t)oh << 32) | ol;
     return o < k ? o : k;
 }
-// 32-bit group minima for the straight-line sweep shapes: one DPP-fused v_min per step.  (Exec is
-// full wherever these run -- wave-uniform control flow -- so bound_ctrl never substitutes a zero.)
-template <int CTRL>
-__device__ __forceinline__ int32_t dpp_i32(int32_t x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
-template <uint32_t LG>
-__device__ __forceinline__ int32_t group_min_i32(int32_t v) {
-    if constexpr (LG >= 1) v = min(v, dpp_i32<0xB1>(v));
-    if constexpr (LG >= 2) v = min(v, dpp_i32<0x4E>(v));
-    if constexpr (LG >= 3) v = min(v, dpp_i32<0x141>(v));
-    if constexpr (LG >= 4) v = min(v, dpp_i32<0x140>(v));
-    return v;
-}
-template <uint32_t LG>
-__device__ __forceinline__ uint32_t group_min_u32(uint32_t v) {
-    if constexpr (LG >= 1) v = min(v, (uint32_t)dpp_i32<0xB1>((int32_t)v));
-    if constexpr (LG >= 2) v = min(v, (uint32_t)dpp_i32<0x4E>((int32_t)v));
-    if constexpr (LG >= 3) v = min(v, (uint32_t)dpp_i32<0x141>((int32_t)v));
-    if constexpr (LG >= 4) v = min(v, (uint32_t)dpp_i32<0x140>((int32_t)v));
-    return v;
-}
 __device__ __forceinline__ uint64_t shfl_min_step(uint64_t k, int d) {
     const uint32_t oh = (uint32_t)__shfl_xor((int)(uint32_t)(k >> 32), d, 64);
     const uint32_t ol = (uint32_t)__shfl_xor((int)(uint32_t)k, d, 64);
@@ -105,22 +85,6 @@ __device__ __forceinline__ uint64_t group_min(uint64_t k, uint32_t lg) {  // lg 
 }
 
 __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }
-
-// LDS access by absolute 32-bit LDS address (the sweep keeps ready-made addresses in its descriptors; going through
-// `pool + offset` makes the compiler add the array's link-time base -- zero -- to every address, on the VALU)
-#define KGPU_LDS(T) __attribute__((address_space(3))) T
-template <class T> __device__ __forceinline__ T lds_ld(uint32_t addr) { return *(const KGPU_LDS(T) *)(uintptr_t)addr; }
-template <class T> __device__ __forceinline__ void lds_st(uint32_t addr, T v) { *(KGPU_LDS(T) *)(uintptr_t)addr = v; }
-__device__ __forceinline__ uint2 lds_ld2(uint32_t addr) { const uint64_t v = lds_ld<uint64_t>(addr); return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); }
-
-// Wavefront-level ordering point.  LDS executes one wavefront's instructions in issue order, so
-// data written by one lane is visible to the others at the next instruction; this only stops the
-// compiler from moving LDS accesses across it (no s_barrier: the workgroup's wavefronts are
-// independent, and no vmcnt wait: global loads in flight stay in flight).
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 
 // ---- LDS page pool: 64 pages, bit i of *bm set = page i taken ---------------------------------
 #ifdef KGPU_STEP_TIMING
@@ -304,20 +268,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             const uint64_t m = __ballot(start);
             const uint32_t ci = cb + __popcll(m & ((1ull << lane) - 1));
             if (start) {
-                uint32_t l, cp;
-                if (b < 0x80) { l = 1; cp = b; }
-                else if (b >= 0xC2 && b <= 0xDF) { l = 2; cp = b & 0x1F; }
-                else if ((b & 0xF0) == 0xE0) { l = 3; cp = b & 0x0F; }
-                else if (b >= 0xF0 && b <= 0xF4) { l = 4; cp = b & 0x07; }
-                else { l = 1; cp = 0; bad = 1; }
-                if (k + l > B) { bad = 1; l = 1; }
-                for (uint32_t j = 1; j < l; ++j) {
-                    const uint32_t bb = text[k + j];
-                    if ((bb & 0xC0) != 0x80) bad = 1;
-                    cp = (cp << 6) | (bb & 0x3F);
-                }
-                if (l == 3 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) bad = 1;
-                if (l == 4 && (cp < 0x10000 || cp > 0x10FFFF)) bad = 1;
+                uint32_t cp;
+                const uint32_t l = utf8_decode_lead(b, k, B, [&](uint32_t kk) -> uint32_t { return text[kk]; }, cp, bad);
                 lensum += l;
                 cbyte[ci] = (uint16_t)k;
                 cp16[ci] = (uint16_t)(cp < 0xFFFFu ? cp : 0xFFFFu);
@@ -518,8 +470,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         // busiest position), its slot in the bucket of the position it ends at.  The order inside a bucket is free:
         // the sweep breaks ties on the node index it carries.
         // (with the tiled matrix the bucket carries the right id as its tile offset, (r >> 3) * 64 + (r & 7): the gather adds it as is)
-        const bool tiled = d.conn_tiled != nullptr;
-        auto rword = [&](uint32_t r) { return tiled ? ((r >> 3) << 6) | (r & 7u) : r; };
+        auto rword = [&](uint32_t r) { return conn_rword(d, r); };
         for (uint32_t t0 = 1; t0 < N - 1; t0 += 256) {  // four nodes per lane: the four record gathers are in flight together
             uint32_t tt[4], ee[4];
             Morph8 mm[4];
@@ -580,43 +531,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                 const uint32_t p0 = boff[q], P = boff[q + 1] - p0;
                 const uint32_t ti = t - nb[q];
                 const uint32_t base = ebase[q] - eb0 + ti * P;  // pair (ti, j) lives at ti*P + j
-                const uint32_t L = nLeft[t];
-                const int16_t *col = d.conn_tiled ? d.conn_tiled + ((size_t)(L >> 3) * d.conn_rt64 + (L & 7u) * 8u) : d.conn + (size_t)d.conn_rows * L;
-                for (uint32_t j = 0; j < P; j += 8) {  // two groups of four per round, the second only where the row goes on
-                    const uint32_t j1 = min(j + 1, P - 1), j2 = min(j + 2, P - 1), j3 = min(j + 3, P - 1);
-                    const bool more = j + 4 < P;
-                    const uint32_t j4 = j + 4, j5 = min(j + 5, P - 1), j6 = min(j + 6, P - 1), j7 = min(j + 7, P - 1);
-                    const uint32_t r0 = bk[p0 + j].y & 0xFFFFu, r1 = bk[p0 + j1].y & 0xFFFFu;
-                    const uint32_t r2 = bk[p0 + j2].y & 0xFFFFu, r3 = bk[p0 + j3].y & 0xFFFFu;
-                    uint32_t r4 = 0, r5 = 0, r6 = 0, r7 = 0;
-                    if (more) { r4 = bk[p0 + j4].y & 0xFFFFu; r5 = bk[p0 + j5].y & 0xFFFFu; r6 = bk[p0 + j6].y & 0xFFFFu; r7 = bk[p0 + j7].y & 0xFFFFu; }
-                    const int16_t c0 = col[r0], c1 = col[r1], c2 = col[r2], c3 = col[r3];
-                    int16_t c4 = 0, c5 = 0, c6 = 0, c7 = 0;
-                    if (more) { c4 = col[r4]; c5 = col[r5]; c6 = col[r6]; c7 = col[r7]; }
-                    mpair[base + j] = c0; mpair[base + j1] = c1; mpair[base + j2] = c2; mpair[base + j3] = c3;
-                    if (more) { mpair[base + j4] = c4; mpair[base + j5] = c5; mpair[base + j6] = c6; mpair[base + j7] = c7; }
-                }
+                gather_target_row(bk + p0, P, conn_row(d, nLeft[t]), mpair + base);
             }
             wave_sync();
             if (prof) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
             if (stop_after == 6) { qa = qb; continue; }  // ablation timing: every block's gather, no sweep (the KGPU_STOP(6) below then ends the sentence)
 
-            // -- 4: Viterbi sweep over the block (lattice.rs:116-142), LDS only.
-            // One dependent chain per position: what a step costs is that chain and its taken branches, not its
-            // arithmetic (measured on one wavefront alone: LDS write -> read 86 cycles, three dependent DPP minima 43,
-            // a taken branch 32, an exec-masked block 64, descriptor read-out + scalar dispatch 52 -- tools/ubench).  So:
-            //  * per-position descriptors are ready-made LDS byte addresses, one position per lane for 64 positions at a
-            //    time, broadcast with v_readlane (no LDS round trip, no wait);
-            //  * ONE straight-line body serves 97.7 % of the positions (P <= 16; a second instantiation P <= 32): pair
-            //    (ti, j) sits on lane ti * G + j and again as (ti, j + G), G = 8 lanes per target, eight targets per pass
-            //    (one pass for nine positions in ten);
-            //  * every load is unconditional and unclamped (an index past the arrays reads someone else's LDS or zero,
-            //    and is deselected afterwards), an absent candidate is a total no real one reaches (real <= INF + 32767)
-            //    that still cannot overflow when the word cost is added -- so P = 0 ("nothing ends here") needs no case;
-            //  * there is no exec-masked region: after the butterfly every lane of a group holds the group's result, so all
-            //    of them store the same value to the same address; the groups beyond T store to a sink;
-            //  * two DPP group minima: the total, then the node index among the ties (strict '<' over ascending insertion
-            //    order, lattice.rs:125,136).
+            // -- 4: Viterbi sweep over the block (lattice.rs:116-142), LDS only: one dependent chain per position.  The step itself -- descriptors as
+            // ready-made LDS addresses broadcast with v_readlane, three straight-line bodies, two DPP group minima -- is sweep_position_fast (kgpu_device.h).
             KGPU_TM(const uint64_t tm_s0 = __builtin_amdgcn_s_memtime();)
             const uint32_t lds0 = (uint32_t)(uintptr_t)(KGPU_LDS(uint8_t) *)pool;  // absolute LDS addresses, wave-uniform: SGPRs
             const uint32_t a_ncs = bcast32(lds0 + (uint32_t)((uint8_t *)nCS - pool)), a_bk = bcast32(lds0 + (uint32_t)((uint8_t *)bk - pool));
@@ -631,7 +553,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                     dT = nb1 - dt0;
                     dP = boff[ql + 1] - dp0;
                     const bool fastq = dP <= 32 && dT - 1u < 127u;  // 1 <= T <= 127, P <= 32
-                    d0 = (a_ncs + 4 * dt0) | (fastq ? (dT << 18) | (dP << 25) : 1u << 31);
+                    d0 = sweep_desc0(a_ncs, dt0, dT, dP, fastq);
                     d1 = a_bk + 8 * dp0;
                     d2 = a_mp + 2 * deb;
                 }
@@ -641,54 +563,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                     const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)r);
                     const uint32_t D2 = (uint32_t)__builtin_amdgcn_readlane((int)d2, (int)r);
                     if (!(D0 >> 31)) {
-                        const uint32_t acs = D0 & 0x3FFFFu, T = (D0 >> 18) & 127u, P = D0 >> 25;
-                        const uint32_t apre = a_pre + ((acs - a_ncs) >> 1);  // pre[t0]
-                        // (target groups past T redo target T - 1: same loads, same result, same stores -- no sink, no select)
-                        auto pass = [&](auto LGc, uint32_t tb) {
-                            constexpr uint32_t LG = decltype(LGc)::value, G = 1u << LG;
-                            const uint32_t j = lane & (G - 1u), ti = min(tb + (lane >> LG), T - 1u);
-                            const bool j0v = j < P, j1v = j + G < P;
-                            const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
-                            const uint2 e0 = lds_ld2(D1 + 8 * j), e1 = lds_ld2(D1 + 8 * j + 8 * G);
-                            const uint32_t am = D2 + 2 * (__umul24(ti, P) + j);
-                            const int32_t pc0 = lds_ld<int16_t>(am), pc1 = lds_ld<int16_t>(am + 2 * G);
-                            __builtin_amdgcn_sched_barrier(0);  // the five reads stay one round trip
-                            constexpr int32_t ABSENT = 0x7FFEFFFF;
-                            const int32_t v0 = j0v ? (int32_t)e0.x + pc0 : ABSENT;
-                            const int32_t v1 = j1v ? (int32_t)e1.x + pc1 : ABSENT;
-                            const int32_t vmin = group_min_i32<LG>(min(v0, v1));
-                            // ties: the smallest node index wins; it sits in the upper half of the word (the right id below it is along for the ride)
-                            const uint32_t n0 = v0 == vmin ? e0.y : 0xFFFFFFFFu, n1 = v1 == vmin ? e1.y : 0xFFFFFFFFu;
-                            const uint32_t nmin = group_min_u32<LG>(min(n0, n1));
-                            const int32_t tot = vmin + (int32_t)(int16_t)cs;
-                            const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
-                            lds_st<uint16_t>(apre + 2 * ti, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
-                            lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
-                        };
-                        auto pass1 = [&](uint32_t tb) {  // P <= 8 (87 % of the positions): one candidate per lane
-                            const uint32_t j = lane & 7u, ti = min(tb + (lane >> 3), T - 1u);
-                            const bool j0v = j < P;
-                            const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
-                            const uint2 e0 = lds_ld2(D1 + 8 * j);
-                            const int32_t pc0 = lds_ld<int16_t>(D2 + 2 * (__umul24(ti, P) + j));
-                            __builtin_amdgcn_sched_barrier(0);
-                            const int32_t v0 = j0v ? (int32_t)e0.x + pc0 : 0x7FFEFFFF;  // absent: see below
-                            const int32_t vmin = group_min_i32<3>(v0);
-                            const uint32_t nmin = group_min_u32<3>(v0 == vmin ? e0.y : 0xFFFFFFFFu);
-                            const int32_t tot = vmin + (int32_t)(int16_t)cs;
-                            const bool ok = tot < INF;
-                            lds_st<uint16_t>(apre + 2 * ti, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
-                            lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
-                        };
-                        if (P <= 8) {
-                            pass1(0u);
-                            if (T > 8) for (uint32_t tb = 8; tb < T; tb += 8) pass1(tb);
-                        } else if (P <= 16) {
-                            pass(std::integral_constant<uint32_t, 3>{}, 0u);
-                            if (T > 8) for (uint32_t tb = 8; tb < T; tb += 8) pass(std::integral_constant<uint32_t, 3>{}, tb);
-                        } else {
-                            for (uint32_t tb = 0; tb < T; tb += 4) pass(std::integral_constant<uint32_t, 4>{}, tb);
-                        }
+                        sweep_position_fast(lane, D0, D1, D2, a_ncs, a_pre, a_bk);   // kgpu_device.h: the step both LDS kernels share
                     } else {
                         KGPU_TM(tmSlowSteps += 1; const uint64_t tm_sl0 = __builtin_amdgcn_s_memtime();)
                         const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)dT, (int)r);

@@ -22,8 +22,6 @@
 // positions long, a FIFO-order violation by a dictionary word longer than a window, node indices beyond the 16-bit window of the tie-break)
 // it pushes onto the next launch's work list: the general kernel (kgpu_kernels.hip), the last resort.  Without a list to hand on to it
 // flags Control::window_fail and the host reruns the batch through the general kernel.
-#include <type_traits>
-
 #include "kgpu_device.h"
 
 namespace kgpu {
@@ -51,47 +49,13 @@ constexpr uint32_t NCH_LOG = 13, NCHUNKS = 32;   // node records: chunks of 8192
 constexpr uint32_t FCH_LOG = 12, FCHUNKS = 16;   // far entries: chunks of 4096 (64 KB), at most 65536 waiting at once
 constexpr uint32_t WIDE_MIN = 96;          // FIFO entries at one end position from which they are streamed instead of staged in LDS
 constexpr uint32_t NONE16 = 0xFFFFu;
+constexpr uint32_t SLOWT = 8;               // targets relaxed together on the any-shape path (registers: a 64-bit key and a row pointer each)
 constexpr uint32_t PAIR_MIN = 1024;        // bytes of pair table a window wants beyond its largest position
 
 struct Far { uint32_t end; int32_t dp; uint32_t right; uint32_t node; };          // a bucket entry that outlives its window (16 B)
 struct NodeRec { int32_t sid; uint32_t start; };   // what the tokens need (8 B); the best predecessor lives in a dense array of its own (the backtrace reads every node's)
 
-template <int CTRL>
-__device__ __forceinline__ int32_t w_dpp(int32_t x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
-template <uint32_t LG>
-__device__ __forceinline__ int32_t wmin_i32(int32_t v) {
-    if constexpr (LG >= 1) v = min(v, w_dpp<0xB1>(v));
-    if constexpr (LG >= 2) v = min(v, w_dpp<0x4E>(v));
-    if constexpr (LG >= 3) v = min(v, w_dpp<0x141>(v));
-    if constexpr (LG >= 4) v = min(v, w_dpp<0x140>(v));
-    return v;
-}
-template <uint32_t LG>
-__device__ __forceinline__ uint32_t wmin_u32(uint32_t v) {
-    if constexpr (LG >= 1) v = min(v, (uint32_t)w_dpp<0xB1>((int32_t)v));
-    if constexpr (LG >= 2) v = min(v, (uint32_t)w_dpp<0x4E>((int32_t)v));
-    if constexpr (LG >= 3) v = min(v, (uint32_t)w_dpp<0x141>((int32_t)v));
-    if constexpr (LG >= 4) v = min(v, (uint32_t)w_dpp<0x140>((int32_t)v));
-    return v;
-}
-__device__ __forceinline__ uint64_t wmin_u64_all(uint64_t k) {  // over the 64 lanes
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        const uint32_t oh = (uint32_t)__shfl_xor((int)(uint32_t)(k >> 32), d, 64), ol = (uint32_t)__shfl_xor((int)(uint32_t)k, d, 64);
-        const uint64_t o = ((uint64_t)oh << 32) | ol;
-        k = o < k ? o : k;
-    }
-    return k;
-}
 __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }
-#define KW_LDS(T) __attribute__((address_space(3))) T
-template <class T> __device__ __forceinline__ T lds_ld(uint32_t addr) { return *(const KW_LDS(T) *)(uintptr_t)addr; }
-template <class T> __device__ __forceinline__ void lds_st(uint32_t addr, T v) { *(KW_LDS(T) *)(uintptr_t)addr = v; }
-__device__ __forceinline__ uint2 lds_ld2(uint32_t addr) { const uint64_t v = lds_ld<uint64_t>(addr); return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); }
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 
 // The double-array walk of da_walk_first (kgpu_device.h; trie/da.rs:155-182) with the text read through `byte(k)`.
 template <class BY, class F>
@@ -150,8 +114,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
     const uint32_t lds_bytes = kargs->lds_bytes;
     const uint32_t lane = threadIdx.x;
     const int32_t base_root = d.da[1].base;
-    const bool tiled = d.conn_tiled != nullptr;
-    auto rword = [&](uint32_t r) { return tiled ? ((r >> 3) << 6) | (r & 7u) : r; };
+    auto rword = [&](uint32_t r) { return conn_rword(d, r); };
     Slab sa{nullptr, 0};
     uint64_t accW[7] = {0, 0, 0, 0, 0, 0, 0};
     uint64_t tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // shader clocks per phase (only summed when a.count_work): prepass, stage, seeds, walk, scan, emit, gather, sweep, flush, backtrace+tokens
@@ -269,20 +232,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                     ci[u] = C + __popcll(m & ((1ull << lane) - 1));
                     st[u] = start; kk[u] = k; cpx[u] = 0;
                     if (start) {
-                        uint32_t l, cp;
-                        if (b < 0x80) { l = 1; cp = b; }
-                        else if (b >= 0xC2 && b <= 0xDF) { l = 2; cp = b & 0x1F; }
-                        else if ((b & 0xF0) == 0xE0) { l = 3; cp = b & 0x0F; }
-                        else if (b >= 0xF0 && b <= 0xF4) { l = 4; cp = b & 0x07; }
-                        else { l = 1; cp = 0; bad = 1; }
-                        if (k + l > B) { bad = 1; l = 1; }
-                        for (uint32_t j = 1; j < l; ++j) {
-                            const uint32_t bb = ltext[r + j];
-                            if ((bb & 0xC0) != 0x80) bad = 1;
-                            cp = (cp << 6) | (bb & 0x3F);
-                        }
-                        if (l == 3 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) bad = 1;
-                        if (l == 4 && (cp < 0x10000 || cp > 0x10FFFF)) bad = 1;
+                        uint32_t cp;
+                        const uint32_t l = utf8_decode_lead(b, k, B, [&](uint32_t kk) -> uint32_t { return ltext[kk - k0]; }, cp, bad);
                         lensum += l;
                         cpx[u] = cp;
                     }
@@ -629,7 +580,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
             KW_T(5);
             KW_ARGS();
             // -- gather + sweep, block by block (the pool kernel's step: kgpu_pool.hip)
-            const uint32_t lds0 = (uint32_t)(uintptr_t)(KW_LDS(uint8_t) *)lds;
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(KGPU_LDS(uint8_t) *)lds;
             const uint32_t a_ncs = bcast32(lds0 + (uint32_t)((uint8_t *)nCS - lds)), a_bk = bcast32(lds0 + (uint32_t)((uint8_t *)bk - lds));
             const uint32_t a_mp = bcast32(lds0 + (uint32_t)((uint8_t *)mpair - lds)), a_pre = bcast32(lds0 + (uint32_t)((uint8_t *)pre - lds));
             uint32_t qa = 0;
@@ -647,21 +598,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                     const uint32_t p0 = boff[q], P = boff[q + 1] - p0;
                     const uint32_t ti = t - nb[q];
                     const uint32_t base = ebase[q] - eb0 + ti * P;
-                    const uint32_t L = nLeft[t];
-                    const int16_t *col = tiled ? d.conn_tiled + ((size_t)(L >> 3) * d.conn_rt64 + (L & 7u) * 8u) : d.conn + (size_t)d.conn_rows * L;
-                    for (uint32_t j = 0; j < P; j += 8) {
-                        const uint32_t j1 = min(j + 1, P - 1), j2 = min(j + 2, P - 1), j3 = min(j + 3, P - 1);
-                        const bool more = j + 4 < P;
-                        const uint32_t j4 = j + 4, j5 = min(j + 5, P - 1), j6 = min(j + 6, P - 1), j7 = min(j + 7, P - 1);
-                        const uint32_t r0 = bk[p0 + j].y & 0xFFFFu, r1 = bk[p0 + j1].y & 0xFFFFu, r2 = bk[p0 + j2].y & 0xFFFFu, r3 = bk[p0 + j3].y & 0xFFFFu;
-                        uint32_t r4 = 0, r5 = 0, r6 = 0, r7 = 0;
-                        if (more) { r4 = bk[p0 + j4].y & 0xFFFFu; r5 = bk[p0 + j5].y & 0xFFFFu; r6 = bk[p0 + j6].y & 0xFFFFu; r7 = bk[p0 + j7].y & 0xFFFFu; }
-                        const int16_t c0 = col[r0], c1 = col[r1], c2 = col[r2], c3 = col[r3];
-                        int16_t c4 = 0, c5 = 0, c6 = 0, c7 = 0;
-                        if (more) { c4 = col[r4]; c5 = col[r5]; c6 = col[r6]; c7 = col[r7]; }
-                        mpair[base + j] = c0; mpair[base + j1] = c1; mpair[base + j2] = c2; mpair[base + j3] = c3;
-                        if (more) { mpair[base + j4] = c4; mpair[base + j5] = c5; mpair[base + j6] = c6; mpair[base + j7] = c7; }
-                    }
+                    gather_target_row(bk + p0, P, conn_row(d, nLeft[t]), mpair + base);
                 }
                 wave_sync();
                 KW_T(6);
@@ -674,7 +611,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                         dP = boff[ql + 1] - dp0;
                         const uint32_t wn_l = wideN[ql];
                         const bool fastq = dP <= 32 && dT - 1u < 127u && wn_l == 0;
-                        d0 = (a_ncs + 4 * dt0) | (fastq ? (dT << 18) | (dP << 25) : 1u << 31);
+                        d0 = sweep_desc0(a_ncs, dt0, dT, dP, fastq);
                         d1 = a_bk + 8 * dp0;
                         d2 = a_mp + 2 * deb;
                         if (dP == 0 && wn_l == 0) {   // nothing ends here (lattice.rs:121-140 with an empty edges[pos]): its targets stay at INF (set by emit) with no
@@ -688,52 +625,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                         const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)r);
                         const uint32_t D2 = (uint32_t)__builtin_amdgcn_readlane((int)d2, (int)r);
                         if (!(D0 >> 31)) {
-                            const uint32_t acs = D0 & 0x3FFFFu, T = (D0 >> 18) & 127u, P = D0 >> 25;
-                            const uint32_t apre = a_pre + ((acs - a_ncs) >> 1);
-                            auto pass = [&](auto LGc, uint32_t tbb) {
-                                constexpr uint32_t LG = decltype(LGc)::value, G = 1u << LG;
-                                const uint32_t j = lane & (G - 1u), ti = min(tbb + (lane >> LG), T - 1u);
-                                const bool j0v = j < P, j1v = j + G < P;
-                                const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
-                                const uint2 e0 = lds_ld2(D1 + 8 * j), e1 = lds_ld2(D1 + 8 * j + 8 * G);
-                                const uint32_t am = D2 + 2 * (__umul24(ti, P) + j);
-                                const int32_t pc0 = lds_ld<int16_t>(am), pc1 = lds_ld<int16_t>(am + 2 * G);
-                                __builtin_amdgcn_sched_barrier(0);
-                                constexpr int32_t ABSENT = 0x7FFEFFFF;
-                                const int32_t v0 = j0v ? (int32_t)e0.x + pc0 : ABSENT;
-                                const int32_t v1 = j1v ? (int32_t)e1.x + pc1 : ABSENT;
-                                const int32_t vmin = wmin_i32<LG>(min(v0, v1));
-                                const uint32_t n0 = v0 == vmin ? e0.y : 0xFFFFFFFFu, n1 = v1 == vmin ? e1.y : 0xFFFFFFFFu;
-                                const uint32_t nmin = wmin_u32<LG>(min(n0, n1));
-                                const int32_t tot = vmin + (int32_t)(int16_t)cs;
-                                const bool ok = tot < INF;  // .min(INF) then strict '<' (lattice.rs:135-136)
-                                lds_st<uint16_t>(apre + 2 * ti, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
-                                lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
-                            };
-                            auto pass1 = [&](uint32_t tbb) {  // P <= 8: one candidate per lane
-                                const uint32_t j = lane & 7u, ti = min(tbb + (lane >> 3), T - 1u);
-                                const bool j0v = j < P;
-                                const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
-                                const uint2 e0 = lds_ld2(D1 + 8 * j);
-                                const int32_t pc0 = lds_ld<int16_t>(D2 + 2 * (__umul24(ti, P) + j));
-                                __builtin_amdgcn_sched_barrier(0);
-                                const int32_t v0 = j0v ? (int32_t)e0.x + pc0 : 0x7FFEFFFF;
-                                const int32_t vmin = wmin_i32<3>(v0);
-                                const uint32_t nmin = wmin_u32<3>(v0 == vmin ? e0.y : 0xFFFFFFFFu);
-                                const int32_t tot = vmin + (int32_t)(int16_t)cs;
-                                const bool ok = tot < INF;
-                                lds_st<uint16_t>(apre + 2 * ti, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
-                                lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
-                            };
-                            if (P <= 8) {
-                                pass1(0u);
-                                if (T > 8) for (uint32_t tbb = 8; tbb < T; tbb += 8) pass1(tbb);
-                            } else if (P <= 16) {
-                                pass(std::integral_constant<uint32_t, 3>{}, 0u);
-                                if (T > 8) for (uint32_t tbb = 8; tbb < T; tbb += 8) pass(std::integral_constant<uint32_t, 3>{}, tbb);
-                            } else {
-                                for (uint32_t tbb = 0; tbb < T; tbb += 4) pass(std::integral_constant<uint32_t, 4>{}, tbb);
-                            }
+                            sweep_position_fast(lane, D0, D1, D2, a_ncs, a_pre, a_bk);   // kgpu_device.h: the step both LDS kernels share
                         } else {
                             // any shape, and the streamed (wide) positions: one target at a time, the lanes split its predecessors;
                             // key = (total, node index) -- strict '<' over ascending insertion order (lattice.rs:125,136)
@@ -743,21 +635,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                             const uint32_t p0 = (D1 - a_bk) >> 3, eb = (D2 - a_mp) >> 1;
                             const uint32_t q = qa + r;
                             const uint32_t wn = wideN[q], wlo = fcnt[q];
-                            for (uint32_t tg = 0; tg < T; tg += 8) {  // eight targets share every load of a predecessor
-                                const uint32_t nt8 = min(8u, T - tg);
-                                uint64_t key[8];
-                                const int16_t *col[8];
+                            for (uint32_t tg = 0; tg < T; tg += SLOWT) {  // SLOWT targets share every load of a predecessor
+                                const uint32_t nt8 = min(SLOWT, T - tg);
+                                uint64_t key[SLOWT];
+                                const int16_t *col[SLOWT];
 #pragma unroll
-                                for (int k = 0; k < 8; ++k) {
+                                for (int k = 0; k < (int)SLOWT; ++k) {
                                     key[k] = ~0ull;
                                     const uint32_t L = nLeft[t0 + tg + min((uint32_t)k, nt8 - 1)];
-                                    col[k] = tiled ? d.conn_tiled + ((size_t)(L >> 3) * d.conn_rt64 + (L & 7u) * 8u) : d.conn + (size_t)d.conn_rows * L;
+                                    col[k] = conn_row(d, L);
                                 }
                                 for (uint32_t jj = lane; jj < P; jj += 64) {
                                     const uint2 e = bk[p0 + jj];
                                     const uint32_t gi = rb + (e.y >> 16);
 #pragma unroll
-                                    for (int k = 0; k < 8; ++k)
+                                    for (int k = 0; k < (int)SLOWT; ++k)
                                         if ((uint32_t)k < nt8) {
                                             const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + (tg + k) * P + jj];
                                             const uint64_t ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | gi;
@@ -767,11 +659,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                                 for (uint32_t f = wlo + lane; f < wlo + wn; f += 64) {
                                     const Far e = *far_rec(f);
                                     const uint32_t r = e.right & 0xFFFFu;
-                                    int32_t cc[8];
+                                    int32_t cc[SLOWT];
 #pragma unroll
-                                    for (int k = 0; k < 8; ++k) cc[k] = (uint32_t)k < nt8 ? (int32_t)col[k][r] : 0;
+                                    for (int k = 0; k < (int)SLOWT; ++k) cc[k] = (uint32_t)k < nt8 ? (int32_t)col[k][r] : 0;
 #pragma unroll
-                                    for (int k = 0; k < 8; ++k)
+                                    for (int k = 0; k < (int)SLOWT; ++k)
                                         if ((uint32_t)k < nt8) {
                                             const int32_t v = e.dp + cc[k];
                                             const uint64_t ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | e.node;
@@ -779,9 +671,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                                         }
                                 }
 #pragma unroll
-                                for (int k = 0; k < 8; ++k)
+                                for (int k = 0; k < (int)SLOWT; ++k)
                                     if ((uint32_t)k < nt8) {
-                                        const uint64_t kk = wmin_u64_all(key[k]);
+                                        const uint64_t kk = wave_min_u64(key[k]);
                                         if (lane == 0) {
                                             const uint32_t cs = nCS[t0 + tg + k];
                                             int32_t dpv = INF; uint32_t prv = NONE16;
