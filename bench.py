@@ -416,6 +416,151 @@ def measure_config(tok, dev, wl, n_chars, passes, queue, streams, label, orc=Non
     }
 
 
+# ------------------------------------------------------------------ one process, several devices (the C ABI's own multi-device entry)
+
+def run_single_process(args):
+    """bench.py --gpus N --single-process [--devices 0,1,...]: cfg 4 through kgpu_multi_* -- ONE process, no torch.distributed: sentence i -> entry
+    i mod N, every entry's shard resident on its device, the compaction kernels store the 8-byte records straight into the ROOT device's memory over
+    xGMI (peer access): the stores are the gather.  torch is used for device memory only.  The same entry may name one device several times
+    (--devices 0,0: the path's self-test on one GPU).  Prints the same line fields as the torch.distributed path."""
+    import ctypes as C
+
+    import torch
+
+    from kanpyo_amd import Tokenizer, _lib, synth
+    from kanpyo_amd.dist import reassemble
+    from kanpyo_amd.tokenizer import TOKEN_DTYPE, pack_sentences
+
+    G, K, W, Q = args.gpus, args.steps, args.warmup, args.queue
+    ndev = torch.cuda.device_count()
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else [g % max(ndev, 1) for g in range(G)]
+    assert len(devices) == G and all(0 <= d < ndev for d in devices), (devices, ndev)
+    L = _lib.lib()
+    sd = synth.build_dict()
+    ncorp = max(1, min(args.corpora if args.corpora > 0 else 100, 100, max(K, 1)))
+    corpora = [synth.make_corpus(sd, N_SENT, seed=100 + k, kind="cfg2") for k in range(ncorp)]
+    toks = {}
+    for d in devices:  # one dictionary handle per distinct device
+        if d not in toks:
+            toks[d] = Tokenizer(sd.dict, device=d)
+    handles = (C.c_void_p * G)(*[toks[d].handle for d in devices])
+    mh = C.c_void_p()
+    _lib.check(L.kgpu_multi_create(handles, G, Q, C.byref(mh)))
+    root = torch.device("cuda", devices[0])
+    # inputs: per corpus, per entry, per batch -- resident on the entry's device
+    wls = [Workload(corpora, g, G) for g in range(G)]
+    nb = max(w.nb(0) for w in wls)
+    cap = max(w.cap() for w in wls)
+    inputs = []  # [corpus][b][g] = (utf8, offsets, n, total)
+    for ci in range(ncorp):
+        per_b = []
+        for b in range(nb):
+            row = []
+            for g in range(G):
+                dev = torch.device("cuda", devices[g])
+                if b < len(wls[g].packed[ci]):
+                    u, o = wls[g].packed[ci][b]
+                else:
+                    u, o = np.zeros(0, np.uint8), np.zeros(1, np.uint64)
+                row.append((torch.from_numpy(np.ascontiguousarray(u)).to(dev) if u.size else torch.zeros(16, dtype=torch.uint8, device=dev),
+                            torch.from_numpy(o.astype(np.int64)).to(dev), len(o) - 1, int(o[-1])))
+            per_b.append(row)
+        inputs.append(per_b)
+    outs = [[dict(t8=torch.empty((cap, 2), dtype=torch.int32, device=root), first=torch.empty(2 * BATCH + 2, dtype=torch.int32, device=root),
+                  toff=torch.empty(BATCH + 1, dtype=torch.int64, device=root), st=torch.empty(BATCH + 16, dtype=torch.uint8, device=root)) for _ in range(G)]
+            for _ in range(Q)]
+    ptrs = lambda rows, k: (C.c_void_p * G)(*[r[k].data_ptr() for r in rows])
+    u64s = lambda vals: (C.c_uint64 * G)(*vals)
+    pending = [None] * Q
+    got = (C.c_uint64 * G)()
+    tokens_total = [0]
+
+    def retire(slot):
+        if pending[slot] is not None:
+            _lib.check(L.kgpu_multi_sync(mh, slot, got))
+            tokens_total[0] += sum(int(x) for x in got)
+            pending[slot] = None
+
+    def job(nsteps, keep=None):
+        k = 0
+        for s_ in range(nsteps):
+            for b in range(nb):
+                slot = k % Q
+                retire(slot)
+                rows = inputs[s_ % ncorp][b]
+                o = outs[slot]
+                _lib.check(L.kgpu_multi_tokenize_device(
+                    mh, slot, (C.c_void_p * G)(*[r[0].data_ptr() for r in rows]), (C.c_void_p * G)(*[r[1].data_ptr() for r in rows]),
+                    u64s([r[2] for r in rows]), u64s([r[3] for r in rows]),
+                    (C.c_void_p * G)(*[x["t8"].data_ptr() for x in o]), u64s([cap] * G), (C.c_void_p * G)(*[x["first"].data_ptr() for x in o]),
+                    (C.c_void_p * G)(*[x["toff"].data_ptr() for x in o]), (C.c_void_p * G)(*[x["st"].data_ptr() for x in o])))
+                pending[slot] = (s_, b)
+                if keep is not None:  # the untimed check wants every batch's records: retire at once and copy them out
+                    retire(slot)
+                    keep.append([(x["t8"][: int(got[g])].cpu().numpy().copy(), x["first"][: 2 * rows[g][2]].cpu().numpy().copy(),
+                                  x["toff"][: rows[g][2] + 1].cpu().numpy().copy()) for g, x in enumerate(o)])
+                k += 1
+        for slot in range(Q):
+            retire(slot)
+
+    # ---- untimed: one step gathered, expanded and reassembled == the same corpus tokenized on the root device alone
+    kept = []
+    job(1, keep=kept)
+    toks24 = [[] for _ in range(G)]
+    cnts = [[] for _ in range(G)]
+    for batch_rows in kept:
+        for g, (t8, first, toff) in enumerate(batch_rows):
+            n_g = len(toff) - 1
+            out = np.empty(len(t8), dtype=TOKEN_DTYPE)
+            toff_u = toff.astype(np.uint64)
+            L.kgpu_expand_tokens(np.ascontiguousarray(t8).ctypes.data, toff_u.ctypes.data, np.ascontiguousarray(first.astype(np.uint32)).ctypes.data, n_g, out.ctypes.data)
+            toks24[g].append(out.view(np.int32).reshape(-1, 6))
+            cnts[g].append(np.diff(toff).astype(np.int64))
+    g_tok, g_off = reassemble(np.concatenate([np.concatenate(x) if x else np.zeros((0, 6), np.int32) for x in toks24]),
+                              np.concatenate([np.concatenate(x) if x else np.zeros(0, np.int64) for x in cnts]), len(corpora[0]), G)
+    u0, o0 = pack_sentences(corpora[0])
+    one_t, one_off, _ = toks[devices[0]].tokenize_packed(u0, o0)
+    gather_check = bool(np.array_equal(g_off.astype(np.uint64), one_off) and np.array_equal(g_tok.reshape(-1), one_t.view(np.int32).reshape(-1)))
+    assert gather_check, "gathered + reassembled token stream differs from the single-device stream"
+
+    def sync_all():
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm_seconds:
+        job(4)
+    if W > 0:
+        job(W)
+    tokens_total[0] = 0
+    sync_all()
+    t0 = time.perf_counter()
+    job(K)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    sentences = sum(len(corpora[s_ % ncorp]) for s_ in range(K))
+    distinct = len(set(devices))
+    result = {
+        "metric": "sentences/sec", "value": sentences / elapsed, "unit": "sentences/s", "n_gpus": G, "steps": K, "warmup": W,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[3] (cfg 4): 100k-sentence corpora of seeds 100..{99 + ncorp} cycled, sentence i -> entry i mod {G} of ONE process "
+                               f"(kgpu_multi_*: devices {devices}), 8-byte records stored into device {devices[0]}'s memory by the shards' compaction kernels; "
+                               "synthetic IPADIC-shaped dictionary (392k records); batch=4096 per entry; inputs resident in HBM",
+                   "batch": BATCH, "sentences_per_step": N_SENT, "batches_per_step_per_gpu": nb, "batches_in_flight": Q, "devices": devices,
+                   "distinct_devices": distinct, "launcher": "single process (C ABI kgpu_multi_create / kgpu_multi_tokenize_device / kgpu_multi_sync), no torch.distributed",
+                   "sharding": f"sentence i -> entry i mod {G}, dictionary replicated per device, no data-path collective"},
+        "sentences_total": sentences,
+        "gather": {"tokens": tokens_total[0], "sentences": sentences, "complete": True, "reassembled_step_equals_one_gpu": gather_check, "record_bytes": 8,
+                   "records": "kgpu_token8 (8 bytes) + the first token's (position, start) per sentence, written by every shard's compaction kernel into the root "
+                              "device's memory (peer stores over xGMI when the entries are distinct devices); kgpu_expand_tokens restores the 24-byte records where they are consumed",
+                   "root_ingest_GB_per_s": tokens_total[0] * 8 * (distinct - 1) / max(distinct, 1) / elapsed / 1e9},
+        "per_rank": [{"rank": g, "device": devices[g], "sentences": int(sum(wls[g].sentences(s_) for s_ in range(K)))} for g in range(G)],
+        "corpora": {"distinct": ncorp, "seeds": f"100..{99 + ncorp}", "sentences_each": N_SENT},
+    }
+    L.kgpu_multi_destroy(mh)
+    print(json.dumps(result), flush=True)
+
+
 # ------------------------------------------------------------------ main
 
 def main():
@@ -438,7 +583,25 @@ def main():
     ap.add_argument("--gather-records", type=int, default=8, choices=(8, 24), help="N>1: bytes per token record on the wire: 8 = kgpu_token8 (+ the first token's "
                     "position / start per sentence; kgpu_expand_tokens restores the 24-byte records on the consumer's side), 24 = kgpu_token")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path even with one rank (self-test)")
+    ap.add_argument("--single-process", action="store_true", help="--gpus N in ONE process through the C ABI's multi-device entry (kgpu_multi_*), no torch.distributed")
+    ap.add_argument("--devices", default="", help="--single-process: the device of every entry, e.g. 0,0 (default: entry g -> device g)")
     args = ap.parse_args()
+    if args.single_process:
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            import io
+            import contextlib
+
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                run_single_process(args)
+        finally:
+            sys.stdout.flush()
+            os.dup2(real_stdout, 1)
+        print(buf.getvalue().strip().split("\n")[-1], flush=True)
+        return
 
     # stdout carries exactly one JSON line: everything else that libraries print there (RCCL's
     # banner at communicator creation, ...) is routed to stderr until the result is ready

@@ -1603,36 +1603,6 @@ extern "C" void *kgpu_host_alloc(uint64_t bytes) {
 }
 extern "C" void kgpu_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
-// ---- measurement only (tools/anyorder_probe.py; not part of include/kanpyo_gpu.h): `reps` launches of the pool kernel over one
-// batch on the ctx stream with nothing in between, optionally any-order.  Returns the wall milliseconds from first launch to stream idle.
-namespace kgpu { int launch_pool_repeat(const DictView &d, const BatchArgs &a, uint32_t pool_bytes, uint32_t waves, uint32_t max_pages,
-                                        int n_workgroups, int reps, bool any_order, void *stream); }
-extern "C" double kgpu_debug_pool_repeat(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n, uint64_t total_bytes,
-                                         int reps, int any_order) {
-    if (!c || !c->plan.n_pools) return -1.0;
-    if (hipSetDevice(c->dict->device) != hipSuccess) return -1.0;
-    if (c->pending) (void)kgpu_ctx_sync(c, nullptr);
-    if (c->arena.ensure(ARENA_INITIAL) || c->stage.ensure((size_t)(total_bytes + n + 1) * sizeof(kgpu_token) + 64) ||
-        c->tok_count.ensure((size_t)(n + 1) * 4) || c->ovf.ensure((size_t)(n + 1) * 4 * 4) || c->out_status.ensure((size_t)n + 16)) return -1.0;
-    BatchArgs a{};
-    a.utf8 = d_utf8; a.offsets = d_offsets; a.n = n; a.ctl = c->d_ctl;
-    a.arena = (uint8_t *)c->arena.p; a.arena_bytes = c->arena.bytes;
-    a.stage = (kgpu_token *)c->stage.p; a.tok_count = (uint32_t *)c->tok_count.p; a.status = (uint8_t *)c->out_status.p;
-    a.est_q8 = c->dict->est_q8.load(std::memory_order_relaxed);
-    for (int k = 0; k < 4; ++k) a.ovf[k] = (uint32_t *)c->ovf.p + (size_t)k * (n + 1);
-    if (hipMemsetAsync(c->d_ctl, 0, sizeof(Control), c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1.0;
-    c->ctl_dirty = true;
-    uint64_t wg = c->plan.pool_workgroups[0];
-    const uint64_t want = (n + c->plan.pool_waves[0] - 1) / c->plan.pool_waves[0];
-    if (want < wg) wg = want;
-    timespec t0, t1;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    if (launch_pool_repeat(c->dict->view, a, c->plan.pool_bytes[0], c->plan.pool_waves[0], c->plan.pool_max_pages[0], (int)wg, reps, any_order != 0, c->stream)) return -1.0;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1.0;
-    clock_gettime(CLOCK_MONOTONIC, &t1);
-    return (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
-}
-
 // ---- measurement / test only (bench.py's concurrent_callers leg, tests/test_gpu_concurrent.py; not part of include/kanpyo_gpu.h): `threads` host
 // threads call kgpu_tokenize_batch in a loop, thread t with n_pattern[t % n_pat] sentences per call (the reference's shape is 1: src/bin/kanpyo.rs:106-126),
 // walking round the corpus from its own starting point.  With `expect_tokens` / `expect_offsets` (the whole corpus tokenized once, e.g. by the oracle)

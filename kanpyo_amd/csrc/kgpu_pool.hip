@@ -34,8 +34,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include <hip/hip_ext.h>
-
 #include "kgpu_device.h"
 
 namespace kgpu {
@@ -794,26 +792,6 @@ int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const WorkIO &io
     const bool byte_walk = d.da2 == nullptr;
     if (a.count_work) return byte_walk ? launch_pool_inst<true, true>(pa, pool_bytes, waves, n_workgroups, stream) : launch_pool_inst<true, false>(pa, pool_bytes, waves, n_workgroups, stream);
     return byte_walk ? launch_pool_inst<false, true>(pa, pool_bytes, waves, n_workgroups, stream) : launch_pool_inst<false, false>(pa, pool_bytes, waves, n_workgroups, stream);
-}
-
-// Measurement only (tools/anyorder_probe.py): the pool kernel `reps` times over the same batch on one stream, nothing between the
-// launches; any_order: without the barrier bit (hipExtAnyOrderLaunch), so that consecutive launches of ONE stream may overlap.
-int launch_pool_repeat(const DictView &d, const BatchArgs &a, uint32_t pool_bytes, uint32_t waves, uint32_t max_pages,
-                       int n_workgroups, int reps, bool any_order, void *stream) {
-    const WorkIO io{nullptr, nullptr, a.ovf[0], &a.ctl->ovf_count[0], &a.ctl->late_count[0]};
-    if (pool_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
-        if (e != hipSuccess) return (int)e;
-    }
-    if (!d.da2) return (int)hipErrorInvalidValue;  // (probe of the product kernel only)
-    for (int r = 0; r < reps; ++r) {
-        if (any_order)
-            hipExtLaunchKernelGGL((k_tokenize_pool<false, false>), dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, nullptr, nullptr,
-                                  hipExtAnyOrderLaunch, PoolArgs{d, a, io, pool_bytes, max_pages, 0u});
-        else
-            hipLaunchKernelGGL((k_tokenize_pool<false, false>), dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, PoolArgs{d, a, io, pool_bytes, max_pages, 0u});
-    }
-    return (int)hipGetLastError();
 }
 
 }  // namespace kgpu

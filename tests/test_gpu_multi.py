@@ -136,3 +136,23 @@ def test_device_resident_shards_gathered_on_the_root(env):
             assert np.array_equal(g_tok.reshape(-1), exp.tokens.view(np.int32).reshape(-1))
     finally:
         L.kgpu_multi_destroy(mh)
+
+
+def test_bench_single_process_path_on_one_gpu():
+    """bench.py --gpus 2 --single-process --devices 0,0: cfg 4's workload through kgpu_multi_* in one process (no torch.distributed); the line has the
+    multi-rank path's fields, and the run itself asserts that a gathered + expanded + reassembled step equals the single-device token stream."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process", "--devices", "0,0", "--steps", "2", "--warmup", "1",
+                        "--prewarm-seconds", "0.05", "--corpora", "1", "--queue", "4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().split("\n")[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "config", "sentences_total", "gather", "per_rank", "corpora"):
+        assert k in line, k
+    assert line["n_gpus"] == 2 and line["sentences_total"] == 200_000 and line["gather"]["reassembled_step_equals_one_gpu"] is True
+    assert line["value"] > 1e6

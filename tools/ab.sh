@@ -1,7 +1,38 @@
 #!/bin/bash
-# A/B of library builds on the GPU box: bash tools/ab.sh <reps> <lib>...   (bench.py headline value per run, same box, interleaved)
-REPS=$1; shift
-for r in $(seq $REPS); do for lib in "$@"; do
-  v=$(KGPU_LIB=$PWD/kanpyo_amd/$lib timeout 200 python bench.py --no-cpu --no-extras ${BENCH_ARGS:-} 2>/dev/null | python -c "import json,sys; print(round(json.load(sys.stdin)['value']/1e6,2))")
-  echo "$lib $v"
-done; done | sort | awk '{a[$1]=a[$1]" "$2} END {for (k in a) print k":"a[k]}'
+# ONE A/B driver for the GPU box (replaces the ~30 one-off ab_*.sh / cfg3_*.sh / window_*.sh / pool_*.sh scripts of rounds 2-3).
+#
+#   bash tools/ab.sh [-r REPS] [-c COMMAND] VARIANT...
+#
+# A VARIANT is "label" or "label:ENV=val,ENV2=val,..." -- environment settings for one arm (KGPU_LIB=<other build of the library>, KGPU_POOL=40:4:48,
+# KGPU_WINDOW=12, KGPU_STREAMS=..., GPU_MAX_HW_QUEUES=..., BENCH_Q=...).  The arms run interleaved, REPS times each (default 2), on the same box.
+# COMMAND (default: the bench.py headline) is one of
+#   bench                 python bench.py --no-cpu --no-extras             -> M sentences/s (value), redone sentences
+#   cfg3[:n[:batch]]      python tools/bench_cfg.py cfg3 n batch            -> the tool's result line       (defaults 400000, 65536)
+#   cfg5[:n[:batch]]      python tools/bench_cfg.py cfg5 n batch                                            (defaults 1000, 4096)
+#   window:cfg5|cfg3      python tools/window_timing.py ...                 -> rate + shader clocks per character by phase of the windowed kernel
+#   e2e                   python tools/e2e_quick.py                         -> large host call, 4096-sentence calls
+#   callers[:threads]     python tools/concurrent_probe.py threads          -> concurrent small calls
+#   anything else         run as given (quote it)
+# Example (round 4, pool routing limit x windowed-kernel LDS on cfg 3):
+#   bash tools/ab.sh -c cfg3 p40w12:KGPU_POOL=40:4:40,KGPU_WINDOW=12 p48w12:KGPU_POOL=40:4:48,KGPU_WINDOW=12 p48w16:KGPU_POOL=40:4:48,KGPU_WINDOW=16
+REPS=2; CMD=bench
+while getopts "r:c:" o; do case $o in r) REPS=$OPTARG;; c) CMD=$OPTARG;; *) exit 2;; esac; done
+shift $((OPTIND - 1))
+cd "$(dirname "$0")/.."
+IFS=: read -r kind a1 a2 <<< "$CMD"
+case $kind in
+  bench)   run() { timeout 300 python bench.py --no-cpu --no-extras 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print(round(d['value']/1e6,2), 'M sentences/s, redone', d['routing']['redone'][0])"; } ;;
+  cfg3)    run() { timeout 600 python tools/bench_cfg.py cfg3 ${a1:-400000} ${a2:-65536} 2>&1 | grep -v amdgpu.ids | tail -1; } ;;
+  cfg5)    run() { timeout 600 python tools/bench_cfg.py cfg5 ${a1:-1000} ${a2:-4096} 2>&1 | grep -v amdgpu.ids | tail -1; } ;;
+  window)  run() { timeout 600 python tools/window_timing.py ${a1:-cfg5} $([ "${a1:-cfg5}" = cfg3 ] && echo 60000 || echo 1000) 8 2>&1 | grep -v amdgpu.ids | head -2; } ;;
+  e2e)     run() { timeout 600 python tools/e2e_quick.py 2>&1 | grep -v amdgpu.ids; } ;;
+  callers) run() { timeout 600 python tools/concurrent_probe.py ${a1:-1,16,64} 2>&1 | grep -v amdgpu.ids; } ;;
+  *)       run() { timeout 900 bash -c "$CMD" 2>&1 | grep -v amdgpu.ids | tail -3; } ;;
+esac
+export BENCH_Q=${BENCH_Q:-8}
+for r in $(seq "$REPS"); do
+  for v in "$@"; do
+    label=${v%%:*}; envs=""; [ "$v" != "$label" ] && envs=${v#*:}
+    echo "[$label] $(env $(echo "$envs" | tr ',' ' ') bash -c "$(declare -f run); kind=$kind a1=$a1 a2=$a2 CMD='$CMD' run")"
+  done
+done
