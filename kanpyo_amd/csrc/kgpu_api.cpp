@@ -684,6 +684,15 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
             if (rc) { c->pending = false; return rc; }
             continue;
         }
+        {   // KGPU_WINDOW_TRACE=1: why the windowed kernel handed sentences on (Control::phase[1..9] count its reasons in non-profiling runs)
+            static const bool wtrace = env_flag_now("KGPU_WINDOW_TRACE");
+            if (wtrace && c->last_window && !c->last.count_work && c->h_ctl->ovf_count[c->last_pools] > 0) {
+                const unsigned long long *w = c->h_ctl->phase;
+                fprintf(stderr, "windowed kernel: %u of %u sentences handed on (batch of %llu): seeds out of range %llu, prefix overflow %llu, node chunks %llu, FIFO full %llu, "
+                                "FIFO chunks %llu, FIFO order %llu, carry list %llu, window LDS %llu\n", c->h_ctl->ovf_count[c->last_pools], c->last_pools ? c->h_ctl->ovf_count[c->last_pools - 1] : (unsigned)c->last.n,
+                        (unsigned long long)c->last.n, w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
+            }
+        }
         const int li_last = c->last_pools - 1 + (c->last_window ? 1 : 0);   // the list the chain ended on
         if (!c->last_tail && c->last.n && li_last >= 0 && !c->h_ctl->arena_overflow && c->h_ctl->ovf_count[li_last] > 0) {
             // The chain ended without its tail and a sentence needed it: ONLY what is missing (the windowed kernel if it was not in the chain,

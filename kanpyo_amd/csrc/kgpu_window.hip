@@ -49,7 +49,8 @@ constexpr uint32_t NCH_LOG = 13, NCHUNKS = 32;   // node records: chunks of 8192
 constexpr uint32_t FCH_LOG = 12, FCHUNKS = 16;   // far entries: chunks of 4096 (64 KB), at most 65536 waiting at once
 constexpr uint32_t WIDE_MIN = 96;          // FIFO entries at one end position from which they are streamed instead of staged in LDS
 constexpr uint32_t NONE16 = 0xFFFFu;
-constexpr uint32_t SLOWT = 8;               // targets relaxed together on the any-shape path (registers: a 64-bit key and a row pointer each)
+constexpr uint32_t BIGP = 64;               // a position with more predecessors than this gets no pair table: its connection costs are loaded inside its (any-shape) step
+constexpr uint32_t SLOWT = 4;               // targets relaxed together on the any-shape path (registers: a 64-bit key and a row pointer each)
 constexpr uint32_t PAIR_MIN = 1024;        // bytes of pair table a window wants beyond its largest position
 
 struct Far { uint32_t end; int32_t dp; uint32_t right; uint32_t node; };          // a bucket entry that outlives its window (16 B)
@@ -453,11 +454,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                 wave_sync();
                 // relaxations: targets x (LDS predecessors + streamed ones)
                 const uint32_t P = lane < nw ? boff[lane + 1] - boff[lane] : 0u;
-                const uint32_t x = v * P;
+                // a position with a very large bucket (the end of a long same-category run: six unknown words per start position end there, lattice.rs:66-84)
+                // would need targets x predecessors pair costs in LDS -- more than a window has.  It gets none (bit 31 of wideN): its step loads them itself.
+                const bool bigp = P > BIGP;
+                if (lane < nw && bigp) wideN[lane] |= 0x80000000u;
+                const uint32_t x = bigp ? 0u : v * P;
                 const uint32_t xs = wave_incl_scan(x, lane);
                 if (lane <= nw) ebase[lane] = xs - x;
                 E = (uint32_t)__builtin_amdgcn_readlane((int)xs, 63);
-                wEw = (lane < nw) ? v * (P + wideN[lane]) : 0u;
+                wEw = (lane < nw) ? v * (P + (wideN[lane] & 0x7FFFFFFFu)) : 0u;
                 maxpairs = x;
 #pragma unroll
                 for (int dd = 32; dd > 0; dd >>= 1) maxpairs = max(maxpairs, (uint32_t)__shfl_xor((int)maxpairs, dd, 64));
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
             for (uint32_t f = fhead + lane; f < fhead + fin; f += 64) {
                 const Far e = *far_rec(f);
                 const uint32_t rel = e.end - w0;
-                if (wideN[rel] == 0) {
+                if ((wideN[rel] & 0x7FFFFFFFu) == 0) {
                     const uint32_t slot = boff[rel] + atomicAdd(&bfill[rel], 1u);
                     bk[slot] = make_uint2((uint32_t)e.dp, (e.right & 0xFFFFu) | ((e.node - rb) << 16));
                     brel[slot] = (uint8_t)rel;
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                     const uint32_t p0 = boff[q], P = boff[q + 1] - p0;
                     const uint32_t ti = t - nb[q];
                     const uint32_t base = ebase[q] - eb0 + ti * P;
-                    gather_target_row(bk + p0, P, conn_row(d, nLeft[t]), mpair + base);
+                    if (!(wideN[q] >> 31)) gather_target_row(bk + p0, P, conn_row(d, nLeft[t]), mpair + base);
                 }
                 wave_sync();
                 KW_T(6);
@@ -634,7 +639,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                             const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)dt0, (int)r);
                             const uint32_t p0 = (D1 - a_bk) >> 3, eb = (D2 - a_mp) >> 1;
                             const uint32_t q = qa + r;
-                            const uint32_t wn = wideN[q], wlo = fcnt[q];
+                            const uint32_t wn = wideN[q] & 0x7FFFFFFFu, wlo = fcnt[q];
+                            const bool nopair = (wideN[q] >> 31) != 0;
                             for (uint32_t tg = 0; tg < T; tg += SLOWT) {  // SLOWT targets share every load of a predecessor
                                 const uint32_t nt8 = min(SLOWT, T - tg);
                                 uint64_t key[SLOWT];
@@ -647,11 +653,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                                 }
                                 for (uint32_t jj = lane; jj < P; jj += 64) {
                                     const uint2 e = bk[p0 + jj];
-                                    const uint32_t gi = rb + (e.y >> 16);
+                                    const uint32_t gi = rb + (e.y >> 16), r = e.y & 0xFFFFu;
+                                    int32_t cc[SLOWT];
+#pragma unroll
+                                    for (int k = 0; k < (int)SLOWT; ++k)   // (no pair table for this position: the costs straight from the matrix, connection.rs:12-14)
+                                        cc[k] = (uint32_t)k < nt8 ? (nopair ? (int32_t)col[k][r] : (int32_t)mpair[eb + (tg + k) * P + jj]) : 0;
 #pragma unroll
                                     for (int k = 0; k < (int)SLOWT; ++k)
                                         if ((uint32_t)k < nt8) {
-                                            const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + (tg + k) * P + jj];
+                                            const int32_t v = (int32_t)e.x + cc[k];
                                             const uint64_t ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | gi;
                                             key[k] = ck < key[k] ? ck : key[k];
                                         }
