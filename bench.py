@@ -979,28 +979,6 @@ def main():
                                                          "result arrays), host buffers in and out, wall time per call; n <= 128 takes the single-launch "
                                                          "path (pinned in/out, the kernel compacts and publishes itself), of which ~40 us are the one "
                                                          "sentence's own dependent chain on one wavefront")
-        # ---- the reference's server shape: many host threads, ONE sentence per call (src/tokenizer.rs:16 is &self, Send + Sync; src/bin/kanpyo.rs:106-126).
-        # Native threads (kgpu_debug_concurrent_callers: Python threads would measure the GIL); concurrent small calls share launches (the combiner).
-        try:
-            from kanpyo_amd.tokenizer import concurrent_callers
-
-            utf8_c, offs_c = pack_sentences(corpora[0][:20000])
-            cc = {}
-            for nthr, calls in ((1, 400), (16, 300), (64, 300), (256, 150)):
-                concurrent_callers(tok, utf8_c, offs_c, nthr, 20)  # warm: contexts, pinned blocks
-                tok.routing(reset=True)
-                r = concurrent_callers(tok, utf8_c, offs_c, nthr, calls)
-                rt = tok.routing()
-                r["combined_calls"], r["combined_launches"], r["small_calls"] = rt["combined_calls"], rt["combined_launches"], rt["small_calls"]
-                r["sentences_per_launch"] = r["sentences"] / max(rt["small_calls"] - rt["combined_calls"] + rt["combined_launches"], 1)
-                cc[f"threads{nthr}"] = r
-            cc["what"] = ("kgpu_tokenize_batch with n = 1 in a loop from N native host threads over the first 20k cfg 2 sentences; closed loop, so "
-                          "sentences/s = threads / mean latency (Little): calls that arrive while another thread's small launch is being assembled "
-                          "join it (leader / follower, <= 15 us window, <= 128 sentences)")
-            cc["host_cpus"] = cpu_quota()
-            result["pcie_inclusive"]["concurrent_callers"] = cc
-        except Exception as e:
-            print(f"concurrent_callers leg failed: {e}", file=sys.stderr)
         if not args.no_extras:
             # one large call: the whole 100k-sentence corpus four times over (400k sentences, ~45 MB in, ~300 MB of 24-byte records out)
             reps_c = 4
@@ -1031,6 +1009,29 @@ def main():
                                           "unit": "sentences/s", "what": "SURVEY 8(d) end-to-end incl. H2D / D2H: the better of pcie_inclusive.large_call_{pageable,pinned}; "
                                                                          "`value` is the device-resident rate"}
 
+    if world == 1:
+        # ---- the reference's server shape: many host threads, ONE sentence per call (src/tokenizer.rs:16 is &self, Send + Sync; src/bin/kanpyo.rs:106-126).
+        # Native threads (kgpu_debug_concurrent_callers: Python threads would measure the GIL); concurrent small calls share launches (the combiner).
+        try:
+            from kanpyo_amd.tokenizer import concurrent_callers
+
+            utf8_c, offs_c = pack_sentences(corpora[0][:20000])
+            cc = {}
+            for nthr, calls in ((1, 400), (16, 300), (64, 300), (128, 200)):
+                concurrent_callers(tok, utf8_c, offs_c, nthr, 20)  # warm: contexts, pinned blocks
+                tok.routing(reset=True)
+                r = concurrent_callers(tok, utf8_c, offs_c, nthr, calls)
+                rt = tok.routing()
+                r["combined_calls"], r["combined_launches"], r["small_calls"] = rt["combined_calls"], rt["combined_launches"], rt["small_calls"]
+                r["sentences_per_launch"] = r["sentences"] / max(rt["small_calls"] - rt["combined_calls"] + rt["combined_launches"], 1)
+                cc[f"threads{nthr}"] = r
+            cc["what"] = ("kgpu_tokenize_batch with n = 1 in a loop from N native host threads over the first 20k cfg 2 sentences; closed loop, so "
+                          "sentences/s = threads / mean latency (Little): calls that arrive while another thread's small launch is being assembled "
+                          "join it (leader / follower, <= 15 us window, <= 128 sentences)")
+            cc["host_cpus"] = cpu_quota()
+            result["pcie_inclusive"]["concurrent_callers"] = cc
+        except Exception as e:
+            print(f"concurrent_callers leg failed: {e}", file=sys.stderr)
     if extras_dir:  # the corpus generator (a pure-Python loop on one core) starts only now: the host-side legs above share the box's CPU quota with nothing
         open(os.path.join(extras_dir, "go"), "w").close()
 

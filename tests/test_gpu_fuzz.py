@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 POOLS = ["0", "8:2:64", "16:4:32", "40:4:32", "40:4:40", "40:4:48", "40:8:20", "80:8:20", "80:10:64", "160:16:64", "80:8:20,160:4:64", "24:3:48"]
-LONGS = ["0", "4", "12", "32", "160"]
+WINDOWS = ["0", "8", "10", "12", "16", "32"]  # KiB of LDS of the windowed kernel behind the pools ("0": off, the general kernel takes its place)
 
 
 @pytest.fixture(scope="module")
@@ -49,17 +49,17 @@ def test_dense_dictionaries_every_sweep_shape(libs, seed, monkeypatch):
     rng = random.Random(seed)
     total = 0
     for k in range(12):
-        pool, long_kib = rng.choice(POOLS), rng.choice(LONGS)
+        pool, window_kib = rng.choice(POOLS), rng.choice(WINDOWS)
         plain = rng.random() < 0.25
         monkeypatch.setenv("KGPU_POOL", pool)
-        monkeypatch.setenv("KGPU_LONG", long_kib)
+        monkeypatch.setenv("KGPU_WINDOW", window_kib)
         if plain:
             monkeypatch.setenv("KGPU_PLAIN_LEAVES", "1")
         else:
             monkeypatch.delenv("KGPU_PLAIN_LEAVES", raising=False)
         d, sents = synth.dense_case(rng)
         tok, orc = Tokenizer(d), oracle.OracleTokenizer.from_dict(d)
-        total += _same(tok, orc, sents, f"seed {seed} round {k} pool={pool} long={long_kib} plain={plain}")
+        total += _same(tok, orc, sents, f"seed {seed} round {k} pool={pool} window={window_kib} plain={plain}")
     assert total > 0
 
 
@@ -74,15 +74,14 @@ def test_keys_of_every_utf8_width_random_chains(libs, seed, monkeypatch):
     rng = random.Random(seed)
     total = 0
     for k in range(16):
-        pool, long_kib, window_kib = rng.choice(POOLS), rng.choice(LONGS), rng.choice(["0", "12", "16"])
+        pool, window_kib = rng.choice(POOLS), rng.choice(WINDOWS)
         byte_trie = rng.random() < 0.2
         monkeypatch.setenv("KGPU_POOL", pool)
-        monkeypatch.setenv("KGPU_LONG", long_kib)
         monkeypatch.setenv("KGPU_WINDOW", window_kib)
         monkeypatch.setenv("KGPU_BYTE_TRIE", "1" if byte_trie else "0")
         d, sents = synth.width_case(rng)
         tok, orc = Tokenizer(d), oracle.OracleTokenizer.from_dict(d)
-        total += _same(tok, orc, sents, f"seed {seed} round {k} pool={pool} long={long_kib} window={window_kib} byte_trie={byte_trie}")
+        total += _same(tok, orc, sents, f"seed {seed} round {k} pool={pool} window={window_kib} byte_trie={byte_trie}")
     assert total > 0
 
 
@@ -97,12 +96,12 @@ def test_mixed_corpora_random_chains(libs, seed, nkeys, monkeypatch):
     sd = synth.build_dict(nkeys, seed=rng.randrange(1 << 30))
     orc = oracle.OracleTokenizer.from_dict(sd.dict)
     for k in range(4):
-        pool, long_kib = rng.choice(POOLS), rng.choice(LONGS)
+        pool, window_kib = rng.choice(POOLS), rng.choice(WINDOWS)
         monkeypatch.setenv("KGPU_POOL", pool)
-        monkeypatch.setenv("KGPU_LONG", long_kib)
+        monkeypatch.setenv("KGPU_WINDOW", window_kib)
         tok = Tokenizer(sd.dict)
         for j in range(3):
-            _same(tok, orc, synth.mixed_case(sd, rng, sizes=(1, 5, 50, 120, 700, 4096)), f"seed {seed} chain {k}.{j} pool={pool} long={long_kib}")
+            _same(tok, orc, synth.mixed_case(sd, rng, sizes=(1, 5, 50, 120, 700, 4096)), f"seed {seed} chain {k}.{j} pool={pool} window={window_kib}")
 
 
 def test_default_chain_many_small_dictionaries(libs):

@@ -115,7 +115,7 @@ def test_cfg5_long_documents(full):
 
 
 def test_cfg3_and_cfg5_at_scale(full):
-    """The routing between the pool kernel and the long-sentence kernel under a realistic mix, several batches
+    """The routing between the pool kernel and the windowed kernel under a realistic mix, several batches
     deep (the reservation estimate and the optional-launch heuristics adapt from batch to batch)."""
     from kanpyo_amd import synth
 
@@ -294,19 +294,19 @@ def test_device_api_and_work_counters(full):
     assert p["launches"] == 1 and p["tokenize_ms"] > 0  # (a batch that finds the chain's tail left out gets the tail alone afterwards: the chain is timed once)
 
 
-@pytest.mark.parametrize("pool,long_kib", [("0", "0"), ("0", "12"), ("0", "4"), ("0", "160"), ("80:10", "32"), ("80:8:20", "12"), ("80:8,160:4", "32"),
-                                           ("16:4:8", "16"), ("8:2,160:2", "0"), ("160:16:64", "32"), ("40:16,24:1", "8"), ("24:1", "64")])
-def test_every_launch_chain_is_bit_exact(libs, pool, long_kib, monkeypatch):
+@pytest.mark.parametrize("pool,window_kib", [("0", "0"), ("0", "12"), ("0", "8"), ("0", "64"), ("80:10", "32"), ("80:8:20", "12"), ("80:8,160:4", "24"),
+                                             ("16:4:8", "16"), ("8:2,160:2", "0"), ("160:16:64", "10"), ("40:16,24:1", "9"), ("24:1", "48")])
+def test_every_launch_chain_is_bit_exact(libs, pool, window_kib, monkeypatch):
     """Force sentences through every launch chain.  KGPU_POOL = KiB of LDS per workgroup : independent
     wavefronts sharing it [: pages of 64 a sentence may take] ('0' = no pool kernel), under pressure: more wavefronts than the pool can serve
-    at once, pools too small for the long sentences, reservations that prove too small (redo).  KGPU_LONG =
-    KiB of LDS of the long-sentence kernel (HBM lattice, LDS-blocked sweep; '0' = off, tiny = most positions
-    fall back to the global-memory step).  Whatever is left ends in the plain HBM-scratch kernel."""
+    at once, pools too small for the long sentences, reservations that prove too small (redo).  KGPU_WINDOW = KiB of LDS of the windowed
+    kernel behind the pools ('0' = off: the general, HBM-scratch kernel serves everything the pools route away; small = windows are halved
+    again and again and the kernel hands on what does not fit even four positions long).  Whatever is left ends in the general kernel."""
     from kanpyo_amd import Tokenizer, synth
 
     _, oracle = libs
     monkeypatch.setenv("KGPU_POOL", pool)
-    monkeypatch.setenv("KGPU_LONG", long_kib)
+    monkeypatch.setenv("KGPU_WINDOW", window_kib)
     sd = synth.build_dict(20000, seed=11)
     tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
     sents = synth.make_corpus(sd, 3000, 3, "cfg2") + synth.make_corpus(sd, 300, 4, "cfg3") + synth.make_corpus(sd, 2, 6, "cfg5") + ["", "あ", "ア" * 1500]
@@ -456,7 +456,7 @@ def test_small_calls_single_launch_path(small, monkeypatch):
         assert_same(tok, orc, corpus[:n])
     assert_same(tok, orc, [""])
     assert_same(tok, orc, ["", "すもももももももものうち", ""])
-    assert_same(tok, orc, corpus[:5] + ["ア" * 3000] + corpus[5:9])          # one sentence for the long-sentence kernel: whole call falls back
+    assert_same(tok, orc, corpus[:5] + ["ア" * 3000] + corpus[5:9])          # one sentence for the windowed kernel: whole call falls back
     assert_same(tok, orc, [corpus[0]] * 128)
     utf8, offs = pack_sentences([corpus[0].encode(), b"\xe3\x81", corpus[1].encode()])
     t, toff, status = tok.tokenize_packed(utf8, offs)
@@ -569,7 +569,7 @@ def test_large_host_call_chunk_byte_counts(small):
 def test_windowed_long_sentence_kernel(libs, window_kib, pool, monkeypatch):
     """The windowed kernel (kgpu_window.hip, KGPU_WINDOW = KiB of LDS per workgroup; in the chain for sentences of 3072 bytes and more, for
     everything when there is no pool kernel): the lattice is built and relaxed window by window, only the carry list / the far FIFO /
-    16 bytes per node outlive a window (src/lattice.rs:101-154).  What it cannot hold travels on to the HBM-lattice kernel -- same
+    16 bytes per node outlive a window (src/lattice.rs:101-154).  What it cannot hold travels on to the general (HBM-scratch) kernel -- same
     records either way."""
     from kanpyo_amd import Tokenizer, synth
 
@@ -585,12 +585,58 @@ def test_windowed_long_sentence_kernel(libs, window_kib, pool, monkeypatch):
     assert_same(tok, orc, ["", "", "すもも", ""])
 
 
+@pytest.mark.parametrize("window_kib", ["12", "9", "24"])
+def test_windowed_kernel_big_buckets_and_many_prefixes(libs, window_kib, monkeypatch):
+    """Two things the windowed kernel used to hand on to the general kernel and now holds itself (round 4):
+    * a position whose bucket has more than 64 predecessors -- the end of a long same-category run: every start position of the run contributes its
+      unknown words there (src/lattice.rs:66-84) -- gets no pair table; its step loads the connection costs itself (connection.rs:12-14);
+    * a start position with more than eight dictionary prefixes parks the ninth and later ones in the window's shared overflow area
+      (trie/da.rs:155-182 yields them in ascending length; the node order of src/lattice.rs:105-110 must survive).
+    Pool off: every sentence goes through the windowed kernel.  Routing must show that nothing was handed on."""
+    from kanpyo_amd import Dict, Tokenizer, synth
+    from kanpyo_amd.device import PROFILE_OFF
+
+    _, oracle = libs
+    monkeypatch.setenv("KGPU_POOL", "0")
+    monkeypatch.setenv("KGPU_WINDOW", window_kib)
+    # (1) IPADIC-shaped dictionary: katakana / digit / latin runs of 20..200 characters between ordinary words
+    sd = synth.build_dict(20000, seed=11)
+    tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
+    rng = np.random.default_rng(int(window_kib))
+    words = synth.make_corpus(sd, 400, 7, "cfg2")
+    sents = []
+    for k in range(300):
+        run = "".join(map(chr, rng.integers(0x30A1, 0x30F7, size=int(rng.integers(20, 200))))) if k % 3 else "".join(map(chr, rng.integers(0x30, 0x3A, size=int(rng.integers(20, 200)))))
+        sents.append(words[k][: int(rng.integers(0, 30))] + run + words[k + 1][: int(rng.integers(1, 30))] + (run[:40] if k % 5 == 0 else ""))
+    ctx, t, toff, utf8, offs = _device_run(tok, sents, PROFILE_OFF)
+    exp = orc.tokenize_batch(utf8, offs, 8)
+    assert np.array_equal(toff.astype(np.uint64), exp.offsets) and np.array_equal(t.reshape(-1), exp.tokens.view(np.int32).reshape(-1))
+    if window_kib != "9":   # (at 9 KB some windows do not fit even four positions long: those sentences may travel on -- still the same records)
+        assert ctx.profile()["deferred"][0] == 0, ctx.profile()
+    # (2) nested prefixes: "あ", "ああ", ... up to 30 characters, three records each: up to 30 prefixes per start position
+    kws = []
+    for n in range(1, 31):
+        kws += ["あ" * n] * 3
+    kws += ["い", "あい"]
+    kws = sorted(kws, key=lambda x: x.encode())
+    nr = np.random.default_rng(3)
+    morphs = np.stack([nr.integers(0, 5, len(kws)), nr.integers(0, 5, len(kws)), nr.integers(-500, 5000, len(kws))], axis=1)
+    p = fixture_dict_parts()
+    d = Dict.from_parts(kws, morphs, 5, 5, nr.integers(-900, 900, 25), p["char_class"], p["char_category"], p["invoke_list"], p["group_list"],
+                        {0: (1, 1), 1: (1, 2), 2: (2, 1)}, [[0, 0, 4000], [1, 1, 3500]])
+    tok2, orc2 = Tokenizer(d), oracle.OracleTokenizer.from_dict(d)
+    sents2 = ["あ" * n for n in (1, 8, 9, 10, 17, 33, 64, 200)] + ["あ" * 12 + "い" + "あ" * 40, "いあいあ" * 30, "あ" * 5 + "x" + "あ" * 70]
+    ctx2, t2, toff2, utf82, offs2 = _device_run(tok2, sents2, PROFILE_OFF)
+    exp2 = orc2.tokenize_batch(utf82, offs2, 2)
+    assert np.array_equal(toff2.astype(np.uint64), exp2.offsets) and np.array_equal(t2.reshape(-1), exp2.tokens.view(np.int32).reshape(-1))
+
+
 @pytest.mark.parametrize("pool,window_kib", [("40:4:40", "12"), ("0", "12"), ("0", "0")])
 def test_dictionary_keys_of_every_utf8_width(libs, pool, window_kib, monkeypatch):
     """The device walks a character-level copy of the trie (kgpu_chartrie.cpp; reference walk: trie/da.rs:155-182, byte by byte).  Keys of 1-,
     2-, 3- and 4-byte characters, keys that are prefixes of each other across widths, characters beyond the kernels' BMP table (non-BMP, and
     U+FFFF, which shares the table's "not here" value) at the start, in the middle and at the end of keys -- through the pool kernel, the
-    windowed kernel and the HBM-lattice kernel (pool off / window off), short and very long sentences, the single-launch small-call path."""
+    windowed kernel and the general kernel (pool off / window off), short and very long sentences, the single-launch small-call path."""
     from kanpyo_amd import Dict, Tokenizer
 
     _, oracle = libs
@@ -609,7 +655,7 @@ def test_dictionary_keys_of_every_utf8_width(libs, pool, window_kib, monkeypatch
     tok, orc = Tokenizer(d), oracle.OracleTokenizer.from_dict(d)
     alphabet = list("abcéあい𠮷野家😀￿xy東京都𩸽λμz ")
     sents = ["".join(rng.choice(alphabet, size=int(n))) for n in rng.integers(1, 60, 400)]
-    sents += ["".join(rng.choice(alphabet, size=int(n))) for n in (700, 1500, 2500)]  # the long-sentence kernels (>= 3072 bytes: the windowed one)
+    sents += ["".join(rng.choice(alphabet, size=int(n))) for n in (700, 1500, 2500)]  # well beyond the pool kernel's reach: the windowed kernel
     sents += ["", "𠮷", "￿", "😀" * 300, "𠮷野家" * 500, "a￿x￿y" * 200] + words
     assert_same(tok, orc, sents)
     assert_same(tok, orc, sents[:5])  # small call
@@ -629,7 +675,7 @@ def test_byte_level_walk_is_kept_and_agrees(small, monkeypatch):
 
 
 def test_chain_tail_is_left_out_and_comes_back(libs):
-    """While no recent batch left a sentence for the long-sentence kernels, the launch chain ends behind the pool kernel (no empty tail launch);
+    """While no recent batch left a sentence for the windowed kernel, the launch chain ends behind the pool kernel (no empty tail launch);
     a batch that does need the tail is found by the last work list's count and run again with it (kgpu_routing.tail_reruns) -- same records
     (src/tokenizer.rs:16: calls are independent, a rerun is invisible)."""
     from kanpyo_amd import Tokenizer, synth
