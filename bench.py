@@ -512,8 +512,8 @@ def run_single_process(args):
         for g, (t8, first, toff) in enumerate(batch_rows):
             n_g = len(toff) - 1
             out = np.empty(len(t8), dtype=TOKEN_DTYPE)
-            toff_u = toff.astype(np.uint64)
-            L.kgpu_expand_tokens(np.ascontiguousarray(t8).ctypes.data, toff_u.ctypes.data, np.ascontiguousarray(first.astype(np.uint32)).ctypes.data, n_g, out.ctypes.data)
+            toff_u, t8_c, first_u = toff.astype(np.uint64), np.ascontiguousarray(t8), np.ascontiguousarray(first.astype(np.uint32))  # (named: they must outlive the call)
+            L.kgpu_expand_tokens(t8_c.ctypes.data, toff_u.ctypes.data, first_u.ctypes.data, n_g, out.ctypes.data)
             toks24[g].append(out.view(np.int32).reshape(-1, 6))
             cnts[g].append(np.diff(toff).astype(np.int64))
     g_tok, g_off = reassemble(np.concatenate([np.concatenate(x) if x else np.zeros((0, 6), np.int32) for x in toks24]),
@@ -521,6 +521,10 @@ def run_single_process(args):
     u0, o0 = pack_sentences(corpora[0])
     one_t, one_off, _ = toks[devices[0]].tokenize_packed(u0, o0)
     gather_check = bool(np.array_equal(g_off.astype(np.uint64), one_off) and np.array_equal(g_tok.reshape(-1), one_t.view(np.int32).reshape(-1)))
+    if not gather_check:
+        same_off = np.array_equal(g_off.astype(np.uint64), one_off)
+        bad = np.nonzero(np.diff(g_off.astype(np.int64)) != np.diff(one_off.astype(np.int64)))[0]
+        print(f"single-process check: offsets equal {same_off}; {len(g_off)} vs {len(one_off)} offsets, {g_tok.shape} vs {one_t.shape} tokens; first differing sentences {bad[:8]}", file=sys.stderr)
     assert gather_check, "gathered + reassembled token stream differs from the single-device stream"
 
     def sync_all():
