@@ -1190,7 +1190,8 @@ static int small_call(kgpu_dict *d, kgpu_ctx *c, SmallReq *const *reqs, size_t n
         }
     }
     if (c->pending && (rc = kgpu_ctx_sync(c, nullptr)) != KGPU_OK && rc != KGPU_ERR_CAPACITY) return rc;
-    if ((rc = c->arena.ensure(ARENA_INITIAL)) || (rc = c->stage.ensure((size_t)(total + n + 1) * sizeof(kgpu_token) + 64)) ||
+    // (no scratch arena: this path launches the pool kernel alone, whose lattices live in LDS -- a context that only ever serves small calls holds no 256 MiB)
+    if ((rc = c->stage.ensure((size_t)(total + n + 1) * sizeof(kgpu_token) + 64)) ||
         (rc = c->tok_count.ensure((size_t)(n + 1) * 4)) || (rc = c->ovf.ensure((size_t)(n + 1) * 4 * 4)))
         return rc;
     uint64_t *h_off = (uint64_t *)(c->sm_host + SM_OFF_OFFS);

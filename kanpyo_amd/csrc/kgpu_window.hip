@@ -306,6 +306,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
 #endif
         // ---- the windows ----
         uint32_t w0 = 0, gw = 1 /* global index of the window's first node: BOS is node 0 */, ncarry = 1, fhead = 0, ftail = 0, last_far_end = 0;
+        uint32_t fhead_end = 0xFFFFFFFFu;   // end position of the FIFO's head entry (0xFFFFFFFF: the FIFO is empty)
         uint32_t wT = 0, wE = 0;
         bool failed = false;
         uint32_t why = 0;  // which limit a failed sentence ran into (Control::phase[why] counts them: KGPU_WINDOW_TRACE)
@@ -366,13 +367,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
             uint32_t seed_bad = 0;
             for (uint32_t k = lane; k < ncarry; k += 64) atomicAdd(&boff[crel(ncarry)[k]], 1u);
             uint32_t fin = 0;  // FIFO entries [fhead, fhead + fin) end inside this window
-            for (uint32_t f0 = fhead; f0 < ftail; f0 += 64) {
-                const uint32_t f = f0 + lane;
-                bool in = false;
-                if (f < ftail) { const Far e = *far_rec(f); in = e.end < w0 + nw; if (in) { atomicAdd(&fcnt[e.end - w0], 1u); if (e.node < rb) seed_bad = 1; } }
-                const uint64_t m = __ballot(in);
-                fin += __popcll(m);
-                if (m != ~0ull) break;  // ends never decrease: the first entry beyond the window ends the scan
+            uint32_t next_head_end = fhead_end;   // the end position of the entry that will head the FIFO once this window is through
+            // (the head's end position is known from the scan that stopped at it: while it lies beyond the window no entry ends inside it -- ends never
+            // decrease -- and the FIFO is not read at all: through a 1024-character run that is one round trip less for every one of its 32 windows)
+            if (fhead < ftail && fhead_end < w0 + nw) {
+                next_head_end = 0xFFFFFFFFu;
+                for (uint32_t f0 = fhead; f0 < ftail; f0 += 64) {
+                    const uint32_t f = f0 + lane;
+                    bool in = false;
+                    uint32_t e_end = 0xFFFFFFFFu;
+                    if (f < ftail) { const Far e = *far_rec(f); e_end = e.end; in = e.end < w0 + nw; if (in) { atomicAdd(&fcnt[e.end - w0], 1u); if (e.node < rb) seed_bad = 1; } }
+                    const uint64_t m = __ballot(in);
+                    fin += __popcll(m);
+                    if (m != ~0ull) {  // the first entry beyond the window ends the scan (past the tail: the FIFO is exhausted, "none")
+                        next_head_end = (uint32_t)__builtin_amdgcn_readlane((int)e_end, (int)(__ffsll((unsigned long long)~m) - 1));
+                        break;
+                    }
+                }
             }
             fin = bcast32(fin);
             if (__ballot(seed_bad != 0) != 0) { failed = true; why = 1; break; }
@@ -733,10 +744,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                 }
                 if (__ballot(fbad != 0) != 0) { failed = true; why = 6; break; }
                 last_far_end = bcast32(farEnd[NF - 1]);
+                if (next_head_end == 0xFFFFFFFFu && fhead + fin == ftail) next_head_end = bcast32(farEnd[0]);   // the FIFO was (or has just become) empty: these head it
                 ftail += NF;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the next window may already take some of these from the FIFO
             }
             fhead += fin;
+            fhead_end = next_head_end;
             {
                 const uint32_t c0 = boff[nw], nc = Nb - c0;
                 const uint32_t gnext = gw + N, rbn = gnext >= 0x8000u ? gnext - 0x8000u : 0u;  // the next window's base
