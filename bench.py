@@ -32,8 +32,9 @@ import sys
 import time
 
 # Four launches side by side are the optimum on MI355X (3: 68.6, 4: 71.5, 5: 58 M sentences/s); HIP's default of 4 hardware
-# queues leaves its streams three.  Read by the HIP runtime when it initialises, so it is set before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# queues leaves its streams three.  The variable is read by the HIP runtime when it initialises: libkanpyo_gpu.so sets GPU_MAX_HW_QUEUES=8
+# itself when it is loaded before the first HIP call (kgpu_api.cpp: kgpu_preinit) -- bench.py therefore loads the library before it touches
+# torch.cuda and does NOT set the variable; the line reports the streams the library runs on (config.streams; 4 = the variable took effect).
 
 import numpy as np
 
@@ -431,11 +432,11 @@ def run_single_process(args):
     from kanpyo_amd.dist import reassemble
     from kanpyo_amd.tokenizer import TOKEN_DTYPE, pack_sentences
 
+    L = _lib.lib()  # before the first HIP call: the library asks for its hardware queues itself
     G, K, W, Q = args.gpus, args.steps, args.warmup, args.queue
     ndev = torch.cuda.device_count()
     devices = [int(x) for x in args.devices.split(",")] if args.devices else [g % max(ndev, 1) for g in range(G)]
     assert len(devices) == G and all(0 <= d < ndev for d in devices), (devices, ndev)
-    L = _lib.lib()
     sd = synth.build_dict()
     ncorp = max(1, min(args.corpora if args.corpora > 0 else 100, 100, max(K, 1)))
     corpora = [synth.make_corpus(sd, N_SENT, seed=100 + k, kind="cfg2") for k in range(ncorp)]
@@ -626,8 +627,9 @@ def main():
     import torch  # before libkanpyo_gpu.so (build_dict loads it): torch bundles its own libamdhip64 and must win
     import torch.distributed as dist
 
-    from kanpyo_amd import synth
+    from kanpyo_amd import _lib, synth
 
+    _lib.lib()  # before any HIP call of this process: the library asks for the hardware queues it needs (see the top of this file)
     sd = synth.build_dict()
     extras_dir, extras_proc = None, None
     if world == 1 and not args.no_extras:  # before the HIP runtime is initialised in this process: fork is safe
@@ -831,6 +833,7 @@ def main():
                         "batch=4096 (24 full batches + the 1696-sentence tail per 100k sentences at N=1); one step = one whole corpus; "
                         "inputs resident in HBM, dense tokens left in HBM",
             "batch": BATCH, "sentences_per_step": N_SENT, "batches_per_step_per_gpu": wl.nb(0), "batches_in_flight": Q,
+            "streams": eng.ctxs[0].plan()["streams"], "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
             "sharding": "sentence i -> GPU i mod N, dictionary replicated, one gatherv of token records to rank 0 per chunk of "
                         f"{cs} step(s)" if multi else "single GPU",
         },

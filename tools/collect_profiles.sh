@@ -5,9 +5,11 @@
 set -u
 OUT=$(realpath -m "$1"); TAG=$2
 REPO=$(cd "$(dirname "$0")/.." && pwd)
-export GPU_MAX_HW_QUEUES=8
 mkdir -p "$OUT"
-python "$REPO/bench.py" > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
+# the plain bench line: no GPU_MAX_HW_QUEUES in the environment -- the library sets it itself (config.streams says whether that took effect)
+(unset GPU_MAX_HW_QUEUES; python "$REPO/bench.py" > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err")
+# under rocprofv3 the profiler initialises the runtime before the library is loaded: there the variable comes from the environment
+export GPU_MAX_HW_QUEUES=8
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python "$REPO/bench.py" --steps 20 --warmup 5 --no-cpu --no-extras > "$OUT/trace.json" 2> "$OUT/trace.err"
 cp "$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)" "$OUT/${TAG}_kernel_stats.csv"
@@ -32,6 +34,6 @@ bash "$REPO/tools/pmc_phases.sh" "$OUT/phases" 1 2 3 4 5 6 7 0 > "$OUT/${TAG}_ph
 # the bench line once more, now that the counter files belong to this tree (traffic_stale false)
 cp "$OUT/pmc_traffic.json" "$OUT/pmc_instructions.json" "$REPO/profiles/"
 cp "$OUT/${TAG}_bench.json" "$OUT/${TAG}_bench_first.json"
-(cd "$REPO" && python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench2.err")
+(cd "$REPO" && unset GPU_MAX_HW_QUEUES && python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench2.err")
 rm -rf "$OUT"/trace "$OUT"/trace_cfg5 "$OUT"/trace_cfg3 "$OUT"/pmc/pass*/ "$OUT"/pmc_cfg5/pass*/ "$OUT"/phases
 echo done
