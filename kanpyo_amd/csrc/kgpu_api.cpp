@@ -14,6 +14,7 @@
 #include <deque>
 #include <functional>
 #include <thread>
+#include <dirent.h>
 #include <pthread.h>
 #include <sched.h>
 #include <linux/futex.h>
@@ -130,14 +131,19 @@ extern "C" const char *kgpu_last_error(void) { return g_err; }
 // and the caller has not set it.  Loaded too late (or with the variable set below 5) it runs on three streams and says so
 // (kgpu_plan_info.streams, and a warning in kgpu_last_error after kgpu_dict_create).
 static bool g_queues_ok = false;
-static bool kfd_is_open() {
-    char link[64], target[256];
-    for (int fd = 0; fd < 256; ++fd) {
-        snprintf(link, sizeof link, "/proc/self/fd/%d", fd);
+static bool kfd_is_open() {   // has this process opened the compute driver already (= has a HIP / HSA runtime been initialised)?
+    DIR *dir = opendir("/proc/self/fd");
+    if (!dir) return true;     // cannot tell: assume the worst (three streams) rather than count on queues that may not be there
+    bool found = false;
+    char link[300], target[256];
+    while (const dirent *e = readdir(dir)) {
+        if (e->d_name[0] == '.') continue;
+        snprintf(link, sizeof link, "/proc/self/fd/%s", e->d_name);
         const ssize_t k = readlink(link, target, sizeof target - 1);
-        if (k > 0) { target[k] = 0; if (strcmp(target, "/dev/kfd") == 0) return true; }
+        if (k > 0) { target[k] = 0; if (strcmp(target, "/dev/kfd") == 0) { found = true; break; } }
     }
-    return false;
+    closedir(dir);
+    return found;
 }
 __attribute__((constructor)) static void kgpu_preinit() {
     const char *e = getenv("GPU_MAX_HW_QUEUES");
