@@ -13,9 +13,10 @@ from kanpyo_amd._lib import kernel_source_hash  # the sources the profiled libra
 src, dst = sys.argv[1], sys.argv[2]
 tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
 d = json.load(open(src))
-# the plain instantiation only: the <true> one (device-side work counters) runs outside the timed region
+# the product instantiation only (k_tokenize_pool<false, ...>): the profiling one (<true, ...>: device-side work counters, and the byte-level
+# walk beside the product's) runs outside the timed region
 FULL = " [full 4096-sentence launches]"
-kernels = [k for k in d if "k_tokenize_pool" in k and "<true>" not in k and k.endswith(FULL)]
+kernels = [k for k in d if "k_tokenize_pool" in k and "pool<true" not in k and k.endswith(FULL)]
 main = kernels[0]
 batches = d[main]["FETCH_SIZE"]["dispatches"]
 fetch_kb = d[main]["FETCH_SIZE"]["per_dispatch"]  # per launch of the dominant kernel over a full batch (the general kernel
