@@ -646,7 +646,7 @@ LaunchPlan default_launch_plan(int device) {
     t.n_pools = 0;
     {
         const char *e = getenv("KGPU_POOL");
-        const char *q = e ? e : "40:4:48";
+        const char *q = e ? e : "40:4:40";
         while (*q && t.n_pools < 2) {
             int kib = atoi(q), w = 8, mp = 64;
             const char *c = q;
@@ -675,7 +675,7 @@ LaunchPlan default_launch_plan(int device) {
     // windowed kernel (everything the pools route away): KGPU_WINDOW="<KiB>" of LDS per single-wavefront workgroup, "0" = off (the general kernel then serves it all)
     {
         const char *e = getenv("KGPU_WINDOW");
-        int kib = e ? atoi(e) : 12;   // 12 KB: 13 workgroups per CU (cfg 5: 1.08 M documents/s; 16 KB: 0.76; 10 KB: windows outgrow the LDS too often)
+        int kib = e ? atoi(e) : 10;   // 10 KB: 16 workgroups per CU = the four wavefronts per SIMD its 128 VGPRs allow (round 4, after big buckets lost their pair tables: cfg 3 22.5 M sentences/s against 19.2 at 12 KB and 20.8 at 11, cfg 5 2.67 against 2.71 Gchar/s)
         if (kib < 8 || kib > 160) kib = 0;
         t.window_lds_bytes = (uint32_t)kib * 1024;
         const int per_cu = kib ? window_workgroups_per_cu(t.window_lds_bytes) : 0;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Where the windowed long-sentence kernel's time goes (shader clocks per character, PROFILE_WORK run): python tools/window_timing.py cfg5|cfg3 n [Q]"""
 import os, sys, time
-os.environ.setdefault("KGPU_WINDOW", "12")
+os.environ.setdefault("KGPU_WINDOW", "10")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from kanpyo_amd import Tokenizer, synth
