@@ -25,7 +25,11 @@ tok = Tokenizer(sd.dict)
 warn = L.kgpu_last_error().decode()
 from kanpyo_amd.device import DeviceContext
 plan = DeviceContext(tok).plan()
-print(json.dumps({"streams": plan["streams"], "warning": warn, "env": os.environ.get("GPU_MAX_HW_QUEUES")}))
+import ctypes
+getenv = ctypes.CDLL(None).getenv          # the C environment (os.environ is Python's start-up snapshot: it does not see the library's setenv)
+getenv.restype = ctypes.c_char_p
+env = getenv(b"GPU_MAX_HW_QUEUES")
+print(json.dumps({"streams": plan["streams"], "warning": warn, "env": env.decode() if env else None}))
 """ % ROOT
 
 
