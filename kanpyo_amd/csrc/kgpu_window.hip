@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
             if (4 * (64 + lane) < tl) pf_t1 = g32[64 + lane];
         };
         prefetch(0, 0);
-        uint32_t wlim = WIN;  // positions per window: halved when a window's lattice outgrows the LDS, doubled back afterwards
+        uint32_t wlim = WIN;  // positions per window: halved when a window's lattice outgrows the LDS, grown again by how empty the LDS was (see the end of the loop)
         wave_sync();
         uint32_t eos_pre = NONE;
         for (; w0 <= C && !failed; ) {
@@ -492,9 +492,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
             uint16_t *pre = nLeft;
             int16_t *mpair = (int16_t *)(lds + off);
             const uint32_t pair_need = min(2 * E, max(2 * maxpairs, PAIR_MIN));
-            if (N > 0x7FFF || NF >= 0x7FFF || Nb + NF > 0xFFF0 || off + cbytes(ncarry) + mbytes + 16 > lds_bytes || off + pair_need > lds_bytes ||
-                off0 + 8 * (Nb + NF + 1) + align_up(Nb, 4) + cbytes(Nb - boff[nw]) > moff /* the flush writes the next carry list above the buckets it reads */) {
-                if (wlim > 4 && nw > 1) { wlim = max(4u, nw >> 1); continue; }  // the same window once more, half as long
+            // What this window needs of the LDS (the three layouts that must fit: emit, sweep, flush), and from it the length that WOULD fill 7/8 of the
+            // budget at this lattice density: the part above the fixed arrays grows with the positions.  A window that does not fit is redone that long
+            // (it has been walked and counted for nothing -- round 3 halved it, and doubled back after every success: through a dense stretch every
+            // other window was thrown away); the next window starts that long as well.
+            const uint32_t lds_used = max(max(off + cbytes(ncarry) + mbytes + 16, off + pair_need),
+                                          off0 + 8 * (Nb + NF + 1) + align_up(Nb, 4) + cbytes(Nb - boff[nw]) + (lds_bytes - moff));
+            const uint32_t lds_base = off0 + mbytes + 16;
+            const uint32_t fit_len = (nw * (lds_bytes - lds_base) * 7u) / (max(lds_used, lds_base + 1u) - lds_base) / 8u;   // (63 x 160 KB x 7 < 2^32)
+            if (N > 0x7FFF || NF >= 0x7FFF || Nb + NF > 0xFFF0 || lds_used > lds_bytes) {
+                if (wlim > 4 && nw > 1) { wlim = max(4u, min(nw - 1, fit_len)); continue; }  // the same window once more, as long as the LDS allows at this density
                 failed = true; why = 8;
                 break;
             }
@@ -766,7 +773,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                 if (__ballot(cbad != 0) != 0) { failed = true; why = 7; break; }
                 ncarry = nc;
             }
-            wlim = min(WIN, wlim * 2);
+            wlim = min(WIN, max(4u, fit_len));   // the next window: as long as fills 7/8 of the LDS at this window's density
             wT += wTw; wE += wEw;
             wbyte0 = wbyte_next;
             staged = false;
