@@ -340,18 +340,6 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
         }
     }
 
-    // ---- the matrix once more, in cache-line tiles (DictView::conn_tiled) ----
-    std::vector<int16_t> conn_tiled;
-    uint32_t conn_rt64 = 0;
-    if (!rank_r.empty() && rows < 8192) {
-        const uint64_t RT = (rows + 7) / 8, LT = (cols + 7) / 8;
-        conn_rt64 = (uint32_t)(RT * 64);
-        conn_tiled.assign((size_t)(LT * RT * 64), 0);
-        for (uint64_t l = 0; l < cols; ++l)
-            for (uint64_t r = 0; r < rows; ++r)
-                conn_tiled[(size_t)(((l >> 3) * RT + (r >> 3)) * 64 + (l & 7) * 8 + (r & 7))] = conn[(size_t)(l * rows + r)];
-    }
-
     // ---- the device copy of the double array carries the duplicate counts in its leaves ----
     // A leaf (reached through the terminator byte, trie/da.rs:118-123) stores base = -id.  The walk has to load that node
     // anyway, and the record count of the surface (index.rs:46-51) is the next thing it needs: with ids below 2^21 the spare
@@ -419,8 +407,7 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
     if ((rc = upload(d, first, &d->view.first)) ||
         (rc = upload(d, da, &d->view.da)) || (rc = upload(d, morphs, &d->view.morph)) ||
         (rc = upload(d, unk_morphs, &d->view.unk_morph)) || (rc = upload(d, conn, &d->view.conn)) ||
-        (rc = upload(d, cat, &d->view.cat)) || (rc = upload(d, cinfo, &d->view.cinfo)) ||
-        (!conn_tiled.empty() && (rc = upload(d, conn_tiled, &d->view.conn_tiled)))) {
+        (rc = upload(d, cat, &d->view.cat)) || (rc = upload(d, cinfo, &d->view.cinfo))) {
         kgpu_dict_destroy(d);
         return rc;
     }
@@ -429,7 +416,6 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
     d->view.n_morph = (uint32_t)morphs.size();
     d->view.n_unk_morph = (uint32_t)unk_morphs.size();
     d->view.conn_rows = (uint32_t)rows;
-    d->view.conn_rt64 = conn_rt64;
     d->view.bos_right = bos_right; d->view.eos_left = eos_left;
     d->view.cat_len = (uint32_t)std::min<size_t>(cat.size(), 0x110000);
     d->info.da_len = da.size(); d->info.n_morphs = morphs.size(); d->info.n_unk_morphs = unk_morphs.size();

@@ -407,8 +407,8 @@ __device__ __forceinline__ uint32_t sweep_desc0(uint32_t a_ncs, uint32_t t0, uin
 
 // ---- the connection-cost gather of one target (connection.rs:12-14): M[right(j)][left(t)] for the P predecessors of its position into the LDS pair
 // table, eight independent gathers in flight per lane (two groups of four, the second only where the row goes on; the last group of a row padded
-// with a repeat of its final entry: ceil(P / 8) dependent rounds).  bk: the position's bucket (its .y carries the right id -- as a tile offset with
-// the tiled matrix), col: the target's row (tiled: its 8-row strip), out: the target's row of the pair table.
+// with a repeat of its final entry: ceil(P / 8) dependent rounds).  bk: the position's bucket (its .y carries the right id),
+// col: the target's row of the matrix, out: the target's row of the pair table.
 __device__ __forceinline__ void gather_target_row(const uint2 *bk, uint32_t P, const int16_t *col, int16_t *out) {
     for (uint32_t j = 0; j < P; j += 8) {
         const uint32_t j1 = min(j + 1, P - 1), j2 = min(j + 2, P - 1), j3 = min(j + 3, P - 1);
@@ -424,12 +424,9 @@ __device__ __forceinline__ void gather_target_row(const uint2 *bk, uint32_t P, c
         if (more) { out[j4] = c4; out[j5] = c5; out[j6] = c6; out[j7] = c7; }
     }
 }
-// The row of the (frequency-ranked) connection matrix a target with left id L reads: the tiled copy's 8-row strip when there is one.
-__device__ __forceinline__ const int16_t *conn_row(const DictView &d, uint32_t L) {
-    return d.conn_tiled ? d.conn_tiled + ((size_t)(L >> 3) * d.conn_rt64 + (L & 7u) * 8u) : d.conn + (size_t)d.conn_rows * L;
-}
-// ... and the form in which a bucket carries a right id r: as is, or as its tile offset (r >> 3) * 64 + (r & 7), which the gather adds as is.
-__device__ __forceinline__ uint32_t conn_rword(const DictView &d, uint32_t r) { return d.conn_tiled ? ((r >> 3) << 6) | (r & 7u) : r; }
+// The row of the (frequency-ranked) connection matrix a target with left id L reads (connection.rs:12-14).  Layouts that put the pairs of one gather
+// instruction into fewer cache lines -- 8 x 8 tiles (rounds 2-3), the transpose -- measure the same as this one (profiles/experiments/r04_matrix_layouts.txt).
+__device__ __forceinline__ const int16_t *conn_row(const DictView &d, uint32_t L) { return d.conn + (size_t)d.conn_rows * L; }
 
 // Work-list plumbing shared by the kernels of a launch chain: launch k takes its sentence ids
 // from list `in_list` (nullptr = identity over [0, n)) and pushes the ones it does not

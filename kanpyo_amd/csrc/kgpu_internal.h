@@ -60,11 +60,6 @@ struct DictView {
     uint32_t bos_right, eos_left;                  // the ranked ids of context id 0 (BOS/EOS Morph(0,0,0))
     const uint8_t *cat;      uint32_t cat_len;    // char_category_def.rs:17,33-38
     const CatInfo *cinfo;                          // 256 entries
-    // The same matrix in 8 x 8 tiles of 128 bytes (one cache line): element (right, left) at
-    // ((left >> 3) * RT + (right >> 3)) * 64 + (left & 7) * 8 + (right & 7), RT = ceil(rows / 8), conn_rt64 = RT * 64.  With
-    // frequency-ranked ids the pairs a position needs fall into a few tiles, and the lanes of one gather instruction that
-    // hit the same line share one request.  nullptr: ids not ranked or >= 8192 rows -- the pool kernel then uses `conn`.
-    const int16_t *conn_tiled; uint32_t conn_rt64; uint32_t pad_;
     // Character-level double array (kgpu_chartrie.cpp; nullptr: the dictionary is walked byte by byte): one dependent load per character
     // instead of one per byte.  crec: per BMP code point; nb_cp / nb_code: the few characters >= U+FFFF that occur in keys.
     const CtNode *da2;       uint32_t da2_len; uint32_t n_nb;

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
     uint32_t stop_after;
     // (the empty asm makes the pointer opaque: what was read before it is dead, what is not used before the next one is never loaded)
 #define KGPU_ARGS() do { KArgs kq_ = kargs; asm volatile("" : "+s"(kq_)); \
-        d.da = kq_->d.da; d.da_len = kq_->d.da_len; d.leaf_dup = kq_->d.leaf_dup; d.first = kq_->d.first; d.morph = kq_->d.morph; d.n_morph = kq_->d.n_morph; d.unk_morph = kq_->d.unk_morph; d.n_unk_morph = kq_->d.n_unk_morph; d.conn = kq_->d.conn; d.conn_rows = kq_->d.conn_rows; d.bos_right = kq_->d.bos_right; d.eos_left = kq_->d.eos_left; d.cat = kq_->d.cat; d.cat_len = kq_->d.cat_len; d.cinfo = kq_->d.cinfo; d.conn_tiled = kq_->d.conn_tiled; d.conn_rt64 = kq_->d.conn_rt64; d.da2 = kq_->d.da2; d.da2_len = kq_->d.da2_len; d.n_nb = kq_->d.n_nb; d.crec = kq_->d.crec; d.nb_cp = kq_->d.nb_cp; d.nb_code = kq_->d.nb_code; \
+        d.da = kq_->d.da; d.da_len = kq_->d.da_len; d.leaf_dup = kq_->d.leaf_dup; d.first = kq_->d.first; d.morph = kq_->d.morph; d.n_morph = kq_->d.n_morph; d.unk_morph = kq_->d.unk_morph; d.n_unk_morph = kq_->d.n_unk_morph; d.conn = kq_->d.conn; d.conn_rows = kq_->d.conn_rows; d.bos_right = kq_->d.bos_right; d.eos_left = kq_->d.eos_left; d.cat = kq_->d.cat; d.cat_len = kq_->d.cat_len; d.cinfo = kq_->d.cinfo; d.da2 = kq_->d.da2; d.da2_len = kq_->d.da2_len; d.n_nb = kq_->d.n_nb; d.crec = kq_->d.crec; d.nb_cp = kq_->d.nb_cp; d.nb_code = kq_->d.nb_code; \
         a.utf8 = kq_->a.utf8; a.offsets = kq_->a.offsets; a.n = kq_->a.n; a.ctl = kq_->a.ctl; a.arena = kq_->a.arena; a.arena_bytes = kq_->a.arena_bytes; a.stage = kq_->a.stage; a.tok_count = kq_->a.tok_count; a.status = kq_->a.status; a.out = kq_->a.out; a.out_cap = kq_->a.out_cap; a.tok_offsets = kq_->a.tok_offsets; a.count_work = kq_->a.count_work; a.ovf[0] = kq_->a.ovf[0]; a.ovf[1] = kq_->a.ovf[1]; a.ovf[2] = kq_->a.ovf[2]; a.ovf[3] = kq_->a.ovf[3]; a.est_q8 = kq_->a.est_q8; a.dump_lattice = kq_->a.dump_lattice; a.fused_host = kq_->a.fused_host; a.fused_seq = kq_->a.fused_seq; a.stat_slots = kq_->a.stat_slots; \
         io.in_list = kq_->io.in_list; io.in_count = kq_->io.in_count; io.out_list = kq_->io.out_list; io.out_count = kq_->io.out_count; io.late_count = kq_->io.late_count; stop_after = kq_->stop_after; } while (0)
     KGPU_ARGS();
@@ -467,8 +467,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         // 3b, lane = node: its morph record (one gather per 64 nodes instead of one dependent load per record of the
         // busiest position), its slot in the bucket of the position it ends at.  The order inside a bucket is free:
         // the sweep breaks ties on the node index it carries.
-        // (with the tiled matrix the bucket carries the right id as its tile offset, (r >> 3) * 64 + (r & 7): the gather adds it as is)
-        auto rword = [&](uint32_t r) { return conn_rword(d, r); };
         for (uint32_t t0 = 1; t0 < N - 1; t0 += 256) {  // four nodes per lane: the four record gathers are in flight together
             uint32_t tt[4], ee[4];
             Morph8 mm[4];
@@ -485,14 +483,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                 if (tt[k] < N - 1) {
                     const uint32_t slot = boff[ee[k]] + atomicAdd(&bfill[ee[k]], 1u);
                     nLeft[tt[k]] = (uint16_t)mm[k].left; nCS[tt[k]] = (uint32_t)(uint16_t)mm[k].cost | (slot << 16);
-                    bk[slot].y = rword((uint32_t)(uint16_t)mm[k].right) | (tt[k] << 16);
+                    bk[slot].y = (uint32_t)(uint16_t)mm[k].right | (tt[k] << 16);
                 }
             }
         }
         if (lane == 0) {
             nLeft[N - 1] = (uint16_t)d.eos_left; nCS[N - 1] = Nb << 16;  // EOS: Morph(0,0,0), ranked id; its dp goes to the sink slot
             nStart[N - 1] = (uint16_t)C; nSid[N - 1] = 0;
-            bk[0] = make_uint2(0u, rword(d.bos_right));  // BOS: dp None -> 0 (lattice.rs:127), right_id 0 (ranked), node 0
+            bk[0] = make_uint2(0u, d.bos_right);  // BOS: dp None -> 0 (lattice.rs:127), right_id 0 (ranked), node 0
         }
         wave_sync();
         if (lane == 0) pre[0] = NONE16;

@@ -108,14 +108,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
     const KArgs kargs = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
     DictView d; BatchArgs a; WorkIO io;
 #define KW_ARGS() do { KArgs kq_ = kargs; asm volatile("" : "+s"(kq_)); \
-        d.da = kq_->d.da; d.da_len = kq_->d.da_len; d.leaf_dup = kq_->d.leaf_dup; d.first = kq_->d.first; d.morph = kq_->d.morph; d.n_morph = kq_->d.n_morph; d.unk_morph = kq_->d.unk_morph; d.n_unk_morph = kq_->d.n_unk_morph; d.conn = kq_->d.conn; d.conn_rows = kq_->d.conn_rows; d.bos_right = kq_->d.bos_right; d.eos_left = kq_->d.eos_left; d.cat = kq_->d.cat; d.cat_len = kq_->d.cat_len; d.cinfo = kq_->d.cinfo; d.conn_tiled = kq_->d.conn_tiled; d.conn_rt64 = kq_->d.conn_rt64; d.da2 = kq_->d.da2; d.da2_len = kq_->d.da2_len; d.n_nb = kq_->d.n_nb; d.crec = kq_->d.crec; d.nb_cp = kq_->d.nb_cp; d.nb_code = kq_->d.nb_code; \
+        d.da = kq_->d.da; d.da_len = kq_->d.da_len; d.leaf_dup = kq_->d.leaf_dup; d.first = kq_->d.first; d.morph = kq_->d.morph; d.n_morph = kq_->d.n_morph; d.unk_morph = kq_->d.unk_morph; d.n_unk_morph = kq_->d.n_unk_morph; d.conn = kq_->d.conn; d.conn_rows = kq_->d.conn_rows; d.bos_right = kq_->d.bos_right; d.eos_left = kq_->d.eos_left; d.cat = kq_->d.cat; d.cat_len = kq_->d.cat_len; d.cinfo = kq_->d.cinfo; d.da2 = kq_->d.da2; d.da2_len = kq_->d.da2_len; d.n_nb = kq_->d.n_nb; d.crec = kq_->d.crec; d.nb_cp = kq_->d.nb_cp; d.nb_code = kq_->d.nb_code; \
         a.utf8 = kq_->a.utf8; a.offsets = kq_->a.offsets; a.n = kq_->a.n; a.ctl = kq_->a.ctl; a.arena = kq_->a.arena; a.arena_bytes = kq_->a.arena_bytes; a.stage = kq_->a.stage; a.tok_count = kq_->a.tok_count; a.status = kq_->a.status; a.count_work = kq_->a.count_work; \
         io.in_list = kq_->io.in_list; io.in_count = kq_->io.in_count; io.out_list = kq_->io.out_list; io.out_count = kq_->io.out_count; } while (0)
     KW_ARGS();
     const uint32_t lds_bytes = kargs->lds_bytes;
     const uint32_t lane = threadIdx.x;
     const int32_t base_root = d.da[1].base;
-    auto rword = [&](uint32_t r) { return conn_rword(d, r); };
     Slab sa{nullptr, 0};
     uint64_t accW[7] = {0, 0, 0, 0, 0, 0, 0};
     uint64_t tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // shader clocks per phase (only summed when a.count_work): prepass, stage, seeds, walk, scan, emit, gather, sweep, flush, backtrace+tokens
@@ -310,7 +309,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
         uint32_t wT = 0, wE = 0;
         bool failed = false;
         uint32_t why = 0;  // which limit a failed sentence ran into (Control::phase[why] counts them: KGPU_WINDOW_TRACE)
-        if (lane == 0) { carry8(1)[0] = make_uint2(0u, rword(d.bos_right)); crel(1)[0] = 0; }  // BOS: node 0, ends at 0, dp None -> 0 (lattice.rs:127,156-164)
+        if (lane == 0) { carry8(1)[0] = make_uint2(0u, d.bos_right); crel(1)[0] = 0; }  // BOS: node 0, ends at 0, dp None -> 0 (lattice.rs:127,156-164)
         uint32_t wbyte0 = 0;  // first byte of the next window's characters
         uint2 pf_rec = make_uint2(0u, 0u);
         uint32_t pf_t0 = 0, pf_t1 = 0;
@@ -594,7 +593,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                         else if (ee[k] & 0x8000u) slot = Nb + (ee[k] & 0x7FFFu);                 // ends beyond the LDS buckets: a far-out slot
                         else { slot = boff[ee[k]] + atomicAdd(&bfill[ee[k]], 1u); brel[slot] = (uint8_t)ee[k]; }
                         nLeft[tt[k]] = (uint16_t)mm[k].left; nCS[tt[k]] = (uint32_t)(uint16_t)mm[k].cost | (slot << 16);
-                        bk[slot] = make_uint2((uint32_t)INF, rword((uint32_t)(uint16_t)mm[k].right) | ((gw + tt[k] - rb) << 16));
+                        bk[slot] = make_uint2((uint32_t)INF, (uint32_t)(uint16_t)mm[k].right | ((gw + tt[k] - rb) << 16));
                     }
                 }
             }

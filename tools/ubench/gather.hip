@@ -8,15 +8,17 @@
 #include <cstdio>
 #include <vector>
 
-template <int INFLIGHT>
+// GROUP: that many neighbouring lanes read (different 2-byte elements of) the same 128-byte line
+template <int INFLIGHT, int GROUP = 1>
 __global__ void k_gather(const int16_t *tab, uint32_t mask, int rounds, uint64_t *cycles, int *sink) {
-    uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
+    uint32_t x = ((blockIdx.x * blockDim.x + threadIdx.x) / GROUP) * 2654435761u + 12345u;
+    const uint32_t within = (threadIdx.x % GROUP) * (64 / GROUP);
     int acc = 0;
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
     for (int r = 0; r < rounds; ++r) {
         int16_t v[INFLIGHT];
 #pragma unroll
-        for (int k = 0; k < INFLIGHT; ++k) { x = x * 1664525u + 1013904223u; v[k] = tab[(x >> 8) & mask]; }
+        for (int k = 0; k < INFLIGHT; ++k) { x = x * 1664525u + 1013904223u; v[k] = tab[GROUP == 1 ? (x >> 8) & mask : ((((x >> 8) & mask) & ~63u) | within)]; }
 #pragma unroll
         for (int k = 0; k < INFLIGHT; ++k) acc += v[k];
     }
@@ -48,5 +50,17 @@ int main() {
                    reqs / avg, avg / (rounds * 8.0 ));
         }
     }
+    // lanes sharing lines: G neighbouring lanes per 128-byte line, 4 MB table, 16 waves per CU, 4 loads in flight
+    auto run = [&](auto kern, int g) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipMemset(cyc, 0, 256 * 8);
+            hipLaunchKernelGGL(kern, dim3(256), dim3(64 * 16), 0, 0, tab, (uint32_t)(n - 1), rounds * 2, cyc, sink);
+            hipDeviceSynchronize();
+        }
+        std::vector<uint64_t> h(256); hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
+        double avg = 0; for (auto c : h) avg += c; avg /= 256;
+        printf("lanes per line %2d: %.0f cycles, %.2f lane-requests per cycle per CU, %.0f cycles per wave-instruction\n", g, avg, 16.0 * 64 * rounds * 8 / avg, avg / (rounds * 8.0));
+    };
+    run(k_gather<4, 1>, 1); run(k_gather<4, 2>, 2); run(k_gather<4, 4>, 4); run(k_gather<4, 8>, 8); run(k_gather<4, 16>, 16); run(k_gather<4, 64>, 64);
     return 0;
 }
