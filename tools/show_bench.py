@@ -6,7 +6,7 @@ r = p["roofline"]
 print(f"value {p['value']/1e6:.2f} M sentences/s, ms/step {p['ms_per_step']:.3f}, e2e {p.get('value_end_to_end',{}).get('value',0)/1e6:.2f} M")
 print(f"roofline: per launch {r['frac']:.4f} ({r['avg_kernel_ms']*1e3:.1f} us), alone {r.get('frac_alone')} ({r.get('kernel_alone_ms')}), job rate {r['frac_at_job_rate']:.4f}")
 if "stages" in r:
-    print("stages:", {k: (round(v["ms_per_step"], 3), round(v["frac"], 3)) for k, v in r["stages"].items() if isinstance(v, dict)})
+    print("stages:", {k: (round(v["ms_per_step"], 3), round(v["frac"], 3) if v["frac"] is not None else None) for k, v in r["stages"].items() if isinstance(v, dict) and "ms_per_step" in v})
 print("routing:", p["routing"])
 pi = p.get("pcie_inclusive", {})
 print("latency:", {k: round(v["median_us"], 1) for k, v in pi.get("call_latency", {}).items()}, "4096/call", round(pi.get("value", 0) / 1e6, 2), "M")
