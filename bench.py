@@ -1160,6 +1160,17 @@ def main():
                     extra.append(measure_config(tok, dev, wl_x, n_chars, passes, args.queue, 0, lab, orc=extras_orc))
             except Exception as e:
                 print(f"{kind} leg failed: {e}", file=sys.stderr)
+        # ---- ONE context (a caller that keeps a single batch in flight): the cfg 2 corpus in batches of 4096 and of 16384
+        try:
+            u2, o2 = pack_sentences(corpora[0])
+            chars2 = sum(map(len, corpora[0]))
+            for b1 in (BATCH, 4 * BATCH):
+                line = measure_config(tok, dev, PackedWorkload(u2, o2, batch=b1), chars2, 10, 1, 0,
+                                      f"ONE context, one batch in flight: the cfg 2 corpus (100k sentences, ~40 chars) in batches of {b1}", orc=None)
+                line["contexts"] = 1
+                extra.append(line)
+        except Exception as e:
+            print(f"single-context leg failed: {e}", file=sys.stderr)
         # ---- a real Kanpyo dictionary, when one is on the box (KANPYO_DICT=/path/ipa.dict, optional KANPYO_SENTENCES=/path/text): parity + rate on it.
         # The dictionary cannot be obtained in the build environment (reference README.md:74-82: fetched from GitHub Releases), so this line is
         # normally absent; tests/test_real_dict.py is the matching parity test.
