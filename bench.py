@@ -1051,6 +1051,15 @@ def main():
             result["pcie_inclusive"]["concurrent_callers"] = cc
         except Exception as e:
             print(f"concurrent_callers leg failed: {e}", file=sys.stderr)
+    if world == 1:
+        # ---- the host-side merge of the multi-device call, alone (no device): what kgpu_tokenize_batch_multi's calling thread + workers sustain on this box's CPUs
+        try:
+            from kanpyo_amd.tokenizer import merge_bench
+
+            result["multi_merge"] = merge_bench(8, 8192, 32, reps=20)
+            result["multi_merge"]["host_cpus"] = cpu_quota()
+        except Exception as e:
+            print(f"multi_merge leg failed: {e}", file=sys.stderr)
     if extras_dir:  # the corpus generator (a pure-Python loop on one core) starts only now: the host-side legs above share the box's CPU quota with nothing
         open(os.path.join(extras_dir, "go"), "w").close()
 

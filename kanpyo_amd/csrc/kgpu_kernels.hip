@@ -386,7 +386,7 @@ __global__ __launch_bounds__(1024) void k_scan_counts(BatchArgs a, Control *host
         if (tid == 1023) carry_s = carry + woff + vs;
         __syncthreads();
     }
-    if (tid == 0) a.tok_offsets[a.n] = carry_s;
+    if (tid == 0) { a.tok_offsets[a.n] = carry_s; if (a.toff8) a.toff8[a.n] = carry_s; }   // (the mirrored table's last entry here, not in the compaction: an empty shard has no sentence to write it)
     static_assert(sizeof(Control) % 4 == 0 && sizeof(Control) / 4 <= 1024, "Control is copied one dword per thread");
     if (tid < sizeof(Control) / 4) {
         uint32_t *dc = (uint32_t *)a.ctl, *hc = (uint32_t *)host_ctl;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void k_compact8(BatchArgs a, Control *host_ctl
             const uint2 f = cnt ? make_uint2(src[0].position, src[0].start) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
             *(uint2 *)(a.first8 + 2 * s) = f;
             if (a.status8) a.status8[s] = a.status[s];
-            if (a.toff8) { a.toff8[s] = dst; if (s + 1 == a.n) a.toff8[a.n] = dst + cnt; }
+            if (a.toff8) a.toff8[s] = dst;   // ([n] comes from k_scan_counts)
         }
         if (dst + cnt > a.out_cap) continue;
         bool bad = false;
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_scan_compact(BatchArgs a, Control *host
     const bool last_wg = s0 + per_wg >= a.n;
     const uint64_t total = prefix + wsum[0] + wsum[1] + wsum[2] + wsum[3];
     if (last_wg) {
-        if (tid == 0) a.tok_offsets[a.n] = total;
+        if (tid == 0) { a.tok_offsets[a.n] = total; if (a.toff8) a.toff8[a.n] = total; }   // (n = 0 included: an empty shard's mirrored table is {0})
         static_assert(sizeof(Control) % 4 == 0 && sizeof(Control) / 4 <= 256 * 4, "Control is copied a few dwords per thread");
         for (uint32_t k = tid; k < sizeof(Control) / 4; k += 256) {
             uint32_t *dc = (uint32_t *)a.ctl, *hc = (uint32_t *)host_ctl;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void k_scan_compact(BatchArgs a, Control *host
                 const uint2 f = cnt ? make_uint2(src[0].position, src[0].start) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
                 *(uint2 *)(a.first8 + 2 * sx) = f;
                 if (a.status8) a.status8[sx] = a.status[sx];
-                if (a.toff8) { a.toff8[sx] = dst; if (sx + 1 == a.n) a.toff8[a.n] = dst + cnt; }
+                if (a.toff8) a.toff8[sx] = dst;
             }
             if (dst + cnt > a.out_cap) continue;
             bool bad = false;

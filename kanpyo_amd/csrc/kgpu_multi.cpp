@@ -19,6 +19,64 @@
 
 #include "kgpu_runtime.h"
 
+namespace kgpu {
+
+// ---- the merge of G shards' results into the caller's order (host only: no device call in here; tests/test_multi_merge_cpu.py drives it without a GPU).
+// Global sentence j of a super-chunk lives in shard j mod G at local index j / G.  Per slice of the super-chunk: its token total is a difference of two
+// entries of every shard's offset table (O(G), on the merging thread), an exclusive scan over the slices gives every slice its base, and one task per
+// slice then walks the G shard cursors once -- offsets, expansion of the 8-byte records and status bytes in the same pass, no division per sentence.
+struct MergeSrc { const kgpu_token8 *rec; const uint32_t *first; const uint64_t *toff; const uint8_t *st; };
+
+// sentences j < x of a super-chunk with j mod G == g
+static inline uint64_t shard_prefix(uint64_t x, uint64_t g, uint64_t G) { return (x + G - 1 - g) / G; }
+
+// slice_base[t] = tokens of the super-chunk in front of slice t (t = 0 .. nt; [nt] = the super-chunk's total)
+void merge_plan(const MergeSrc *src, int G, uint64_t cnt, uint64_t slice, std::vector<uint64_t> &slice_base) {
+    const uint64_t nt = (cnt + slice - 1) / slice, Gu = (uint64_t)G;
+    slice_base.assign((size_t)nt + 1, 0);
+    uint64_t run = 0;
+    for (uint64_t t = 0; t < nt; ++t) {
+        slice_base[(size_t)t] = run;
+        const uint64_t a = t * slice, b = std::min(cnt, a + slice);
+        for (uint64_t g = 0; g < Gu; ++g) run += src[g].toff[shard_prefix(b, g, Gu)] - src[g].toff[shard_prefix(a, g, Gu)];
+    }
+    slice_base[(size_t)nt] = run;
+}
+
+// sentences [a, b) of the super-chunk: tok_offsets[j] (already pointing at the super-chunk's first entry), the 24-byte records (tokens = the caller's
+// whole array, or nullptr: offsets and status only), status bytes.  base = tokens in front of sentence a, in the caller's numbering.
+void merge_slice(const MergeSrc *src, int G, uint64_t a, uint64_t b, uint64_t base, kgpu_token *tokens, uint64_t *tok_offsets, uint8_t *status) {
+    const uint64_t Gu = (uint64_t)G;
+    uint64_t g = a % Gu, k = a / Gu, run = base;
+    for (uint64_t j = a; j < b; ++j) {
+        const MergeSrc &sx = src[g];
+        const uint64_t t0 = sx.toff[k], t1 = sx.toff[k + 1];
+        tok_offsets[j] = run;
+        if (tokens) {
+            uint32_t pos = sx.first[2 * k], st = sx.first[2 * k + 1];
+            const kgpu_token8 *in = sx.rec + t0;
+            kgpu_token *out = tokens + run;
+            for (uint64_t q = 0, e = t1 - t0; q < e; ++q) {
+                const uint32_t p = in[q].packed, chars = KGPU_T8_CHARS(p), bytes = KGPU_T8_BYTES(p);
+                out[q] = kgpu_token{in[q].id, KGPU_T8_CLS(p), pos, st, st + chars, bytes};
+                pos += bytes; st += chars;
+            }
+        }
+        if (status) status[j] = sx.st[k];
+        run += t1 - t0;
+        if (++g == Gu) { g = 0; ++k; }
+    }
+}
+
+// The caller's current device, restored on every exit path: the multi-device entry points visit every device on the calling thread.
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
+}  // namespace kgpu
+
 namespace {
 
 constexpr int NSLOT = 8;       // chunks of one device between submission and the end of their expansion
@@ -151,6 +209,7 @@ extern "C" int kgpu_tokenize_batch_multi(kgpu_dict *const *dicts, int n_dicts, c
     if (!dicts || n_dicts < 1 || n_dicts > 64 || !offsets || !tok_offsets || (token_capacity && !tokens)) { set_error("kgpu_tokenize_batch_multi: bad argument"); return KGPU_ERR_INVALID_ARG; }
     for (int g = 0; g < n_dicts; ++g) if (!dicts[g]) { set_error("kgpu_tokenize_batch_multi: null dictionary handle %d", g); return KGPU_ERR_INVALID_ARG; }
     if (n_dicts == 1) return kgpu_tokenize_batch(dicts[0], utf8, offsets, n, tokens, token_capacity, tok_offsets, status, n_tokens);
+    DeviceGuard keep_callers_device;
     for (uint64_t i = 0; i < n; ++i)
         if (offsets[i + 1] < offsets[i]) { set_error("kgpu_tokenize_batch_multi: offsets not monotone at %llu", (unsigned long long)i); return KGPU_ERR_INVALID_ARG; }
     if (offsets[n] - offsets[0] && !utf8) { set_error("kgpu_tokenize_batch_multi: null utf8"); return KGPU_ERR_INVALID_ARG; }
@@ -195,41 +254,31 @@ extern "C" int kgpu_tokenize_batch_multi(kgpu_dict *const *dicts, int n_dicts, c
         mc.ready[c % NSLOT].store(0, std::memory_order_release);
         const uint64_t lo = mc.chunk_lo(c), cnt = mc.chunk_hi(c) - lo;
         const int slot = (int)(c % NSLOT);
-        struct Src { const kgpu_token8 *rec; const uint32_t *first; const uint64_t *toff; const uint8_t *st; };
-        std::vector<Src> src((size_t)G);
+        std::vector<MergeSrc> src((size_t)G);
         for (int g = 0; g < G; ++g) {
             const ShardJob &j = mc.jobs[(size_t)g * NSLOT + slot];
             const uint8_t *ph = (const uint8_t *)j.c->pin_out.h;
-            src[(size_t)g] = Src{(const kgpu_token8 *)ph, (const uint32_t *)(ph + j.off_first), (const uint64_t *)(ph + j.off_toff), ph + j.off_status};
+            src[(size_t)g] = MergeSrc{(const kgpu_token8 *)ph, (const uint32_t *)(ph + j.off_first), (const uint64_t *)(ph + j.off_toff), ph + j.off_status};
         }
-        uint64_t run = tok_done;
-        if (!overflow) {
-            for (uint64_t jx = 0; jx < cnt; ++jx) {
-                const Src &sx = src[(size_t)(jx % (uint64_t)G)];
-                const uint64_t k = jx / (uint64_t)G;
-                tok_offsets[lo + jx] = run;
-                run += sx.toff[k + 1] - sx.toff[k];
-            }
-            if (run > token_capacity) overflow = true; else tok_offsets[lo + cnt] = run;
-        }
-        if (overflow) { run = tok_done; for (int g = 0; g < G; ++g) { const uint64_t m = mc.shard_count(c, g); run += src[(size_t)g].toff[m] - src[(size_t)g].toff[0]; } }
-        tok_done = run;
+        // slice totals from the shards' offset tables (O(slices x G) on this thread), then one task per slice does everything else
         const uint64_t SLICE = 2048;
-        const int nt = (int)((cnt + SLICE - 1) / SLICE);
+        std::vector<uint64_t> slice_base;
+        merge_plan(src.data(), G, cnt, SLICE, slice_base);
+        const int nt = (int)(slice_base.size() - 1);
+        const uint64_t chunk_tokens = slice_base[(size_t)nt];
+        if (tok_done + chunk_tokens > token_capacity) overflow = true;   // (from here on: totals and status bytes only)
+        const uint64_t base0 = tok_done;
+        tok_done += chunk_tokens;
+        if (!overflow) tok_offsets[lo + cnt] = tok_done;
         mc.slot_tasks[slot].store(nt, std::memory_order_release);
         outstanding.fetch_add(nt, std::memory_order_acq_rel);
         const bool ovf = overflow;
-        const uint64_t Gu = (uint64_t)G;
         for (int t = 0; t < nt; ++t) {
-            const uint64_t a = (uint64_t)t * SLICE, b = std::min(cnt, a + SLICE);
+            const uint64_t a = (uint64_t)t * SLICE, b = std::min(cnt, a + SLICE), base = base0 + slice_base[(size_t)t];
             std::atomic<int> *st_ = &mc.slot_tasks[slot], *out_ = &outstanding;
             workers().submit([=] {
-                for (uint64_t jx = a; jx < b; ++jx) {
-                    const Src &sx = src[(size_t)(jx % Gu)];
-                    const uint64_t k = jx / Gu;
-                    if (!ovf) kgpu_expand_tokens(sx.rec + sx.toff[k], sx.toff + k, sx.first + 2 * k, 1, tokens + tok_offsets[lo + jx]);
-                    if (status) status[lo + jx] = sx.st[k];
-                }
+                if (!ovf) merge_slice(src.data(), G, a, b, base, tokens, tok_offsets + lo, status ? status + lo : nullptr);
+                else if (status) { uint64_t g = a % (uint64_t)G, k = a / (uint64_t)G; for (uint64_t jx = a; jx < b; ++jx) { status[lo + jx] = src[(size_t)g].st[k]; if (++g == (uint64_t)G) { g = 0; ++k; } } }
                 workers().task_done(*st_);
                 workers().task_done(*out_);
             });
@@ -267,6 +316,7 @@ extern "C" int kgpu_multi_create(kgpu_dict *const *dicts, int n_dicts, int slots
     if (!dicts || !out || n_dicts < 1 || n_dicts > 64 || slots < 1 || slots > 64) { set_error("kgpu_multi_create: bad argument"); return KGPU_ERR_INVALID_ARG; }
     *out = nullptr;
     for (int g = 0; g < n_dicts; ++g) if (!dicts[g]) { set_error("kgpu_multi_create: null dictionary handle %d", g); return KGPU_ERR_INVALID_ARG; }
+    DeviceGuard keep_callers_device;
     kgpu_multi *m = new kgpu_multi();
     m->dicts.assign(dicts, dicts + n_dicts);
     m->slots = slots;
@@ -292,6 +342,7 @@ extern "C" int kgpu_multi_create(kgpu_dict *const *dicts, int n_dicts, int slots
 
 extern "C" void kgpu_multi_destroy(kgpu_multi *m) {
     if (!m) return;
+    DeviceGuard keep_callers_device;
     for (kgpu_ctx *c : m->ctx) if (c) kgpu_ctx_destroy(c);
     delete m;
 }
@@ -304,6 +355,7 @@ extern "C" int kgpu_multi_tokenize_device(kgpu_multi *m, int slot, const uint8_t
         return KGPU_ERR_INVALID_ARG;
     }
     const int G = (int)m->dicts.size();
+    DeviceGuard keep_callers_device;
     for (int g = 0; g < G; ++g) {
         kgpu_ctx *c = m->ctx[(size_t)slot * G + g];
         HIPCHECK(hipSetDevice(m->dicts[g]->device));
@@ -321,6 +373,7 @@ extern "C" int kgpu_multi_tokenize_device(kgpu_multi *m, int slot, const uint8_t
 extern "C" int kgpu_multi_sync(kgpu_multi *m, int slot, uint64_t *n_tokens) {
     if (!m || slot < 0 || slot >= m->slots) { set_error("kgpu_multi_sync: bad argument"); return KGPU_ERR_INVALID_ARG; }
     const int G = (int)m->dicts.size();
+    DeviceGuard keep_callers_device;
     int first_rc = KGPU_OK;
     for (int g = 0; g < G; ++g) {
         uint64_t got = 0;
@@ -329,4 +382,39 @@ extern "C" int kgpu_multi_sync(kgpu_multi *m, int slot, uint64_t *n_tokens) {
         if (rc && !first_rc) first_rc = rc;
     }
     return first_rc;
+}
+
+// ------------------------------------------------------------------------------------------------ test / measurement hook (no device)
+// The merge of kgpu_tokenize_batch_multi over ONE super-chunk given as G shard blocks in host memory (what the shards' compaction kernels leave in
+// their mapped result blocks), through the same plan + worker-pool tasks: tests/test_multi_merge_cpu.py checks it against a plain loop and times it
+// (reps > 1: the same merge repeated, seconds = wall time of all repetitions).  Needs no GPU.
+extern "C" int kgpu_debug_merge_shards(int G, uint64_t cnt, const kgpu_token8 *const *rec, const uint32_t *const *first, const uint64_t *const *toff,
+                                       const uint8_t *const *st, uint64_t slice, int reps, kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets,
+                                       uint8_t *status, uint64_t *n_tokens, double *seconds) {
+    if (G < 1 || G > 64 || !rec || !first || !toff || !st || !tok_offsets || slice == 0 || reps < 1) { set_error("kgpu_debug_merge_shards: bad argument"); return KGPU_ERR_INVALID_ARG; }
+    if (workers().start() == 0) { set_error("kgpu_debug_merge_shards: no worker threads"); return KGPU_ERR_INTERNAL; }
+    std::vector<MergeSrc> src((size_t)G);
+    for (int g = 0; g < G; ++g) src[(size_t)g] = MergeSrc{rec[g], first[g], toff[g], st[g]};
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t total = 0;
+    for (int r = 0; r < reps; ++r) {
+        std::vector<uint64_t> slice_base;
+        merge_plan(src.data(), G, cnt, slice, slice_base);
+        const int nt = (int)(slice_base.size() - 1);
+        total = slice_base[(size_t)nt];
+        const bool fits = tokens && total <= token_capacity;
+        tok_offsets[cnt] = total;
+        std::atomic<int> left{nt};
+        const MergeSrc *sp = src.data();
+        for (int t = 0; t < nt; ++t) {
+            const uint64_t a = (uint64_t)t * slice, b = std::min(cnt, a + slice), base = slice_base[(size_t)t];
+            std::atomic<int> *l = &left;
+            workers().submit([=] { merge_slice(sp, G, a, b, base, fits ? tokens : nullptr, tok_offsets, status); workers().task_done(*l); });
+        }
+        workers().wait_zero(left);
+    }
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (n_tokens) *n_tokens = total;
+    if (tokens && total > token_capacity) { set_error("token buffer too small: need %llu, capacity %llu", (unsigned long long)total, (unsigned long long)token_capacity); return KGPU_ERR_CAPACITY; }
+    return KGPU_OK;
 }

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
+import os
+
 import numpy as np
 
 from .dict import Dict
@@ -93,6 +95,31 @@ def _make_words(rng, pool, weights, count, len_lo, len_hi, len_p, seen, out):
 
 
 def build_dict(n_records: int = 392_000, seed: int = SEED_DICT, n_context: int = N_CONTEXT, dense: bool = False) -> SynthDict:
+    """The synthetic IPADIC-shaped dictionary (deterministic in its arguments).  KANPYO_SYNTH_CACHE=<dir>: the built object is kept there as a pickle
+    and loaded by later processes (the measurement tools set it: 20 s of building per process otherwise); unset = always built."""
+    cache = os.environ.get("KANPYO_SYNTH_CACHE")
+    if not cache:
+        return _build_dict(n_records, seed, n_context, dense)
+    import pickle
+    path = os.path.join(cache, f"synth_{n_records}_{seed}_{n_context}_{int(dense)}.pkl")
+    try:
+        with open(path, "rb") as fh:
+            return pickle.load(fh)
+    except (OSError, pickle.UnpicklingError, EOFError, AttributeError):
+        pass
+    sd = _build_dict(n_records, seed, n_context, dense)
+    try:
+        os.makedirs(cache, exist_ok=True)
+        tmp = path + f".{os.getpid()}"
+        with open(tmp, "wb") as fh:
+            pickle.dump(sd, fh, protocol=pickle.HIGHEST_PROTOCOL)
+        os.replace(tmp, path)
+    except OSError:
+        pass
+    return sd
+
+
+def _build_dict(n_records: int, seed: int, n_context: int, dense: bool) -> SynthDict:
     """dense=True: the same record count laid out for the lattice density real IPADIC text shows (N ~ 8-10 x C; the default shape
     gives 5.4): more short hiragana / kanji surfaces and nested prefixes (more dictionary words per start position), more records per surface
     (homographs: up to 12 on the single-kana particles), corpus weights that favour them -- buckets of more than eight predecessors at about

@@ -211,3 +211,65 @@ def concurrent_callers(tok: Tokenizer, utf8: np.ndarray, offsets: np.ndarray, th
     return {"wall_s": float(stats[0]), "p50_us": float(stats[1]), "p99_us": float(stats[2]), "mean_us": float(stats[3]), "mismatching_calls": int(stats[4]),
             "calls": int(stats[5]), "sentences": int(stats[6]), "sentences_per_s": float(stats[6] / stats[0]) if stats[0] > 0 else 0.0,
             "threads": int(threads), "n_pattern": [int(x) for x in pat]}
+
+
+TOKEN8_DTYPE = np.dtype([("id", "<i4"), ("packed", "<u4")])  # kgpu_token8
+
+
+def merge_shards(shards, cnt: int, slice_sentences: int = 2048, reps: int = 1, token_capacity: int | None = None, want_tokens: bool = True):
+    """Measurement / test helper (kgpu_debug_merge_shards, not part of the public header; needs NO device): the host-side merge of
+    kgpu_tokenize_batch_multi over one super-chunk of `cnt` sentences.  shards[g] = (rec[TOKEN8_DTYPE], first[uint32 m x 2], toff[uint64 m + 1],
+    status[uint8 m]) as shard g's compaction kernel leaves them; sentence j of the super-chunk is shard j mod G's local sentence j // G.
+    -> (rc, tokens, tok_offsets, status, n_tokens, seconds for all `reps` repetitions)."""
+    G = len(shards)
+    L = _lib.lib()
+    f = L.kgpu_debug_merge_shards
+    vp = C.c_void_p
+    f.argtypes = [C.c_int, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp,
+                  C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    f.restype = C.c_int
+    keep = [[np.ascontiguousarray(a, dtype=dt) for a, dt in zip(sh, (TOKEN8_DTYPE, np.uint32, np.uint64, np.uint8))] for sh in shards]
+    arr = lambda k: (vp * G)(*[sh[k].ctypes.data for sh in keep])
+    total = sum(int(sh[2][-1]) for sh in keep)
+    cap = total if token_capacity is None else int(token_capacity)
+    tokens = np.zeros(max(cap, 1), dtype=TOKEN_DTYPE)
+    toff = np.zeros(cnt + 1, dtype=np.uint64)
+    status = np.full(max(cnt, 1), 255, dtype=np.uint8)
+    n_tok, secs = C.c_uint64(0), C.c_double(0)
+    rc = f(G, cnt, arr(0), arr(1), arr(2), arr(3), int(slice_sentences), int(reps), tokens.ctypes.data if want_tokens else None, cap, toff.ctypes.data,
+           status.ctypes.data, C.byref(n_tok), C.byref(secs))
+    return rc, tokens[: min(cap, total)], toff, status[:cnt], int(n_tok.value), float(secs.value)
+
+
+def merge_bench(G: int = 8, sentences_per_shard: int = 8192, tokens_per_sentence: int = 32, reps: int = 20) -> dict:
+    """The rate of that merge alone on this host's CPUs (bench.py's `multi_merge` entry): G synthetic shard blocks of a super-chunk, every sentence
+    `tokens_per_sentence` records.  Per sentence the merge reads 8 t + 17 bytes and writes 24 t + 9 (t tokens): the 24-byte expansion is a
+    memory-bandwidth job, so the rate is quoted beside a plain copy of the same number of bytes by the same worker threads' count of NumPy threads."""
+    import time
+
+    cnt = G * sentences_per_shard
+    rng = np.random.default_rng(5)
+    shards = []
+    for g in range(G):
+        m = sentences_per_shard
+        toff = (np.arange(m + 1, dtype=np.uint64) * np.uint64(tokens_per_sentence))
+        nt = int(toff[-1])
+        rec = np.zeros(nt, dtype=TOKEN8_DTYPE)
+        rec["id"] = rng.integers(1, 390000, size=nt)
+        rec["packed"] = 1 | (2 << 2) | (6 << 14)
+        shards.append((rec, np.zeros((m, 2), dtype=np.uint32), toff, np.zeros(m, dtype=np.uint8)))
+    merge_shards(shards, cnt, reps=2)
+    rc, _, _, _, n_tok, secs = merge_shards(shards, cnt, reps=reps)
+    _lib.check(rc)
+    moved = reps * (n_tok * 32 + cnt * 26)
+    a = np.ones(n_tok * 24 // 8, dtype=np.uint64); b = np.empty_like(a)
+    b[:] = a
+    t0 = time.perf_counter()
+    for _ in range(5):
+        b[:] = a
+    copy_gbs = 5 * a.nbytes * 2 / (time.perf_counter() - t0) / 1e9
+    return {"sentences_per_s": reps * cnt / secs, "G": G, "sentences_per_super_chunk": cnt, "tokens_per_sentence": n_tok / cnt,
+            "bytes_moved_GB_per_s": moved / secs / 1e9, "one_thread_copy_GB_per_s": copy_gbs,
+            "what": "kgpu_tokenize_batch_multi's merge alone (no device): G shards' 8-byte records -> the caller's order as 24-byte records + global offsets + "
+                    "status bytes; slice totals from the shards' offset tables on the calling thread, one worker-pool task per 2048 sentences walks the G "
+                    "cursors (no division per sentence); the calling thread's own share is O(slices x G)"}
