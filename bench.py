@@ -56,6 +56,28 @@ def algorithmic_bytes(w):
     return a, b, c
 
 
+ROOFLINE_FIRST = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "stage_A_ms", "stage_B_ms", "stage_C_ms", "stage_A_frac", "stage_B_frac",
+                  "stage_C_frac", "valu_issue_frac", "valu_cycles_per_wave_op", "peak_measured_read", "frac_of_measured_read", "achieved_at_job_rate", "frac_at_job_rate",
+                  "kernel_alone_ms", "frac_alone", "avg_kernel_ms", "launches_in_flight")
+
+
+def hoist_roofline(r):
+    """The driver's record keeps the first ~23 scalar keys of `roofline` and drops nested objects: the north star's per-stage figures (stage B = connection-cost
+    gather + Viterbi sweep against the HBM roofline), the VALU issue fraction and the measured streaming read go first, as scalars; the nested forms stay behind them."""
+    st = r.get("stages") or {}
+    for k, name in (("A", "A_lattice"), ("B", "B_viterbi"), ("C", "C_emit")):
+        if name in st:
+            r[f"stage_{k}_ms"] = st[name]["ms_per_step"]
+            r[f"stage_{k}_frac"] = st[name]["frac"]
+    ins = r.get("instruction") or {}
+    if "valu_issue_frac" in ins:
+        r["valu_issue_frac"] = ins["valu_issue_frac"]
+        r["valu_cycles_per_wave_op"] = ins["cycles_per_wave_op"]
+    out = {k: r[k] for k in ROOFLINE_FIRST if k in r}
+    out.update({k: v for k, v in r.items() if k not in out})
+    return out
+
+
 def result_rate_guess(rate_1thread, nthreads):
     """Sentences per second to expect from `nthreads` host threads (sizes the all-core leg to about two seconds)."""
     return rate_1thread * max(1.0, 0.5 * nthreads)
@@ -387,6 +409,25 @@ def measure_config(tok, dev, wl, n_chars, passes, queue, streams, label, orc=Non
         c.set_profiling(PROFILE_OFF)
         c.profile(reset=True)
     run_job(eng, max(2, -(-eng.Q // max(wl.nb(0), 1))))  # warm: every context has grown its scratch arena, the routing estimate has settled
+    # ---- wavefront-slot occupancy: the kernels' own busy time (shader clocks between taking a sentence and its last store, summed over the wavefronts:
+    # the profiling instantiation's phase clocks, byte-step counting left out) over the duration of THAT pass x the slots the launch plan keeps resident
+    from kanpyo_amd.device import PROFILE_NO_T
+
+    for c in eng.ctxs:
+        c.set_profiling(PROFILE_WORK | PROFILE_NO_T)
+        c.phase_cycles(reset=True)
+    prof_passes = max(1, passes // 4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_job(eng, prof_passes)
+    dt_prof = (time.perf_counter() - t0) / prof_passes
+    busy = 0.0
+    for c in eng.ctxs:
+        busy += float(sum(c.phase_cycles(reset=True).values())) / prof_passes
+        c.work(reset=True)
+        c.set_profiling(PROFILE_OFF)
+    slots = plan["compute_units"] * max(plan["pool_workgroups_per_cu"] * plan["pool_wavefronts"], plan["window_workgroups_per_cu"])
+    slot_occupancy = busy / (dt_prof * CHIP_CLOCK_HZ * max(slots, 1))
     for c in eng.ctxs:
         c.profile(reset=True)
     torch.cuda.synchronize()
@@ -407,6 +448,9 @@ def measure_config(tok, dev, wl, n_chars, passes, queue, streams, label, orc=Non
         "work_per_sentence": {k: work[k] / max(work["sentences"], 1) for k in ("B", "C", "T", "N", "E", "K")},
         "algorithmic_bytes_per_pass": a + b + c_,
         "roofline_at_job_rate": {"achieved": (a + b + c_) / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (a + b + c_) / dt / 1e9 / HBM_PEAK_GBS},
+        "slot_occupancy": slot_occupancy,
+        "slot_occupancy_what": f"busy shader clocks of the wavefronts per pass ({busy:.4g}: the kernels' own phase clocks, profiling instantiation) / "
+                               f"(that pass's {dt_prof * 1e3:.3f} ms x {CHIP_CLOCK_HZ / 1e9:.1f} GHz x {slots} resident wavefront slots); the timed passes run the product instantiation",
         "routing": prof,
         "batch": wl.batch, "batches_per_pass": wl.nb(0), "batches_in_flight": eng.Q,
         "first_batch_bit_exact_vs_oracle": bit_exact,
@@ -1210,6 +1254,7 @@ def main():
 
         shutil.rmtree(extras_dir, ignore_errors=True)
 
+    result["roofline"] = hoist_roofline(result["roofline"])
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
     print(json.dumps(result), flush=True)

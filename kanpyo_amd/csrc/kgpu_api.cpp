@@ -18,6 +18,7 @@
 #include <pthread.h>
 #include <sched.h>
 #include <linux/futex.h>
+#include <sys/prctl.h>
 #include <sys/syscall.h>
 #include <climits>
 #include <memory>
@@ -1167,6 +1168,8 @@ static std::atomic<uint64_t> g_st[8];  // launches, prep ns, launch-call ns, pol
 static inline uint64_t now_ns() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
 extern "C" void kgpu_debug_small_trace(uint64_t out[8]) { for (int k = 0; k < 8; ++k) out[k] = g_st[k].exchange(0); }
 
+static unsigned cpu_budget();
+static void short_sleep_us(unsigned us);
 static int small_call(kgpu_dict *d, kgpu_ctx *c, SmallReq *const *reqs, size_t nreq) {
     static const bool trace = env_flag_now("KGPU_SMALL_TRACE");
     const uint64_t tt0 = trace ? now_ns() : 0;
@@ -1231,8 +1234,13 @@ static int small_call(kgpu_dict *d, kgpu_ctx *c, SmallReq *const *reqs, size_t n
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
-        // many callers inside the entry point: most of them need a CPU to assemble or pick up their results -- this thread's poll lets them have it
-        if ((spin & 63) == 63 && d->combiner_callers() > 8) sched_yield();
+        // many callers inside the entry point: most of them need a CPU to assemble or pick up their results -- this thread's poll lets them have it;
+        // more callers than CPUs: sleep through most of the launch's ~45 us instead (the poll costs the group's CPU quota, the sleep does not)
+        if ((spin & 63) == 63) {
+            const int callers = d->combiner_callers();
+            if (callers > (int)cpu_budget()) short_sleep_us(spin < 64 ? 25 : 8);
+            else if (callers > 8) sched_yield();
+        }
     }
     const uint64_t tt3 = trace ? now_ns() : 0;
     struct TraceOut { bool on; uint64_t t0, t1, t2, t3, n; ~TraceOut() { if (on) { const uint64_t t4 = now_ns(); g_st[0] += 1; g_st[1] += t1 - t0; g_st[2] += t2 - t1; g_st[3] += t3 - t2; g_st[4] += t4 - t3; g_st[5] += n; } } } trace_out{trace, tt0, tt1, tt2, tt3, n};
@@ -1295,6 +1303,38 @@ static int combine_max_in_flight() {
     static const int v = [] { const char *e = getenv("KGPU_COMBINE_LAUNCHES"); const int x = e ? atoi(e) : 4; return x < 1 ? 1 : x > 64 ? 64 : x; }();
     return v;
 }
+// CPUs this process may actually use: hardware threads, narrowed by the affinity mask and the cgroup's CPU quota (cpu.max, or cfs_quota_us / cfs_period_us).
+// With more callers inside the entry point than that, a spinning thread takes the CPU a sleeping caller needs -- and under a CFS quota the spinning burns the
+// whole group's budget for the period (round 4: 128 threads on a 16-CPU quota, p99 64 ms) -- so the waits below sleep instead of spinning.
+static unsigned cpu_budget() {
+    static const unsigned n = [] {
+        unsigned hw = std::thread::hardware_concurrency();
+        if (!hw) hw = 1;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) { const unsigned a = (unsigned)CPU_COUNT(&set); if (a && a < hw) hw = a; }
+        long long quota = -1, period = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32];
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else {
+            if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &quota) != 1) quota = -1; fclose(fq); }
+            if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
+        }
+        if (quota > 0 && period > 0) { const unsigned c = (unsigned)((quota + period - 1) / period); if (c && c < hw) hw = c; }
+        if (const char *e = getenv("KGPU_CPU_BUDGET")) { const int v = atoi(e); if (v > 0) hw = (unsigned)v; }   // (tests: force the crowded mode)
+        return hw;
+    }();
+    return n;
+}
+// A short sleep (the default 50 us timer slack would make 15 us into 65: the slack is lowered for the sleep and put back)
+static void short_sleep_us(unsigned us) {
+    const int slack = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+    if (slack > 2000) prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+    timespec ts{0, (long)us * 1000};
+    nanosleep(&ts, nullptr);
+    if (slack > 2000) prctl(PR_SET_TIMERSLACK, (unsigned long)slack, 0, 0, 0);
+}
 static void futex_wait(std::atomic<uint32_t> *w, uint32_t expected) { syscall(SYS_futex, (uint32_t *)w, FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0); }
 static void futex_wake_all(std::atomic<uint32_t> *w) { syscall(SYS_futex, (uint32_t *)w, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
 
@@ -1325,7 +1365,8 @@ static int small_call_combined(kgpu_dict *d, SmallReq &me) {
     if (win && cb.callers.load(std::memory_order_acquire) > 1) {
         timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
         for (;;) {
-            for (int k = 0; k < 16; ++k) {
+            if (cb.callers.load(std::memory_order_relaxed) > (int)cpu_budget()) short_sleep_us(10);   // more callers than CPUs: the window is slept, not spun
+            else for (int k = 0; k < 16; ++k) {
 #if defined(__x86_64__)
                 __builtin_ia32_pause();
 #endif

@@ -260,7 +260,8 @@ def make_corpus(sd: SynthDict, n: int, seed: int, kind: str = "cfg2") -> list:
     'cfg5' (2048 chars with a >1024 same-category run)."""
     rng = np.random.default_rng(seed)
     if kind == "cfg2":
-        lens = np.clip(np.rint(rng.normal(40, 8, size=n)), 8, 96).astype(int)
+        mean = float(os.environ.get("KANPYO_CFG2_MEAN", "40"))  # (tools only: the same shape at another mean length -- LDS-footprint experiments)
+        lens = np.clip(np.rint(rng.normal(mean, mean / 5, size=n)), 8, 96).astype(int)
         p_noise, heavy, kinds = 0.15, False, [0, 1, 2, 3, 4, 6]
     elif kind == "cfg3":
         lens = np.exp(rng.uniform(np.log(8), np.log(512), size=n)).astype(int)
