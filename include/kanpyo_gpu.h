@@ -154,7 +154,7 @@ typedef struct kgpu_plan_info {
     uint32_t pool_wavefronts;         /* ... independent wavefronts (= sentences in flight) sharing it             */
     uint32_t pool_workgroups_per_cu;  /* ... workgroups resident per CU (occupancy API)                            */
     uint32_t pool_max_pages;          /* ... pages of 64 a sentence may take before it is routed to the long path  */
-    uint32_t long_lds_bytes;          /* (rounds 2-3: a second long-sentence kernel; removed -- always 0.  The fields keep their places.)  */
+    uint32_t long_lds_bytes;          /* unused since round 4 (rounds 2-3: a second long-sentence kernel; removed) -- always 0; the three fields keep their places */
     uint32_t long_workgroups_per_cu;
     uint32_t long_workgroups;
     uint32_t window_lds_bytes;        /* windowed kernel (everything the pool kernel routes away: ~150 characters and more, any length; dense
@@ -162,9 +162,13 @@ typedef struct kgpu_plan_info {
     uint32_t window_workgroups_per_cu;/* ... resident per CU (occupancy API)                                       */
     uint32_t window_workgroups;       /* ... grid of one launch                                                    */
     uint32_t streams;                 /* HIP streams the dictionary's NULL-stream contexts share: 4 when the process has GPU_MAX_HW_QUEUES >= 5
-                                         (the library sets it to 8 itself when it is loaded before the HIP runtime initialises and the variable
+                                         (the library sets it to 16 itself when it is loaded before the HIP runtime initialises and the variable
                                          is unset), else 3 -- and kgpu_last_error() then carries a warning after kgpu_dict_create            */
-    uint32_t reserved[4];
+    uint32_t long_streams;            /* further streams, one per context up to this many, for batches whose chain starts with the windowed kernel
+                                         (long sentences: average length >= KGPU_WINDOW_FIRST bytes, default 1024): what the hardware queues leave
+                                         -- 8 with 16 queues, 2 with 8, 0 (such batches stay on `streams`) with HIP's default 4                */
+    uint32_t window_first_bytes;      /* ... that threshold (0 = every chain starts with the pool kernel)                                     */
+    uint32_t reserved[2];
 } kgpu_plan_info;
 int kgpu_ctx_get_plan(kgpu_ctx *c, kgpu_plan_info *out, size_t out_size);
 
@@ -251,9 +255,10 @@ void kgpu_host_free(void *p);
  * the RCCL gather).  All d_* pointers are device pointers on the dict's
  * device.  kgpu_tokenize_device only enqueues on the ctx stream;
  * kgpu_ctx_sync waits and reports the dense token count (or KGPU_ERR_CAPACITY). */
-int kgpu_ctx_create(kgpu_dict *d, void *hip_stream /* NULL: one of the dictionary's three shared streams */, kgpu_ctx **out);
-/* One batch in flight per ctx; keep three or more contexts busy to fill the chip.  Contexts may share a
- * stream (each waits on its own completion event); those created with NULL share three per dictionary. */
+int kgpu_ctx_create(kgpu_dict *d, void *hip_stream /* NULL: one of the dictionary's shared streams (kgpu_plan_info.streams of them) */, kgpu_ctx **out);
+/* One batch in flight per ctx; keep four or more contexts busy to fill the chip (eight for cfg 2's 4096-sentence batches).  Contexts may share a
+ * stream (each waits on its own completion event); those created with NULL share kgpu_plan_info.streams per dictionary, and a batch of long
+ * sentences is moved to one of kgpu_plan_info.long_streams for its duration.  With a caller-owned stream everything stays on that stream. */
 void kgpu_ctx_destroy(kgpu_ctx *c);
 int kgpu_tokenize_device(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_t *d_offsets, uint64_t n,
                          uint64_t total_bytes, kgpu_token *d_tokens, uint64_t token_capacity,

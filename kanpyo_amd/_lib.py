@@ -78,7 +78,7 @@ class Routing(C.Structure):  # kgpu_routing: read with its size, fields are only
 class PlanInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("compute_units", "pool_lds_bytes", "pool_wavefronts", "pool_workgroups_per_cu", "pool_max_pages",
                                           "long_lds_bytes", "long_workgroups_per_cu", "long_workgroups", "window_lds_bytes", "window_workgroups_per_cu", "window_workgroups",
-                                          "streams")] + [("reserved", C.c_uint32 * 4)]
+                                          "streams", "long_streams", "window_first_bytes")] + [("reserved", C.c_uint32 * 2)]
 
 
 class LatticeNode(C.Structure):

@@ -120,6 +120,7 @@ static void dict_release(kgpu_dict *d) {
     combiner_delete(d->combiner);
     (void)hipSetDevice(d->device);
     for (hipStream_t st : d->streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipStream_t st : d->long_streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (void *p : d->allocs) (void)hipFree(p);
     delete d;
 }
@@ -132,6 +133,11 @@ extern "C" const char *kgpu_last_error(void) { return g_err; }
 // and the caller has not set it.  Loaded too late (or with the variable set below 5) it runs on three streams and says so
 // (kgpu_plan_info.streams, and a warning in kgpu_last_error after kgpu_dict_create).
 static bool g_queues_ok = false;
+static int g_queues = 4;   // hardware queues the HIP runtime of this process has (or will have): HIP's default unless the variable says otherwise
+#ifndef KGPU_HW_QUEUES
+#define KGPU_HW_QUEUES 16
+#define KGPU_HW_QUEUES_STR "16"
+#endif
 static bool kfd_is_open() {   // has this process opened the compute driver already (= has a HIP / HSA runtime been initialised)?
     DIR *dir = opendir("/proc/self/fd");
     if (!dir) return true;     // cannot tell: assume the worst (three streams) rather than count on queues that may not be there
@@ -148,13 +154,25 @@ static bool kfd_is_open() {   // has this process opened the compute driver alre
 }
 __attribute__((constructor)) static void kgpu_preinit() {
     const char *e = getenv("GPU_MAX_HW_QUEUES");
-    if (e) { g_queues_ok = atoi(e) >= 5; return; }   // the caller's choice stands
+    if (e) { g_queues_ok = atoi(e) >= 5; g_queues = std::max(1, atoi(e)); return; }   // the caller's choice stands
     if (kfd_is_open()) return;                          // the runtime is up already: too late, three streams
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    setenv("GPU_MAX_HW_QUEUES", KGPU_HW_QUEUES_STR, 0);
     g_queues_ok = true;
+    g_queues = KGPU_HW_QUEUES;
 }
 static unsigned planned_streams() {
     static const unsigned n = getenv("KGPU_STREAMS") && atoi(getenv("KGPU_STREAMS")) > 0 ? (unsigned)atoi(getenv("KGPU_STREAMS")) : (g_queues_ok ? 4u : 3u);
+    return n;
+}
+// Streams for chains that start with the windowed kernel, beside the shared ones: what the hardware queues leave (16 queues: eight; 8: two; the default 4: none --
+// such chains then stay on the shared streams).  KGPU_LONG_STREAMS overrides (0 = off).
+static unsigned window_first_bytes();
+static unsigned planned_long_streams() {
+    static const unsigned n = [] {
+        if (const char *e = getenv("KGPU_LONG_STREAMS")) return (unsigned)std::max(0, std::min(16, atoi(e)));
+        const int spare = g_queues - 6;
+        return (unsigned)std::max(0, std::min(8, spare));
+    }();
     return n;
 }
 
@@ -424,7 +442,7 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
     *out = d;
     g_err[0] = 0;
     if (planned_streams() < 4)   // not an error: the handle is good, the message is there for whoever looks
-        set_error("warning: running on %u streams -- GPU_MAX_HW_QUEUES was %s when the HIP runtime initialised; set GPU_MAX_HW_QUEUES=8 in the environment "
+        set_error("warning: running on %u streams -- GPU_MAX_HW_QUEUES was %s when the HIP runtime initialised; set GPU_MAX_HW_QUEUES=16 in the environment "
                   "(or load this library before the first HIP call) for the full rate of concurrent batches", planned_streams(),
                   getenv("GPU_MAX_HW_QUEUES") ? "below 5" : "unset");
     return KGPU_OK;
@@ -460,7 +478,7 @@ extern "C" int kgpu_ctx_create(kgpu_dict *d, void *hip_stream, kgpu_ctx **out) {
     kgpu_ctx *c = new kgpu_ctx();
     c->dict = d;
     d->refs.fetch_add(1, std::memory_order_relaxed);
-    if (hip_stream) c->stream = (hipStream_t)hip_stream;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = true; }
     else {
         std::lock_guard<std::mutex> g(d->pool_mu);
         // Streams that really run side by side: HIP gives a process GPU_MAX_HW_QUEUES hardware queues (default 4), of
@@ -477,6 +495,7 @@ extern "C" int kgpu_ctx_create(kgpu_dict *d, void *hip_stream, kgpu_ctx **out) {
         } else {
             c->stream = d->streams[d->next_stream++ % d->streams.size()];
         }
+        c->short_stream = c->stream;
     }
     if (hipMalloc((void **)&c->d_ctl, sizeof(Control)) != hipSuccess ||
         hipHostMalloc((void **)&c->h_ctl, sizeof(Control), hipHostMallocMapped) != hipSuccess ||
@@ -485,7 +504,7 @@ extern "C" int kgpu_ctx_create(kgpu_dict *d, void *hip_stream, kgpu_ctx **out) {
         kgpu_ctx_destroy(c);
         return KGPU_ERR_HIP;
     }
-    if (hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->switch_ev, hipEventDisableTiming) != hipSuccess) {
         set_error("kgpu_ctx_create: hipEventCreate failed");
         kgpu_ctx_destroy(c);
         return KGPU_ERR_HIP;
@@ -499,7 +518,9 @@ extern "C" void kgpu_ctx_destroy(kgpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->dict->device);
     if (c->pending && c->done_ev) (void)hipEventSynchronize(c->done_ev);
+    if (c->counted_long) { c->dict->long_sentences_in_flight.fetch_sub(c->counted_long, std::memory_order_relaxed); c->counted_long = 0; }
     if (c->done_ev) (void)hipEventDestroy(c->done_ev);
+    if (c->switch_ev) (void)hipEventDestroy(c->switch_ev);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     c->arena.release(); c->ovf.release(); c->stat_slots.release(); c->stage.release(); c->tok_count.release();
     c->in_utf8.release(); c->in_off.release(); c->out_tok.release(); c->out_off.release(); c->out_status.release();
@@ -522,6 +543,44 @@ static int next_event(kgpu_ctx *c, hipEvent_t *ev) {
     return KGPU_OK;
 }
 
+// Which chain the next batch gets, and on which stream.  A batch of long sentences (by its average length: the host knows n and the bytes, not the
+// lengths) starts with the windowed kernel -- the pool launch in front of it would only route: a thousand 40 KB workgroups that each look at four sentences
+// and pass them on, waiting for LDS on a chip full of single-wavefront workgroups (cfg 5, 8 in flight: 2.97 -> 3.40 Gchar/s without it) -- and runs on a stream
+// of the long set, one per context, so that eight such launches overlap instead of four (-> 3.96; both: profiles/experiments/r05_long_chains.txt).
+// The context's previous batch is complete here (kgpu_ctx_sync), so switching streams needs no ordering for the context's own buffers; whatever the
+// host-buffer paths queued on the old stream for THIS batch (their H2D copy) is ordered in front by an event.
+static unsigned window_first_bytes() {
+    static const unsigned v = [] { const char *e = getenv("KGPU_WINDOW_FIRST"); const int x = e ? atoi(e) : 1024; return (unsigned)(x < 0 ? 0 : x); }();   // 0 = never
+    return v;
+}
+static int ctx_pick_chain(kgpu_ctx *c, uint64_t n, uint64_t total_bytes, bool dump) {
+    const unsigned lim = window_first_bytes();
+    c->window_first = lim && n && c->plan.n_pools && c->plan.window_lds_bytes && !dump && c->stop_after == 0 && !c->no_window && total_bytes >= (uint64_t)lim * n;
+    if (c->own_stream) return KGPU_OK;
+    hipStream_t want = c->short_stream;
+    // ... and so does a pool-first chain whose last batch sent an eighth or more of its sentences on to the windowed kernel: its launches behind the pool
+    // kernel are the long ones (cfg 3 in batches of 4096: 15.4 -> 17.5 M sentences/s on eight streams; a pool-ONLY chain loses there: cfg 2 101 -> 86)
+    if ((c->window_first || c->win_share_q8 >= 32) && planned_long_streams()) {
+        if (!c->long_stream) {
+            kgpu_dict *d = c->dict;
+            std::lock_guard<std::mutex> g(d->pool_mu);
+            if (d->long_streams.size() < planned_long_streams()) {
+                hipStream_t st = nullptr;
+                if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) d->long_streams.push_back(st);
+                else (void)hipGetLastError();
+            }
+            if (!d->long_streams.empty()) c->long_stream = d->long_streams[d->next_long++ % d->long_streams.size()];
+        }
+        if (c->long_stream) want = c->long_stream;
+    }
+    if (want != c->stream) {
+        HIPCHECK(hipEventRecord(c->switch_ev, c->stream));
+        HIPCHECK(hipStreamWaitEvent(want, c->switch_ev, 0));
+        c->stream = want;
+    }
+    return KGPU_OK;
+}
+
 static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
     // The Control block is zero here: the previous launch's scan kernel left it so.
     if (c->ctl_dirty) HIPCHECK(hipMemsetAsync(c->d_ctl, 0, sizeof(Control), c->stream));
@@ -534,7 +593,7 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
         HIPCHECK(hipEventRecord(e0, c->stream));
     }
     if (a.n) {
-        const int pools_now = c->dict->big_pool_batches.load(std::memory_order_relaxed) > 0 ? c->plan.n_pools : std::min(c->plan.n_pools, 1);
+        const int pools_now = (c->window_first && !c->no_window) ? 0 : c->dict->big_pool_batches.load(std::memory_order_relaxed) > 0 ? c->plan.n_pools : std::min(c->plan.n_pools, 1);
         c->last_pools = pools_now;
         // The windowed kernel is in the chain while recent batches left the pools sentences (starts armed) -- an empty launch of a few thousand
         // workgroups behind a chip full of long-running wavefronts is not free -- or always, without a pool kernel in front of it.
@@ -546,7 +605,17 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
         // over that list.
         c->last_tail = (pools_now == 0 && !window_now) || c->stop_after != 0 || a.dump_lattice || c->no_window ||
                        c->dict->tail_batches.load(std::memory_order_relaxed) > 0;
-        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->stop_after, c->stream, ef, window_now, c->last_tail);
+        // Two wavefronts per sentence (the windowed kernel's team form) when the list is short against the chip: every sentence of this batch AND of the
+        // window-first batches already in flight fits the form's resident workgroups -- a lone batch of 1000 documents fills a quarter of the single-
+        // wavefront slots and each document is one wavefront's chain; with eight such batches in flight the chip is full and the ordinary form is the better use of its LDS.
+        static const int team_mode = [] { const char *e = getenv("KGPU_WINDOW_TEAM"); return e ? atoi(e) : -1; }();   // 0: never, 2: whenever possible, default: by the load
+        bool team_now = false;
+        if (pools_now == 0 && window_now && c->plan.window_team_workgroups > 0 && team_mode != 0) {
+            if (!c->counted_long) { c->counted_long = (int)std::min<uint64_t>(a.n, 1u << 30); c->dict->long_sentences_in_flight.fetch_add(c->counted_long, std::memory_order_relaxed); }
+            team_now = team_mode == 2 || c->dict->long_sentences_in_flight.load(std::memory_order_relaxed) <= c->plan.window_team_workgroups;
+        }
+        c->last_team = team_now;
+        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->stop_after, c->stream, ef, window_now, c->last_tail, team_now);
         if (e != hipSuccess) { set_error("k_tokenize launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     } else if (timed) HIPCHECK(hipEventRecord(ef, c->stream));
     if (timed) HIPCHECK(hipEventRecord(e1, c->stream));
@@ -576,6 +645,7 @@ int kgpu::tokenize_device_impl(kgpu_ctx *c, const uint8_t *d_utf8, const uint64_
     HIPCHECK(hipSetDevice(c->dict->device));
     int rc;
     if (c->pending && (rc = kgpu_ctx_sync(c, nullptr)) != KGPU_OK && rc != KGPU_ERR_CAPACITY) return rc;
+    if ((rc = ctx_pick_chain(c, n, total_bytes, false))) return rc;
     if ((rc = c->arena.ensure(ARENA_INITIAL)) || (rc = c->stage.ensure((size_t)(total_bytes + n + 1) * sizeof(kgpu_token) + 64)) ||
         (rc = c->tok_count.ensure((size_t)(n + 1) * 4)) ||
         (rc = c->ovf.ensure((size_t)(n + 1) * 4 * 4)))
@@ -653,6 +723,12 @@ extern "C" void kgpu_expand_tokens(const kgpu_token8 *in, const uint64_t *tok_of
     }
 }
 
+// The pending batch is over (completed or given up): the context is free, its share of the dictionary's long sentences in flight is returned.
+static void ctx_retire(kgpu_ctx *c) {
+    c->pending = false;
+    if (c->counted_long) { c->dict->long_sentences_in_flight.fetch_sub(c->counted_long, std::memory_order_relaxed); c->counted_long = 0; }
+}
+
 extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
     if (!c) { set_error("kgpu_ctx_sync: null ctx"); return KGPU_ERR_INVALID_ARG; }
     HIPCHECK(hipSetDevice(c->dict->device));
@@ -674,7 +750,7 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
             c->tail_pass = false;
             int rc = enqueue(c, c->last);
             c->no_window = false;
-            if (rc) { c->pending = false; return rc; }
+            if (rc) { ctx_retire(c); return rc; }
             continue;
         }
         {   // KGPU_WINDOW_TRACE=1: why the windowed kernel handed sentences on (Control::phase[1..9] count its reasons in non-profiling runs)
@@ -686,7 +762,7 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
                         (unsigned long long)c->last.n, w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
             }
         }
-        const int li_last = c->last_pools - 1 + (c->last_window ? 1 : 0);   // the list the chain ended on
+        const int li_last = c->last_pools - 1 + (c->last_window ? 1 : 0) + (c->last_team ? 1 : 0);   // the list the chain ended on
         if (!c->last_tail && c->last.n && li_last >= 0 && !c->h_ctl->arena_overflow && c->h_ctl->ovf_count[li_last] > 0) {
             // The chain ended without its tail and a sentence needed it: ONLY what is missing (the windowed kernel if it was not in the chain,
             // then the general kernel), over the last work list (still in device memory; its length goes back into the control block the scan
@@ -700,27 +776,27 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
             c->tail_had_window = c->last_window;
             c->tail_count = c->h_ctl->ovf_count[li_last];
             int rc = enqueue_tail(c, li_last);
-            if (rc) { c->pending = false; c->tail_pass = false; return rc; }
+            if (rc) { ctx_retire(c); c->tail_pass = false; return rc; }
             continue;
         }
         if (c->h_ctl->arena_overflow) {
             // a lattice did not fit the scratch arena: grow it and redo the batch
             size_t want = c->arena.bytes * 2;
-            if (want > ARENA_MAX) { set_error("scratch arena exceeded %zu bytes", ARENA_MAX); c->pending = false; return KGPU_ERR_INTERNAL; }
+            if (want > ARENA_MAX) { set_error("scratch arena exceeded %zu bytes", ARENA_MAX); ctx_retire(c); return KGPU_ERR_INTERNAL; }
             int rc = c->arena.ensure(want);
-            if (rc) { c->pending = false; return rc; }
+            if (rc) { ctx_retire(c); return rc; }
             BatchArgs a = c->last;
             a.arena = (uint8_t *)c->arena.p; a.arena_bytes = c->arena.bytes;
             c->rt.arena_regrows++;
             c->tail_pass = false;  // (the whole batch runs again: nothing of an earlier pass is merged)
             // the rerun counts everything again: drop what the aborted run left in the per-wavefront slots (ctl->work went with the control block)
             if (a.stat_slots) HIPCHECK(hipMemsetAsync(a.stat_slots, 0, (size_t)STAT_SLOTS * STAT_WORDS * 8, c->stream));
-            if ((rc = enqueue(c, a))) { c->pending = false; return rc; }
+            if ((rc = enqueue(c, a))) { ctx_retire(c); return rc; }
             continue;
         }
         break;
     }
-    c->pending = false;
+    ctx_retire(c);
     bool first_window = c->last_window, first_tail = c->last_tail;   // what the FIRST pass of this batch had in its chain (the arming below decays on that)
     if (c->tail_pass) {   // the published block is the tail pass's: put back what the first pass had counted
         c->tail_pass = false;
@@ -749,7 +825,14 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
             else if (first_tail) c->dict->tail_batches.fetch_sub(8, std::memory_order_relaxed);
         }
     }
-    if (c->last.n && c->plan.n_pools) {
+    if (c->last.n && c->last_pools > 0)
+        c->win_share_q8 = c->plan.window_lds_bytes ? (uint32_t)std::min<uint64_t>(256, (uint64_t)c->h_ctl->ovf_count[c->last_pools - 1] * 256 / c->last.n) : 0u;
+    if (c->last.n && c->last_pools == 0 && c->last_window && c->plan.n_pools) {
+        // a chain that started with the windowed kernel: what it left arms the general kernel behind it, as above
+        if (c->h_ctl->ovf_count[c->last_team ? 1 : 0] > 0) c->dict->tail_batches.store(64, std::memory_order_relaxed);
+        else if (first_tail) c->dict->tail_batches.fetch_sub(8, std::memory_order_relaxed);
+    }
+    if (c->last.n && c->plan.n_pools && c->last_pools > 0) {
         // The pool kernel reserves est LDS bytes per input byte up front: a reservation that proves
         // too small costs a redo (late_count), one that is too large only idles pages until the
         // lattice is known -- steer for a redo rate of 1-3 %.  Applied to the value the batch ran with; races between
@@ -858,6 +941,8 @@ extern "C" int kgpu_ctx_get_plan(kgpu_ctx *c, kgpu_plan_info *out, size_t out_si
     p.window_lds_bytes = c->plan.window_lds_bytes; p.window_workgroups = (uint32_t)c->plan.window_workgroups;
     p.window_workgroups_per_cu = c->plan.window_lds_bytes ? (uint32_t)window_workgroups_per_cu(c->plan.window_lds_bytes) : 0u;
     p.streams = planned_streams();
+    p.long_streams = c->own_stream ? 0u : planned_long_streams();
+    p.window_first_bytes = (c->plan.n_pools && c->plan.window_lds_bytes) ? window_first_bytes() : 0u;
     std::memcpy(out, &p, std::min(out_size, sizeof p));
     return KGPU_OK;
 }

@@ -129,6 +129,7 @@ struct LaunchPlan {
     int general_workgroups;
     uint32_t window_lds_bytes;  // > 0: the windowed kernel (kgpu_window.hip) behind the pools; 0: the general kernel serves what they route away
     int window_workgroups;
+    int window_team_workgroups;  // resident workgroups of the windowed kernel's two-wavefronts-per-sentence form on the whole chip (0: not available)
 };
 
 // Launchers (kgpu_kernels.hip).  `stream` is a hipStream_t.
@@ -138,9 +139,11 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
                     uint32_t stop_after /* kgpu_ctx_set_ablation; 0 = run everything */, void *stream,
                     void *event_after_first /* hipEvent_t recorded behind the first (dominant) launch, or null */,
                     bool window_now /* the windowed kernel behind the pools (plan.window_lds_bytes) */,
-                    bool tail_now /* false: nothing behind a chain that has a work list (the host launches what is missing if a sentence needed it) */);
+                    bool tail_now /* false: nothing behind a chain that has a work list (the host launches what is missing if a sentence needed it) */,
+                    bool team_now = false /* a chain without pool launches: the windowed kernel's two-wavefronts-per-sentence form first, its ordinary form behind it */);
 int launch_tail_only(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int list_index, bool window_was_in_chain, void *stream);
 int window_workgroups_per_cu(uint32_t lds_bytes);
+int window_team_workgroups_per_cu(uint32_t lds_bytes);
 int launch_general_only(const DictView &d, const BatchArgs &a, void *stream);
 int launch_small_call(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, void *stream);  // pool kernel alone, one sentence per wavefront  // kgpu_lattice_dump: HBM-scratch kernel alone
 int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream);  // host_ctl: device pointer of the pinned result block

@@ -527,13 +527,13 @@ int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
 // Launch chain: the LDS page-pool kernel(s) -> the windowed kernel (whatever the pools route away: long sentences, lattices too dense for a
 // pool) -> the general kernel (what the windowed kernel hands back: the last resort).  Every launch is a persistent grid over its work list
 // (the first one: the identity over [0, n)) and pushes what it does not serve onto the next launch's list.
-int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, void *stream);  // kgpu_window.hip
+int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, int team, void *stream);  // kgpu_window.hip
 
 static int launch_window_over(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, const uint32_t *in_list, const unsigned int *in_count, int li, void *stream) {
     WorkIO io{in_list, in_count, a.ovf[li], &a.ctl->ovf_count[li], nullptr};
     uint64_t wg = plan.window_workgroups;
     if (!in_list && a.n < wg) wg = a.n;
-    return launch_tokenize_window(d, a, io, plan.window_lds_bytes, (int)(wg ? wg : 1), stream);
+    return launch_tokenize_window(d, a, io, plan.window_lds_bytes, (int)(wg ? wg : 1), 1, stream);
 }
 static int launch_general_over(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, const uint32_t *in_list, const unsigned int *in_count, uint32_t stop_after, void *stream) {
     WorkIO io{in_list, in_count, nullptr, nullptr, nullptr};
@@ -544,7 +544,7 @@ static int launch_general_over(const DictView &d, const BatchArgs &a, const Laun
 }
 
 int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, uint32_t stop_after, void *stream,
-                    void *event_after_first, bool window_now, bool tail_now) {
+                    void *event_after_first, bool window_now, bool tail_now, bool team_now) {
     Control *ctl = a.ctl;
     const uint32_t *in_list = nullptr;
     const unsigned int *in_count = nullptr;
@@ -562,6 +562,16 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
     }
     if (event_after_first && (plan.n_pools == 0 || n_pools_now == 0) && hipEventRecord((hipEvent_t)event_after_first, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
     if (window_now && plan.window_lds_bytes && stop_after == 0) {
+        if (team_now && !in_list && plan.window_team_workgroups > 0 && a.n) {
+            // a short list of long sentences: two wavefronts per sentence (kgpu_window.hip, TEAM), one workgroup each; what that form cannot hold goes on to
+            // the ordinary form behind it
+            WorkIO io{nullptr, nullptr, a.ovf[li], &ctl->ovf_count[li], nullptr};
+            int e = launch_tokenize_window(d, a, io, plan.window_lds_bytes, (int)std::min<uint64_t>(a.n, 1u << 30), 2, stream);
+            if (e) return e;
+            in_list = a.ovf[li];
+            in_count = &ctl->ovf_count[li];
+            ++li;
+        }
         int e = launch_window_over(d, a, plan, in_list, in_count, li, stream);
         if (e) return e;
         in_list = a.ovf[li];
@@ -681,6 +691,7 @@ LaunchPlan default_launch_plan(int device) {
         const int per_cu = kib ? window_workgroups_per_cu(t.window_lds_bytes) : 0;
         t.window_workgroups = cus * per_cu;
         if (per_cu <= 0) t.window_lds_bytes = 0;
+        t.window_team_workgroups = t.window_lds_bytes ? cus * std::max(0, window_team_workgroups_per_cu(t.window_lds_bytes)) : 0;
     }
     if (const char *e = getenv("KGPU_GENERAL_WG")) { int v = atoi(e); if (v > 0) t.general_workgroups = v; }
     if (const char *e = getenv("KGPU_POOL_WG")) { int v = atoi(e); if (v > 0 && t.n_pools) t.pool_workgroups[0] = v; }

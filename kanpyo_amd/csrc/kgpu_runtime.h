@@ -86,6 +86,12 @@ struct kgpu_dict {
     // number of contexts shares three streams; each context waits on its own completion event.
     std::vector<hipStream_t> streams;
     unsigned next_stream = 0;
+    // A second set for chains that START with the windowed kernel (batches of long sentences: kgpu_api.cpp, ctx_pick_chain): such a launch holds a thousand
+    // single-wavefront workgroups for milliseconds and its slots empty out one by one, so the chip fills only when more of them overlap than the four launches
+    // the pool kernel wants -- one stream per context, up to eight, created when the first such batch arrives (round 5: cfg 5 2.97 -> 3.96 Gchar/s).
+    std::vector<hipStream_t> long_streams;
+    unsigned next_long = 0;
+    std::atomic<int> long_sentences_in_flight{0};   // sentences of window-first batches between enqueue and completion (decides the two-wavefront form)
     std::vector<uint32_t> left_of_rank, right_of_rank;  // device (ranked) context id -> the dictionary's own; empty = identity
     // One reference for the handle the caller holds plus one per live context: the tables and the shared
     // streams go when the last one does (a context outliving kgpu_dict_destroy keeps working).
@@ -94,7 +100,15 @@ struct kgpu_dict {
 
 struct kgpu_ctx {
     kgpu_dict *dict = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // the stream of the pending / next batch (one of the dictionary's shared streams unless the caller gave one)
+    hipStream_t short_stream = nullptr, long_stream = nullptr;   // what `stream` alternates between (library-owned streams only)
+    bool own_stream = false;            // the caller's stream: never switched
+    bool window_first = false;          // the next batch's chain starts with the windowed kernel (no pool launch in front)
+    bool last_team = false;             // the pending batch's chain started with the two-wavefronts-per-sentence form (one more work list in the chain)
+    int counted_long = 0;               // what the pending batch added to kgpu_dict::long_sentences_in_flight
+    uint32_t win_share_q8 = 0;          // share of the last pool-first batch's sentences that the pools routed to the windowed kernel (x256): an eighth or more
+                                        // and the next batch runs on the context's long stream too (cfg 3: a third of the sentences, three quarters of the characters)
+    hipEvent_t switch_ev = nullptr;     // orders a batch behind what was queued on the stream the context used before
     hipEvent_t done_ev = nullptr;  // recorded behind the batch's last kernel: contexts may share a stream
     Control *d_ctl = nullptr;
     Control *h_ctl = nullptr;  // pinned + device-mapped: the scan kernel publishes the launch's Control block here

@@ -52,6 +52,9 @@ constexpr uint32_t NONE16 = 0xFFFFu;
 constexpr uint32_t BIGP = 64;               // a position with more predecessors than this gets no pair table: its connection costs are loaded inside its (any-shape) step
 constexpr uint32_t SLOWT = 4;               // targets relaxed together on the any-shape path (registers: a 64-bit key and a row pointer each)
 constexpr uint32_t PAIR_MIN = 1024;        // bytes of pair table a window wants beyond its largest position
+constexpr uint32_t CCAP = 384;             // team mode: entries of a carry list (two banks of them in the workgroup's shared LDS)
+constexpr uint32_t SEED_MARK = 0xC0000000u, SEED_FAR = 0x20000000u;   // team mode: a seed's dp is not known when its bucket slot is filled -- the slot holds
+                                           // SEED_MARK | index into the carry bank (| SEED_FAR: offset into the FIFO from its head) until the sweep starts
 
 struct Far { uint32_t end; int32_t dp; uint32_t right; uint32_t node; };          // a bucket entry that outlives its window (16 B)
 struct NodeRec { int32_t sid; uint32_t start; };   // what the tokens need (8 B); the best predecessor lives in a dense array of its own (the backtrace reads every node's)
@@ -94,14 +97,38 @@ __device__ __forceinline__ uint32_t win_walk(const DictView &d, BY &&byte, uint3
 
 }  // namespace
 
+// ---- TEAM mode: TEAM wavefronts per sentence (one workgroup), for work lists shorter than the chip's wavefront slots (a lone batch of long documents fills a
+// quarter of them and every document is one wavefront's dependent chain).  Window k of a sentence belongs to wavefront k mod TEAM, which runs the WHOLE window
+// -- the code below, in its own region of the workgroup's LDS -- but two things chain the windows of a sentence (src/lattice.rs:101-114: the build of a position
+// needs nothing of its neighbours, :116-142: the relaxation does), and each is a token passed from window to window:
+//   * the STRUCTURE token: where the window starts (the one before may have been shortened to fit the LDS), the global index of its first node, which bucket
+//     entries the windows before carry into it (ends, right ids, node indices -- not their costs) and which FIFO entries, the chunk tables.  Held from staging to
+//     the end of emit; the next wavefront stages, walks, scans and emits its window while this one gathers its connection costs and relaxes.
+//   * the VALUE token: the dp of the carried and far entries.  Held from the first relaxation to the last.
+// Per window and wavefront: [structure: stage, seeds, walk, scan, emit] -> gather -> [value: seed dp, sweep, carry / far dp out] -> node records out; with TEAM = 2
+// both chains (structure ~920, value ~640 of a window's ~2000 clocks per character) fit inside the other wavefront's window, so a sentence runs about twice as
+// fast on twice the LDS -- which is why the host picks this only when the slots would otherwise stay empty (launch_tokenize_window).  Seeds enter a window's
+// buckets before their dp exists: the slot holds a marker (SEED_MARK | index) that the value phase replaces.  The carry lists live in two banks of the
+// workgroup's shared LDS (window k writes bank k & 1, window k + 1 reads it); what this form cannot hold (a carry list beyond CCAP entries) fails the
+// sentence on to the next launch: the single-wavefront form of this kernel.
+struct TeamState {
+    uint32_t s_done, v_done;            // windows whose structure / value phase is through
+    uint32_t finished, failed, why;
+    uint32_t w0, gw, ncarry, fhead, ftail, last_far_end, fhead_end, wbyte0, wlim, nchunks_have, fchunks_have;
+    uint32_t eos_pre;
+    uint32_t go, C;                     // sentence set-up by wavefront 0: 1 = windows follow
+    uint32_t slab_lo, slab_hi;
+    uint32_t wT, wE;                    // work counters of the windows (PROF)
+};
+
 // PROF: device-side work counters + per-phase shader clocks (KGPU_PROFILE_WORK) -- a separate instantiation: the accumulators cost ~40 SGPRs
 struct WinArgs { DictView d; BatchArgs a; WorkIO io; uint32_t lds_bytes; };
-template <bool PROF>
 #ifndef KGPU_WIN_WPE
 #define KGPU_WIN_WPE 4
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE))) void k_tokenize_window(WinArgs) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+template <bool PROF, int TEAM>
+__global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM > 1 ? 3 : KGPU_WIN_WPE))) void k_tokenize_window(WinArgs) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
     // The arguments stay in the kernarg segment; every phase reads the fields it uses from there (KW_ARGS(): scalar loads behind a pointer
     // made opaque by an empty asm) -- as by-value parameters the ~90 dwords are live from entry to exit and spill (kgpu_pool.hip does the same).
     typedef const __attribute__((address_space(4))) WinArgs *KArgs;
@@ -112,8 +139,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
         a.utf8 = kq_->a.utf8; a.offsets = kq_->a.offsets; a.n = kq_->a.n; a.ctl = kq_->a.ctl; a.arena = kq_->a.arena; a.arena_bytes = kq_->a.arena_bytes; a.stage = kq_->a.stage; a.tok_count = kq_->a.tok_count; a.status = kq_->a.status; a.count_work = kq_->a.count_work; \
         io.in_list = kq_->io.in_list; io.in_count = kq_->io.in_count; io.out_list = kq_->io.out_list; io.out_count = kq_->io.out_count; } while (0)
     KW_ARGS();
-    const uint32_t lds_bytes = kargs->lds_bytes;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lds_bytes = kargs->lds_bytes;   // of ONE wavefront's region
+    const uint32_t lane = threadIdx.x & 63u, wave = TEAM > 1 ? bcast32(threadIdx.x >> 6) : 0u;
+    // LDS of the workgroup: [chunk tables | TEAM > 1: team state, two carry banks] [region of wavefront 0] [region of wavefront 1] ...
+    constexpr uint32_t SHARED0 = 4 * NCHUNKS + 4 * FCHUNKS;
+    constexpr uint32_t SHARED = TEAM > 1 ? ((SHARED0 + (uint32_t)sizeof(TeamState) + 15u) & ~15u) + 2u * (8u * CCAP + CCAP) : SHARED0;
+    TeamState *team = (TeamState *)(lds_all + SHARED0);
+    uint32_t *bank_dp[2], *bank_y[2];
+    uint8_t *bank_rel[2];
+    if constexpr (TEAM > 1) {
+        uint8_t *b0 = lds_all + ((SHARED0 + (uint32_t)sizeof(TeamState) + 15u) & ~15u);
+        for (int k = 0; k < 2; ++k) { bank_dp[k] = (uint32_t *)(b0 + (size_t)k * 9u * CCAP); bank_y[k] = bank_dp[k] + CCAP; bank_rel[k] = (uint8_t *)(bank_y[k] + CCAP); }
+    }
+    if constexpr (TEAM > 1) if (threadIdx.x == 0) { team->nchunks_have = 0; team->fchunks_have = 0; }   // (the chunk tables persist across the workgroup's sentences; ordered by the first sentence's barrier)
+    uint8_t *const lds = lds_all + SHARED + wave * lds_bytes - SHARED0;   // (the per-wavefront arrays below are carved from `lds + off0`, off0 starting behind the chunk tables' size)
     const int32_t base_root = d.da[1].base;
     Slab sa{nullptr, 0};
     uint64_t accW[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -122,8 +161,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
 
     // ---- LDS, fixed part (persists across the windows of a sentence; the chunk tables across sentences) ----
     uint32_t off0 = 0;
-    uint32_t *nchunk = (uint32_t *)(lds + off0); off0 += 4 * NCHUNKS;   // node-record chunks this workgroup owns (arena offsets / 256)
-    uint32_t *fchunk = (uint32_t *)(lds + off0); off0 += 4 * FCHUNKS;   // far-entry chunks
+    uint32_t *nchunk = (uint32_t *)(lds_all + off0); off0 += 4 * NCHUNKS;   // node-record chunks this workgroup owns (arena offsets / 256); shared by the team
+    uint32_t *fchunk = (uint32_t *)(lds_all + off0); off0 += 4 * FCHUNKS;   // far-entry chunks
     uint8_t *ltext = lds + off0;                 off0 += LTEXT;
     uint32_t *cbw = (uint32_t *)(lds + off0);    off0 += 4 * (WIN + 2);   // byte offset of the window's characters (and one past)
     uint32_t *nb = (uint32_t *)(lds + off0);     off0 += 4 * (WIN + 2);   // nodes starting at position q -> first local node index
@@ -151,7 +190,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
     const uint32_t moff = (lds_bytes - mbytes) & ~15u;
     auto carry8 = [&](uint32_t n) { return (uint2 *)(lds + moff - align_up(8 * n, 16)); };
     auto crel = [&](uint32_t n) { return lds + moff - align_up(8 * n, 16) - align_up(n, 16); };
-    auto cbytes = [&](uint32_t n) { return align_up(8 * n, 16) + align_up(n, 16); };
+    auto cbytes = [&](uint32_t n) { return TEAM > 1 ? 0u : align_up(8 * n, 16) + align_up(n, 16); };   // (team mode: the carry lists live in the shared banks)
+    // team tokens: LDS words, polled (the wavefronts of a team never meet at a barrier inside a sentence's windows)
+    auto lds_get = [&](uint32_t *w) { return bcast32(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); };
+    auto lds_put = [&](uint32_t *w, uint32_t v) { if (lane == 0) __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto team_release = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); };
+    auto team_acquire = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
 
     auto fail = [&](uint64_t s) {  // this sentence needs the HBM-lattice kernel: on to the next launch's list, or (no list) the host reruns the batch
         if (io.out_list) { work_defer(io, lane, s); if (lane == 0) a.tok_count[s] = 0; }
@@ -182,20 +226,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
         const uint32_t B = (uint32_t)(a.offsets[s + 1] - b0);
         const uint8_t *text = a.utf8 + b0;
         uint64_t tlast = PROF ? __builtin_amdgcn_s_memtime() : 0;
-        if (cfg_bad) { fail(s); continue; }
+        // ---- sentence set-up and the two prepasses: the workgroup's first wavefront (a team's others wait at the barrier below)
+        uint2 *crec = nullptr; uint32_t *path = nullptr; uint16_t *code16 = nullptr;
+        uint32_t C = 0;
+        const uint64_t na = (uint64_t)B + 4;
+        const bool ct = d.da2 != nullptr;
+        auto setup_fence = [&]() { if constexpr (TEAM == 1) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } };
+        if constexpr (TEAM > 1) __syncthreads();   // the sentence before is through on every wavefront (its backtrace read what the others wrote; the slab is free)
+        bool go = true;
+        if (TEAM == 1 || wave == 0) go = [&]() -> bool {
+            if (cfg_bad) { fail(s); return false; }
 
         // ---- slab: one 8-byte record per character in HBM (written by the two prepasses, read once per window), then the backtrace's path ----
         //   .x = byte offset (24 bits) | category << 24     .y = BMP code point (0xFFFF: not BMP) | same-category run length from here << 16
-        if (B >= (1u << 24)) { fail(s); continue; }
-        const uint64_t na = (uint64_t)B + 4;
+            if (B >= (1u << 24)) { fail(s); return false; }
         if (!slab_ensure(sa, na * 14 + 64, a, lane)) {
             if (lane == 0) { a.status[s] = KGPU_SENT_NO_SCRATCH; a.tok_count[s] = 0; }
-            continue;
+            return false;
         }
-        uint2 *crec = (uint2 *)sa.ptr;              // [C]: {B, 0}
-        uint32_t *path = (uint32_t *)(crec + na);   // backtrace
-        uint16_t *code16 = (uint16_t *)(path + na); // char-level trie: the characters' codes (0xFFFF: in no key), [C] = 0xFFFF
-        const bool ct = d.da2 != nullptr;
+        crec = (uint2 *)sa.ptr;              // [C]: {B, 0}
+        path = (uint32_t *)(crec + na);      // backtrace
+        code16 = (uint16_t *)(path + na);    // char-level trie: the characters' codes (0xFFFF: in no key), [C] = 0xFFFF
 
         // ---- pass 0: decode + validate + category (char_category_def.rs:33-38), 256 bytes a round: the round's text goes through LDS (the
         // continuation bytes are read there), the next round's is in flight meanwhile, and the four category loads of a round are issued together --
@@ -203,7 +254,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
 #ifdef KGPU_WIN_SPLIT  // measurement build: slot 0 = sentence set-up, 1 (+ stage) = decode pass, 2 (+ seeds) = run-length pass
         KW_T(0);
 #endif
-        uint32_t C = 0, bad = 0, lensum = 0;
+        uint32_t bad = 0, lensum = 0;
         {
             uint32_t pf[5];
             auto fetch = [&](uint32_t k0) {  // (unconditional loads at clamped addresses: a load under a lane mask is waited for on the spot)
@@ -265,10 +316,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
         lensum = bcast32(wave_sum(lensum));
         if (__ballot(bad != 0) != 0 || lensum != B) {
             if (lane == 0) { a.status[s] = KGPU_SENT_INVALID_UTF8; a.tok_count[s] = 0; }
-            continue;
+            return false;
         }
         if (lane == 0) { crec[C] = make_uint2(B, 0u); if (ct) code16[C] = 0xFFFFu; }
-        __syncthreads();
+        setup_fence();
 #ifdef KGPU_WIN_SPLIT
         KW_T(1);
 #endif
@@ -296,20 +347,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                 }
             }
         }
-        __syncthreads();
+        setup_fence();
 
 #ifdef KGPU_WIN_SPLIT
         KW_T(2);
 #else
         KW_T(0);
 #endif
+        return true;
+        }();
+        if constexpr (TEAM > 1) {
+            if (wave == 0 && lane == 0) {
+                team->go = go ? 1u : 0u; team->C = C; team->slab_lo = (uint32_t)(uintptr_t)sa.ptr; team->slab_hi = (uint32_t)((uintptr_t)sa.ptr >> 32);
+                team->s_done = 0; team->v_done = 0; team->finished = 0; team->failed = 0; team->why = 0; team->eos_pre = NONE; team->wT = 0; team->wE = 0;
+                team->w0 = 0; team->gw = 1; team->ncarry = 1; team->fhead = 0; team->ftail = 0; team->last_far_end = 0; team->fhead_end = 0xFFFFFFFFu; team->wbyte0 = 0; team->wlim = WIN;
+                bank_dp[1][0] = 0u; bank_y[1][0] = d.bos_right; bank_rel[1][0] = 0;   // BOS: node 0, ends at 0, dp None -> 0 (lattice.rs:127,156-164): what "window -1" carries
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            go = bcast32(team->go) != 0;
+            if (go && wave != 0) {
+                C = bcast32(team->C);
+                crec = (uint2 *)(((uintptr_t)bcast32(team->slab_hi) << 32) | (uintptr_t)bcast32(team->slab_lo));
+                path = (uint32_t *)(crec + na);
+                code16 = (uint16_t *)(path + na);
+            }
+        }
+        if (!go) continue;
         // ---- the windows ----
         uint32_t w0 = 0, gw = 1 /* global index of the window's first node: BOS is node 0 */, ncarry = 1, fhead = 0, ftail = 0, last_far_end = 0;
         uint32_t fhead_end = 0xFFFFFFFFu;   // end position of the FIFO's head entry (0xFFFFFFFF: the FIFO is empty)
         uint32_t wT = 0, wE = 0;
         bool failed = false;
         uint32_t why = 0;  // which limit a failed sentence ran into (Control::phase[why] counts them: KGPU_WINDOW_TRACE)
-        if (lane == 0) { carry8(1)[0] = make_uint2(0u, d.bos_right); crel(1)[0] = 0; }  // BOS: node 0, ends at 0, dp None -> 0 (lattice.rs:127,156-164)
+        if constexpr (TEAM == 1) if (lane == 0) { carry8(1)[0] = make_uint2(0u, d.bos_right); crel(1)[0] = 0; }  // BOS: node 0, ends at 0, dp None -> 0 (lattice.rs:127,156-164)
         uint32_t wbyte0 = 0;  // first byte of the next window's characters
         uint2 pf_rec = make_uint2(0u, 0u);
         uint32_t pf_t0 = 0, pf_t1 = 0;
@@ -327,11 +399,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
             if (4 * lane < tl) pf_t0 = g32[lane];
             if (4 * (64 + lane) < tl) pf_t1 = g32[64 + lane];
         };
-        prefetch(0, 0);
+        if constexpr (TEAM == 1) prefetch(0, 0);
         uint32_t wlim = WIN;  // positions per window: halved when a window's lattice outgrows the LDS, grown again by how empty the LDS was (see the end of the loop)
         wave_sync();
         uint32_t eos_pre = NONE;
-        for (; w0 <= C && !failed; ) {
+        uint32_t kwin = wave;                     // team: the index of this wavefront's next window
+        bool holding = false, have_v = false;     // team: inside the structure phase (a window that is redone shorter keeps the token) / the value phase
+        for (; TEAM > 1 || (w0 <= C && !failed); ) {
+            if constexpr (TEAM > 1) {
+                if (!holding) {   // the structure token: window kwin - 1 has been emitted (or the sentence is over, one way or the other)
+                    bool stop = false;
+                    for (;;) {
+                        if (lds_get(&team->failed) | lds_get(&team->finished)) { stop = true; break; }
+                        if (lds_get(&team->s_done) == kwin) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (stop) break;
+                    team_acquire();
+                    w0 = bcast32(team->w0); gw = bcast32(team->gw); ncarry = bcast32(team->ncarry); fhead = bcast32(team->fhead); ftail = bcast32(team->ftail);
+                    last_far_end = bcast32(team->last_far_end); fhead_end = bcast32(team->fhead_end); wbyte0 = bcast32(team->wbyte0); wlim = bcast32(team->wlim);
+                    nchunks_have = bcast32(team->nchunks_have); fchunks_have = bcast32(team->fchunks_have);
+                    if (w0 > C) { lds_put(&team->finished, 1u); break; }   // the window before was the last one
+                    holding = true; have_v = false; staged = false;
+                    prefetch(w0, wbyte0);   // (nobody could request this window's records ahead: where it starts was not known)
+                }
+            }
+            const uint32_t pb = (kwin + 1u) & 1u;   // team: the carry bank the window before wrote
             const uint32_t nw = min(wlim, C + 1 - w0);         // positions of this window; position C (if in it) holds only EOS
             const uint32_t nwc = min(nw, C - w0);              // ... of which characters
             const uint32_t rb = gw >= 0x8000u ? gw - 0x8000u : 0u;   // node indices inside the window's LDS are 16-bit offsets from here
@@ -364,7 +457,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
             KW_ARGS();
             // -- seeds: carried entries per relative end; FIFO entries that end inside this window
             uint32_t seed_bad = 0;
-            for (uint32_t k = lane; k < ncarry; k += 64) atomicAdd(&boff[crel(ncarry)[k]], 1u);
+            for (uint32_t k = lane; k < ncarry; k += 64) atomicAdd(&boff[TEAM > 1 ? bank_rel[pb][k] : crel(ncarry)[k]], 1u);
             uint32_t fin = 0;  // FIFO entries [fhead, fhead + fin) end inside this window
             uint32_t next_head_end = fhead_end;   // the end position of the entry that will head the FIFO once this window is through
             // (the head's end position is known from the scan that stopped at it: while it lies beyond the window no entry ends inside it -- ends never
@@ -505,8 +598,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                 break;
             }
             if ((uint64_t)gw + N >= ((uint64_t)NCHUNKS << NCH_LOG)) { failed = true; why = 3; break; }
+            if (TEAM > 1 && Nb - boff[nw] > CCAP) { failed = true; why = 7; break; }   // the carry list does not fit a bank: the single-wavefront form takes the sentence
             const uint32_t mcap = (lds_bytes - off) / 2;
-            if (w0 + nw <= C) prefetch(w0 + nw, wbyte_next);  // the next window's stage: in flight while this one is emitted and relaxed
+            if constexpr (TEAM == 1) if (w0 + nw <= C) prefetch(w0 + nw, wbyte_next);  // the next window's stage: in flight while this one is emitted and relaxed
             wave_sync();
 
             KW_T(4);
@@ -559,9 +653,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
             wave_sync();
             // -- seeds into their buckets: carried entries, then the staged FIFO entries
             for (uint32_t k = lane; k < ncarry; k += 64) {
-                const uint32_t rel = crel(ncarry)[k];
+                const uint32_t rel = TEAM > 1 ? (uint32_t)bank_rel[pb][k] : (uint32_t)crel(ncarry)[k];
                 const uint32_t slot = boff[rel] + atomicAdd(&bfill[rel], 1u);
-                bk[slot] = carry8(ncarry)[k];  // (its node index is already relative to this window's base)
+                if constexpr (TEAM > 1) bk[slot] = make_uint2(SEED_MARK | k, bank_y[pb][k]);   // (its dp follows with the value token)
+                else bk[slot] = carry8(ncarry)[k];  // (its node index is already relative to this window's base)
                 brel[slot] = (uint8_t)rel;
             }
             for (uint32_t f = fhead + lane; f < fhead + fin; f += 64) {
@@ -569,7 +664,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                 const uint32_t rel = e.end - w0;
                 if ((wideN[rel] & 0x7FFFFFFFu) == 0) {
                     const uint32_t slot = boff[rel] + atomicAdd(&bfill[rel], 1u);
-                    bk[slot] = make_uint2((uint32_t)e.dp, (e.right & 0xFFFFu) | ((e.node - rb) << 16));
+                    bk[slot] = make_uint2(TEAM > 1 ? (SEED_MARK | SEED_FAR | (f - fhead)) : (uint32_t)e.dp, (e.right & 0xFFFFu) | ((e.node - rb) << 16));
                     brel[slot] = (uint8_t)rel;
                 }
             }
@@ -599,6 +694,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
             }
             wave_sync();
 
+            [[maybe_unused]] const uint32_t fhead_w = fhead, ftail_w = ftail;   // the FIFO as this window found it
+            if constexpr (TEAM > 1) {
+                // ---- the structure of this window is complete: hand the structure token on.  Everything the next window needs that is not a dp -- the node
+                // chunks, the far entries' ends / right ids / nodes in the FIFO, the carried entries' right ids / nodes / relative ends in this window's bank,
+                // where the next window starts -- is written here; the dp of both follow with the value token.
+                KW_ARGS();
+                if (!chunk_get(nchunk, nchunks_have, (gw + N - 1) >> NCH_LOG, (4u + (uint32_t)sizeof(NodeRec)) << NCH_LOG)) { failed = true; why = 3; break; }
+                if (NF) {
+                    if (NF > ((FCHUNKS - 1) << FCH_LOG) - (ftail - fhead)) { failed = true; why = 4; break; }
+                    if (!chunk_get(fchunk, fchunks_have, min((ftail + NF - 1) >> FCH_LOG, FCHUNKS - 1), sizeof(Far) << FCH_LOG)) { failed = true; why = 5; break; }
+                    uint32_t fbad = 0;
+                    for (uint32_t k = lane; k < NF; k += 64) {
+                        const uint2 e = bk[Nb + k];
+                        const uint32_t en = farEnd[k], prev = k ? farEnd[k - 1] : last_far_end;
+                        if (en < prev) fbad = 1;  // the FIFO lives on non-decreasing ends
+                        *far_rec(ftail + k) = Far{en, INF, e.y & 0xFFFFu, rb + (e.y >> 16)};
+                    }
+                    if (__ballot(fbad != 0) != 0) { failed = true; why = 6; break; }
+                    last_far_end = bcast32(farEnd[NF - 1]);
+                    if (next_head_end == 0xFFFFFFFFu && fhead + fin == ftail) next_head_end = bcast32(farEnd[0]);
+                    ftail += NF;
+                }
+                fhead += fin;
+                fhead_end = next_head_end;
+                const uint32_t c0 = boff[nw], nc = Nb - c0;
+                const uint32_t gnext = gw + N, rbn = gnext >= 0x8000u ? gnext - 0x8000u : 0u;  // the next window's base
+                uint32_t cbad = 0;
+                for (uint32_t sl = c0 + lane; sl < Nb; sl += 64) {  // lane = carried slot, re-based
+                    const uint32_t y = bk[sl].y, g = rb + (y >> 16);
+                    if (g < rbn) cbad = 1;
+                    bank_y[kwin & 1u][sl - c0] = (y & 0xFFFFu) | ((g - rbn) << 16);
+                    bank_rel[kwin & 1u][sl - c0] = (uint8_t)(brel[sl] - nw);
+                }
+                if (__ballot(cbad != 0) != 0) { failed = true; why = 7; break; }
+                if (lane == 0) {
+                    team->w0 = w0 + nw; team->gw = gw + N; team->ncarry = nc; team->fhead = fhead; team->ftail = ftail; team->last_far_end = last_far_end; team->fhead_end = fhead_end;
+                    team->wbyte0 = wbyte_next; team->wlim = min(WIN, max(4u, fit_len)); team->nchunks_have = nchunks_have; team->fchunks_have = fchunks_have;
+                }
+                team_release();
+                lds_put(&team->s_done, kwin + 1u);
+                holding = false;
+            }
             KW_T(5);
             KW_ARGS();
             // -- gather + sweep, block by block (the pool kernel's step: kgpu_pool.hip)
@@ -624,6 +761,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                 }
                 wave_sync();
                 KW_T(6);
+                if constexpr (TEAM > 1) {
+                    if (!have_v) {   // the value token: every window before this one has been relaxed; the seeds' slots get their dp
+                        bool stop = false;
+                        for (;;) {
+                            if (lds_get(&team->failed)) { stop = true; break; }
+                            if (lds_get(&team->v_done) == kwin) break;
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        if (stop) break;
+                        team_acquire();
+                        for (uint32_t sl = lane; sl < Nb; sl += 64) {
+                            const uint32_t x = bk[sl].x;
+                            if ((x & SEED_MARK) == SEED_MARK) {
+                                const uint32_t idx = x & (SEED_FAR - 1u);
+                                bk[sl].x = (x & SEED_FAR) ? (uint32_t)far_rec(fhead_w + idx)->dp : bank_dp[pb][idx];
+                            }
+                        }
+                        wave_sync();
+                        have_v = true;
+                    }
+                }
                 {
                     uint32_t dT = 0, dP = 0, dt0 = 0, d0 = 1u << 31, d1 = 0, d2 = 0;
                     if (lane < nq) {
@@ -725,8 +883,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
             }
 
             KW_ARGS();
+            if constexpr (TEAM > 1) {
+                if (!have_v) break;   // (another wavefront failed the sentence while this one waited for its value token)
+                // ---- this window is relaxed: the dp of what it carries on and of its far entries, then the value token
+                const uint32_t c0 = boff[nw];
+                for (uint32_t sl = c0 + lane; sl < Nb; sl += 64) bank_dp[kwin & 1u][sl - c0] = bk[sl].x;
+                for (uint32_t k = lane; k < NF; k += 64) far_rec(ftail_w + k)->dp = (int32_t)bk[Nb + k].x;
+                team_release();
+                lds_put(&team->v_done, kwin + 1u);
+            }
             // -- flush: node records to HBM, far-out entries to the FIFO, the buckets beyond the window to the carry list
-            if (!chunk_get(nchunk, nchunks_have, (gw + N - 1) >> NCH_LOG, (4u + (uint32_t)sizeof(NodeRec)) << NCH_LOG)) { failed = true; why = 3; break; }
+            if constexpr (TEAM == 1) if (!chunk_get(nchunk, nchunks_have, (gw + N - 1) >> NCH_LOG, (4u + (uint32_t)sizeof(NodeRec)) << NCH_LOG)) { failed = true; why = 3; break; }
             for (uint32_t t = lane; t < N; t += 64) {
                 const uint32_t p = pre[t], st = nStart[t];
                 const uint32_t gp = p == NONE16 ? NONE : rb + p;
@@ -738,6 +905,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
                 if (rec.sid == 0 && w0 + st == C) eos_pre = gp;  // (only EOS has sid 0: BOS is never a target)
             }
             if (nw > nwc) eos_pre = bcast32((uint32_t)__shfl((int)eos_pre, (int)((N - 1) & 63u), 64));  // the lane that wrote node N - 1
+            if constexpr (TEAM > 1) {
+                if (nw > nwc) lds_put(&team->eos_pre, eos_pre);
+                wT += wTw; wE += wEw;
+                wave_sync();
+                KW_T(8);
+                kwin += (uint32_t)TEAM;
+                continue;
+            }
             if (NF) {
                 if (NF > ((FCHUNKS - 1) << FCH_LOG) - (ftail - fhead)) { failed = true; why = 4; break; }
                 if (!chunk_get(fchunk, fchunks_have, min((ftail + NF - 1) >> FCH_LOG, FCHUNKS - 1), sizeof(Far) << FCH_LOG)) { failed = true; why = 5; break; }
@@ -781,19 +956,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
             gw += N;
             w0 += nw;
         }
+        uint32_t gw_end = gw;
+        if constexpr (TEAM > 1) {
+            if (failed && lane == 0) { team->why = why; __hip_atomic_store(&team->failed, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            if constexpr (PROF) {
+                wT = wave_sum(wT); wE = wave_sum(wE);
+                if (lane == 0) { atomicAdd(&team->wT, wT); atomicAdd(&team->wE, wE); }
+            }
+            team_release();
+            __syncthreads();   // every wavefront is through with its windows: node records, far entries and the team's state are complete
+            team_acquire();
+            if (wave != 0) continue;   // the first wavefront alone chases the path and writes the tokens (the others wait at the next sentence's first barrier)
+            failed = bcast32(team->failed) != 0; why = bcast32(team->why);
+            gw_end = bcast32(team->gw); eos_pre = bcast32(team->eos_pre);
+            wT = bcast32(team->wT); wE = bcast32(team->wE);
+        }
         if (failed) {
             if ((why == 3 || why == 5) && __hip_atomic_load(&a.ctl->arena_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 if (lane == 0) { a.status[s] = KGPU_SENT_NO_SCRATCH; a.tok_count[s] = 0; }  // the scratch arena was too small: the host grows it and reruns the batch
             } else fail(s);
             if (lane == 0 && !PROF) atomicAdd(&a.ctl->phase[why < 10 ? why : 9], 1ull);
-            __syncthreads();
+            setup_fence();
             continue;
         }
 
         KW_ARGS();
         // ---- backtrace (lattice.rs:144-153): chase `pre` through windows of node records staged in LDS ----
         KW_T(8);
-        const uint32_t Ntot = gw;  // BOS + every node; EOS is node Ntot - 1
+        const uint32_t Ntot = gw_end;  // BOS + every node; EOS is node Ntot - 1
         uint32_t K = 0;
         {
             // `pre` of a range of nodes staged in LDS, lane 0 chases the chain through it; the path it finds is parked in LDS too (PATHL entries at the
@@ -833,7 +1023,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
         }
         K = bcast32(K);
         const uint64_t ts = b0 - a.offsets[0] + s;
-        __syncthreads();
+        setup_fence();
         for (uint32_t k = lane; k < K; k += 64) {  // Node -> Token (tokenizer.rs:22-43); a word ends where its successor starts
             const NodeRec r = *node_rec(path[K - 1 - k]);
             kgpu_token tk;
@@ -850,10 +1040,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
         if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; }
         KW_T(9);
         if constexpr (PROF) {
-            wT = wave_sum(wT); wE = wave_sum(wE);
+            if constexpr (TEAM == 1) { wT = wave_sum(wT); wE = wave_sum(wE); }
             accW[0] += 1; accW[1] += B; accW[2] += C; accW[3] += wT; accW[4] += Ntot - 1; accW[5] += wE; accW[6] += K;
         }
-        __syncthreads();
+        setup_fence();
     }
     if (PROF && lane == 0) {
         for (int k = 0; k < 7; ++k) atomicAdd(&a.ctl->work[k], (unsigned long long)accW[k]);
@@ -861,23 +1051,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KGPU_WIN_WPE
     }
 }
 
+// LDS of one workgroup of TEAM wavefronts (the kernel's own carve: chunk tables, team state, two carry banks, TEAM regions)
+static uint32_t team_lds_bytes(uint32_t lds_bytes, int team) {
+    const uint32_t shared0 = 4 * NCHUNKS + 4 * FCHUNKS;
+    return team > 1 ? ((shared0 + (uint32_t)sizeof(TeamState) + 15u) & ~15u) + 2u * 9u * CCAP + (uint32_t)team * lds_bytes : lds_bytes;
+}
+
 int window_workgroups_per_cu(uint32_t lds_bytes) {
     if (lds_bytes > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)k_tokenize_window<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return 0;
+        hipFuncSetAttribute((const void *)k_tokenize_window<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return 0;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_window<false>, 64, (size_t)lds_bytes) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_window<false, 1>, 64, (size_t)lds_bytes) != hipSuccess) return 0;
+    return n;
+}
+// ... of the two-wavefronts-per-sentence form (0: it does not fit)
+int window_team_workgroups_per_cu(uint32_t lds_bytes) {
+    const uint32_t tb = team_lds_bytes(lds_bytes, 2);
+    if (tb > 64 * 1024) return 0;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_window<false, 2>, 128, (size_t)tb) != hipSuccess) return 0;
     return n;
 }
 
-int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, void *stream) {
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_window<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_tokenize_window<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+template <bool PROF, int TEAM>
+static int launch_window_inst(const WinArgs &wa, int n_workgroups, void *stream) {
+    const uint32_t tb = team_lds_bytes(wa.lds_bytes, TEAM);
+    if (tb > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_window<PROF, TEAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb);
         if (e != hipSuccess) return (int)e;
     }
-    if (a.count_work) hipLaunchKernelGGL(k_tokenize_window<true>, dim3((unsigned)n_workgroups), dim3(64), lds_bytes, (hipStream_t)stream, WinArgs{d, a, io, lds_bytes});
-    else hipLaunchKernelGGL(k_tokenize_window<false>, dim3((unsigned)n_workgroups), dim3(64), lds_bytes, (hipStream_t)stream, WinArgs{d, a, io, lds_bytes});
+    hipLaunchKernelGGL((k_tokenize_window<PROF, TEAM>), dim3((unsigned)n_workgroups), dim3(64 * TEAM), tb, (hipStream_t)stream, wa);
     return (int)hipGetLastError();
+}
+
+// team: wavefronts per sentence (1, or 2: the host picks 2 when the work list is short against the chip's slots)
+int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, int team, void *stream) {
+    const WinArgs wa{d, a, io, lds_bytes};
+    if (team == 2) return a.count_work ? launch_window_inst<true, 2>(wa, n_workgroups, stream) : launch_window_inst<false, 2>(wa, n_workgroups, stream);
+    return a.count_work ? launch_window_inst<true, 1>(wa, n_workgroups, stream) : launch_window_inst<false, 1>(wa, n_workgroups, stream);
 }
 
 }  // namespace kgpu

@@ -30,7 +30,7 @@ int main(void) {
     S(kgpu_plan_info);
     F(kgpu_plan_info, compute_units); F(kgpu_plan_info, pool_lds_bytes); F(kgpu_plan_info, pool_wavefronts); F(kgpu_plan_info, pool_workgroups_per_cu);
     F(kgpu_plan_info, pool_max_pages); F(kgpu_plan_info, long_lds_bytes); F(kgpu_plan_info, long_workgroups_per_cu); F(kgpu_plan_info, long_workgroups);
-    F(kgpu_plan_info, window_lds_bytes); F(kgpu_plan_info, window_workgroups_per_cu); F(kgpu_plan_info, window_workgroups); F(kgpu_plan_info, streams); F(kgpu_plan_info, reserved);
+    F(kgpu_plan_info, window_lds_bytes); F(kgpu_plan_info, window_workgroups_per_cu); F(kgpu_plan_info, window_workgroups); F(kgpu_plan_info, streams); F(kgpu_plan_info, long_streams); F(kgpu_plan_info, window_first_bytes); F(kgpu_plan_info, reserved);
     S(kgpu_work);
     F(kgpu_work, sentences); F(kgpu_work, B); F(kgpu_work, C); F(kgpu_work, T); F(kgpu_work, N); F(kgpu_work, E); F(kgpu_work, K);
     S(kgpu_lattice_node);

@@ -698,3 +698,60 @@ def test_chain_tail_is_left_out_and_comes_back(libs):
     assert ctx.profile()["tail_reruns"] == 1
     ctx, t, toff, utf8, offs = _device_run(tok, mixed, PROFILE_OFF)  # armed again: no rerun
     assert np.array_equal(t.reshape(-1), exp.tokens.view(np.int32).reshape(-1)) and ctx.profile()["tail_reruns"] == 0
+
+
+def test_long_batches_start_with_the_windowed_kernel(libs, monkeypatch):
+    """A batch whose sentences average >= KGPU_WINDOW_FIRST bytes (default 1024: the host knows n and the byte count, not the lengths) gets no pool launch
+    in front -- the windowed kernel takes the whole batch, short sentences included, on one of the dictionary's long streams -- and the records are the
+    same as through the pool-first chain and the oracle's (src/tokenizer.rs:16: a call's result does not depend on how it was scheduled).  Alternating
+    long and short batches on ONE context switches its stream back and forth; the host-buffer entry point takes the same decision per chunk."""
+    from kanpyo_amd import Tokenizer, synth
+    from kanpyo_amd.device import PROFILE_OFF
+    from kanpyo_amd.tokenizer import pack_sentences
+
+    _, oracle = libs
+    sd = synth.build_dict(20000, seed=5)
+    tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
+    docs = synth.make_corpus(sd, 40, 7, "cfg5") + synth.make_corpus(sd, 30, 8, "cfg2") + ["", "ア" * 1500, "あ"]   # average ~2.7 KB: window first
+    short = synth.make_corpus(sd, 700, 9, "cfg2")
+    utf8, offs = pack_sentences(docs)
+    assert int(offs[-1]) >= 1024 * len(docs)
+    exp = orc.tokenize_batch(utf8, offs, 8)
+    ctx, t, toff, _, _ = _device_run(tok, docs, PROFILE_OFF)
+    plan, prof = ctx.plan(), ctx.profile()
+    assert plan["window_first_bytes"] == 1024
+    assert np.array_equal(toff.astype(np.uint64), exp.offsets) and np.array_equal(t.reshape(-1), exp.tokens.view(np.int32).reshape(-1))
+    assert prof["long_launches"] == 1 and prof["deferred"][0] == 0 and prof["redone"][0] == 0   # list 0 is the windowed kernel's own output: nothing left, nothing routed
+    # the same context, alternating: short batch (pool first, shared stream), long, short
+    import torch
+
+    from kanpyo_amd.device import DeviceContext
+
+    dev = torch.device("cuda", 0)
+    c = DeviceContext(tok)
+    for sents in (short, docs, short, docs):
+        u, o = pack_sentences(sents)
+        e = orc.tokenize_batch(u, o, 8)
+        n, cap = len(sents), int(o[-1]) + len(sents)
+        bufs = (torch.from_numpy(u.copy()).to(dev), torch.from_numpy(o.astype(np.int64)).to(dev), torch.empty((cap, 6), dtype=torch.int32, device=dev),
+                torch.empty(n + 1, dtype=torch.int64, device=dev), torch.empty(n, dtype=torch.uint8, device=dev))
+        c.tokenize(bufs[0].data_ptr(), bufs[1].data_ptr(), n, int(o[-1]), bufs[2].data_ptr(), cap, bufs[3].data_ptr(), bufs[4].data_ptr())
+        nt = c.sync()
+        assert np.array_equal(bufs[3].cpu().numpy().astype(np.uint64), e.offsets)
+        assert np.array_equal(bufs[2][:nt].cpu().numpy().reshape(-1), e.tokens.view(np.int32).reshape(-1))
+    # the host-buffer entry point (chunks of its pipeline take the decision one by one)
+    assert_same(tok, orc, docs * 3 + short + docs)
+    # and with the rule switched off the pool kernel routes as before: same records
+    monkeypatch.setenv("KGPU_WINDOW_FIRST", "0")
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = ("import numpy as np; from kanpyo_amd import Tokenizer, synth; from kanpyo_amd.tokenizer import pack_sentences; from oracle import oracle;"
+            "sd = synth.build_dict(20000, seed=5); tok = Tokenizer(sd.dict); orc = oracle.OracleTokenizer.from_dict(sd.dict);"
+            "docs = synth.make_corpus(sd, 40, 7, 'cfg5') + synth.make_corpus(sd, 30, 8, 'cfg2') + ['', 'ア' * 1500, 'あ'];"
+            "u, o = pack_sentences(docs); t, toff, st = tok.tokenize_packed(u, o); e = orc.tokenize_batch(u, o, 8);"
+            "assert np.array_equal(toff, e.offsets) and np.array_equal(t, e.tokens); r = tok.routing(); assert r['deferred'][0] >= 40, r; print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)   # (the threshold is read once per process)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

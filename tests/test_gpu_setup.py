@@ -43,7 +43,7 @@ def _probe(env_extra):
 
 def test_library_asks_for_its_hardware_queues_itself():
     got = _probe({})
-    assert got == {"streams": 4, "warning": "", "env": "8"}, got
+    assert got == {"streams": 4, "warning": "", "env": "16"}, got
 
 
 def test_three_streams_are_reported_loudly():
