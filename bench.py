@@ -78,6 +78,16 @@ def hoist_roofline(r):
     return out
 
 
+def c_getenv(name):
+    """The C environment (os.environ is Python's start-up snapshot: it does not see the setenv of the library's load-time constructor)."""
+    import ctypes
+
+    g = ctypes.CDLL(None).getenv
+    g.restype = ctypes.c_char_p
+    v = g(name.encode())
+    return v.decode() if v else None
+
+
 def result_rate_guess(rate_1thread, nthreads):
     """Sentences per second to expect from `nthreads` host threads (sizes the all-core leg to about two seconds)."""
     return rate_1thread * max(1.0, 0.5 * nthreads)
@@ -877,7 +887,7 @@ def main():
                         "batch=4096 (24 full batches + the 1696-sentence tail per 100k sentences at N=1); one step = one whole corpus; "
                         "inputs resident in HBM, dense tokens left in HBM",
             "batch": BATCH, "sentences_per_step": N_SENT, "batches_per_step_per_gpu": wl.nb(0), "batches_in_flight": Q,
-            "streams": eng.ctxs[0].plan()["streams"], "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+            "streams": eng.ctxs[0].plan()["streams"], "long_streams": eng.ctxs[0].plan()["long_streams"], "GPU_MAX_HW_QUEUES": c_getenv("GPU_MAX_HW_QUEUES"),
             "sharding": "sentence i -> GPU i mod N, dictionary replicated, one gatherv of token records to rank 0 per chunk of "
                         f"{cs} step(s)" if multi else "single GPU",
         },
@@ -904,6 +914,9 @@ def main():
             "achieved_at_job_rate": job_rate_bytes, "frac_at_job_rate": job_rate_bytes / HBM_PEAK_GBS,
         },
     }
+    wps = result["work_per_sentence"]
+    # what a sentence holds of its pool in the sweep phase (kgpu_pool.hip's own carve: text, 26 B per character, 8 B per bucket entry, 12 B per node, the block's pair table)
+    result["roofline"]["lds_bytes_per_sentence"] = (wps["B"] + 4) + 26 * (wps["C"] + 2) + 8 * (wps["N"] + 2) + 12 * (wps["N"] + 1) + 1024
     result["sentences_total"] = sentences
     if multi:
         result["gather"] = {"chunks": gathered["chunks"], "tokens": gathered["tokens"], "sentences": gathered["sentences"],
@@ -984,8 +997,15 @@ def main():
                 result["roofline"]["instruction"] = {
                     "valu_per_sentence": valu, "salu_per_sentence": salu, "source": ins.get("source", "profiles/pmc_instructions.json"),
                     "stale": ins.get("kernel_src_sha16") != kernel_source_hash(),
-                    "valu_issue_frac": valu * 2 * rate / (CHIP_SIMDS * CHIP_CLOCK_HZ),  # a wave64 VALU op occupies its SIMD-32 for 2 cycles
-                    "what": "wave-VALU-instructions per sentence x 2 cycles x sentences/s / (1024 SIMDs x 2.4 GHz)"}
+                    # tools/ubench/valu.hip (profiles/experiments/r05_valu_issue_rate.txt): a wave64 op occupies its SIMD for 2 cycles only if it is a plain two-operand
+                    # VOP2 add / and / move; DPP forms, VOP3 (v_lshl_add, v_mad, v_add3), v_min, v_cndmask, v_cmp + v_cndmask take 4.  About half of the pool kernel's
+                    # VALU instructions are of the first kind (static mix): 3 cycles per op on average, bracketed by the two bounds.
+                    "cycles_per_wave_op": 3.0,
+                    "valu_issue_frac": valu * 3.0 * rate / (CHIP_SIMDS * CHIP_CLOCK_HZ),
+                    "valu_issue_frac_if_all_2_cycle_ops": valu * 2.0 * rate / (CHIP_SIMDS * CHIP_CLOCK_HZ),
+                    "valu_issue_frac_if_all_4_cycle_ops": valu * 4.0 * rate / (CHIP_SIMDS * CHIP_CLOCK_HZ),
+                    "what": "wave-VALU-instructions per sentence x cycles per op x sentences/s / (1024 SIMDs x 2.4 GHz); SQ_ACTIVE_INST_VALU counts one quad-cycle per "
+                            "instruction whatever it costs and is not a busy time"}
             except Exception as e:
                 print(f"instruction roofline skipped: {e}", file=sys.stderr)
 
@@ -1211,6 +1231,10 @@ def main():
                     extra.append(line)
                 else:
                     extra.append(measure_config(tok, dev, wl_x, n_chars, passes, args.queue, 0, lab, orc=extras_orc))
+                    if kind == "cfg5":   # the config as literally written: ONE batch of 1k documents at a time (the runtime gives such a list two wavefronts per document)
+                        line = measure_config(tok, dev, wl_x, n_chars, 12, 1, 0, lab + " -- ONE batch in flight (one context)", orc=None)
+                        line["contexts"] = 1
+                        extra.append(line)
             except Exception as e:
                 print(f"{kind} leg failed: {e}", file=sys.stderr)
         # ---- ONE context (a caller that keeps a single batch in flight): the cfg 2 corpus in batches of 4096 and of 16384

@@ -228,7 +228,11 @@ int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint64_t *offse
  * made by kgpu_dict_create on that device (the same handle may appear more than once: its device then takes several shards) --
  * one host thread per entry drives its device's chunk pipeline, every device's compaction kernel writes its 8-byte records into
  * pinned host memory, and the records are expanded into `tokens` in the caller's ORIGINAL sentence order: the result is
- * byte-for-byte what kgpu_tokenize_batch gives on one device.  No data-path collective: the shards are independent. */
+ * byte-for-byte what kgpu_tokenize_batch gives on one device.  No data-path collective: the shards are independent.
+ * EXPERIMENTAL (this entry point and kgpu_multi_* below): exercised with one device appearing several times; never yet run with handles on two physical
+ * GPUs (tests/test_gpu_multi.py::test_one_handle_per_device does as soon as a box has two).  One difference from kgpu_tokenize_batch: a token that does not
+ * fit the 8-byte record the shards write (more than 4095 characters or 262143 bytes: no real dictionary) fails the whole call with KGPU_ERR_INTERNAL, where
+ * the single-device call redoes that chunk with 24-byte records.  The caller's current HIP device is restored before the call returns. */
 int kgpu_tokenize_batch_multi(kgpu_dict *const *dicts, int n_dicts, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
                               kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets, uint8_t *status, uint64_t *n_tokens);
 

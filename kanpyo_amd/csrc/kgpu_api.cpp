@@ -166,7 +166,6 @@ static unsigned planned_streams() {
 }
 // Streams for chains that start with the windowed kernel, beside the shared ones: what the hardware queues leave (16 queues: eight; 8: two; the default 4: none --
 // such chains then stay on the shared streams).  KGPU_LONG_STREAMS overrides (0 = off).
-static unsigned window_first_bytes();
 static unsigned planned_long_streams() {
     static const unsigned n = [] {
         if (const char *e = getenv("KGPU_LONG_STREAMS")) return (unsigned)std::max(0, std::min(16, atoi(e)));
@@ -549,12 +548,8 @@ static int next_event(kgpu_ctx *c, hipEvent_t *ev) {
 // of the long set, one per context, so that eight such launches overlap instead of four (-> 3.96; both: profiles/experiments/r05_long_chains.txt).
 // The context's previous batch is complete here (kgpu_ctx_sync), so switching streams needs no ordering for the context's own buffers; whatever the
 // host-buffer paths queued on the old stream for THIS batch (their H2D copy) is ordered in front by an event.
-static unsigned window_first_bytes() {
-    static const unsigned v = [] { const char *e = getenv("KGPU_WINDOW_FIRST"); const int x = e ? atoi(e) : 1024; return (unsigned)(x < 0 ? 0 : x); }();   // 0 = never
-    return v;
-}
 static int ctx_pick_chain(kgpu_ctx *c, uint64_t n, uint64_t total_bytes, bool dump) {
-    const unsigned lim = window_first_bytes();
+    const unsigned lim = c->plan.window_first_bytes;   // (KGPU_WINDOW_FIRST, read with the launch plan when the context is created)
     c->window_first = lim && n && c->plan.n_pools && c->plan.window_lds_bytes && !dump && c->stop_after == 0 && !c->no_window && total_bytes >= (uint64_t)lim * n;
     if (c->own_stream) return KGPU_OK;
     hipStream_t want = c->short_stream;
@@ -605,14 +600,18 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
         // over that list.
         c->last_tail = (pools_now == 0 && !window_now) || c->stop_after != 0 || a.dump_lattice || c->no_window ||
                        c->dict->tail_batches.load(std::memory_order_relaxed) > 0;
-        // Two wavefronts per sentence (the windowed kernel's team form) when the list is short against the chip: every sentence of this batch AND of the
-        // window-first batches already in flight fits the form's resident workgroups -- a lone batch of 1000 documents fills a quarter of the single-
-        // wavefront slots and each document is one wavefront's chain; with eight such batches in flight the chip is full and the ordinary form is the better use of its LDS.
-        static const int team_mode = [] { const char *e = getenv("KGPU_WINDOW_TEAM"); return e ? atoi(e) : -1; }();   // 0: never, 2: whenever possible, default: by the load
+        // Two wavefronts per sentence (the windowed kernel's team form) when the list is short against the chip: the sentences of this batch AND of the
+        // window-first batches in flight lately are at most twice the form's resident workgroups -- a lone batch of 1000 documents fills a quarter of the
+        // single-wavefront slots and each document is one wavefront's chain; with four or more such batches in flight the ordinary form is the better use of the LDS.
+        const int team_mode = c->plan.window_team_mode;   // KGPU_WINDOW_TEAM: 0 never, 2 whenever possible, default by the load
         bool team_now = false;
         if (pools_now == 0 && window_now && c->plan.window_team_workgroups > 0 && team_mode != 0) {
             if (!c->counted_long) { c->counted_long = (int)std::min<uint64_t>(a.n, 1u << 30); c->dict->long_sentences_in_flight.fetch_add(c->counted_long, std::memory_order_relaxed); }
-            team_now = team_mode == 2 || c->dict->long_sentences_in_flight.load(std::memory_order_relaxed) <= c->plan.window_team_workgroups;
+            const int cur = c->dict->long_sentences_in_flight.load(std::memory_order_relaxed), old = c->dict->long_peak.load(std::memory_order_relaxed);
+            const int peak = std::max(cur, old - old / 8);
+            c->dict->long_peak.store(peak, std::memory_order_relaxed);
+            // measured on cfg 5 (1000 documents per batch, Mchar/s, ordinary / team form): 1 in flight 1084 / 1495, 2: 1957 / 2153, 4: 3376 / 2372, 8: 4145 / 2405
+            team_now = team_mode == 2 || peak <= 2 * c->plan.window_team_workgroups;
         }
         c->last_team = team_now;
         hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->stop_after, c->stream, ef, window_now, c->last_tail, team_now);
@@ -942,7 +941,7 @@ extern "C" int kgpu_ctx_get_plan(kgpu_ctx *c, kgpu_plan_info *out, size_t out_si
     p.window_workgroups_per_cu = c->plan.window_lds_bytes ? (uint32_t)window_workgroups_per_cu(c->plan.window_lds_bytes) : 0u;
     p.streams = planned_streams();
     p.long_streams = c->own_stream ? 0u : planned_long_streams();
-    p.window_first_bytes = (c->plan.n_pools && c->plan.window_lds_bytes) ? window_first_bytes() : 0u;
+    p.window_first_bytes = (c->plan.n_pools && c->plan.window_lds_bytes) ? c->plan.window_first_bytes : 0u;
     std::memcpy(out, &p, std::min(out_size, sizeof p));
     return KGPU_OK;
 }

@@ -130,6 +130,8 @@ struct LaunchPlan {
     uint32_t window_lds_bytes;  // > 0: the windowed kernel (kgpu_window.hip) behind the pools; 0: the general kernel serves what they route away
     int window_workgroups;
     int window_team_workgroups;  // resident workgroups of the windowed kernel's two-wavefronts-per-sentence form on the whole chip (0: not available)
+    int window_team_mode;        // KGPU_WINDOW_TEAM: 0 never, 2 whenever the chain starts with the windowed kernel, -1 (default) by the load
+    uint32_t window_first_bytes; // KGPU_WINDOW_FIRST: a batch averaging this many bytes per sentence or more gets no pool launch in front (default 1024; 0 = never)
 };
 
 // Launchers (kgpu_kernels.hip).  `stream` is a hipStream_t.

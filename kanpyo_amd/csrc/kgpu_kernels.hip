@@ -692,6 +692,10 @@ LaunchPlan default_launch_plan(int device) {
         t.window_workgroups = cus * per_cu;
         if (per_cu <= 0) t.window_lds_bytes = 0;
         t.window_team_workgroups = t.window_lds_bytes ? cus * std::max(0, window_team_workgroups_per_cu(t.window_lds_bytes)) : 0;
+        const char *tm = getenv("KGPU_WINDOW_TEAM");
+        t.window_team_mode = tm ? atoi(tm) : -1;
+        const char *wf = getenv("KGPU_WINDOW_FIRST");
+        t.window_first_bytes = (uint32_t)std::max(0, wf ? atoi(wf) : 1024);
     }
     if (const char *e = getenv("KGPU_GENERAL_WG")) { int v = atoi(e); if (v > 0) t.general_workgroups = v; }
     if (const char *e = getenv("KGPU_POOL_WG")) { int v = atoi(e); if (v > 0 && t.n_pools) t.pool_workgroups[0] = v; }

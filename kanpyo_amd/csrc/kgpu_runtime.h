@@ -92,6 +92,8 @@ struct kgpu_dict {
     std::vector<hipStream_t> long_streams;
     unsigned next_long = 0;
     std::atomic<int> long_sentences_in_flight{0};   // sentences of window-first batches between enqueue and completion (decides the two-wavefront form)
+    std::atomic<int> long_peak{0};                  // ... its recent maximum (decays by an eighth per enqueue): a caller that keeps eight batches in flight is not
+                                                    // mistaken for a lone one by the batch that happens to be enqueued while the others are being collected
     std::vector<uint32_t> left_of_rank, right_of_rank;  // device (ranked) context id -> the dictionary's own; empty = identity
     // One reference for the handle the caller holds plus one per live context: the tables and the shared
     // streams go when the last one does (a context outliving kgpu_dict_destroy keeps working).

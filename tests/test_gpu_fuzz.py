@@ -95,13 +95,17 @@ def test_mixed_corpora_random_chains(libs, seed, nkeys, monkeypatch):
     rng = random.Random(seed)
     sd = synth.build_dict(nkeys, seed=rng.randrange(1 << 30))
     orc = oracle.OracleTokenizer.from_dict(sd.dict)
+    rng2 = random.Random(seed + 1)   # (its own stream: the chains and corpora above stay what they were before these two knobs existed)
     for k in range(4):
         pool, window_kib = rng.choice(POOLS), rng.choice(WINDOWS)
+        team, first = rng2.choice(["-1", "0", "2", "2"]), rng2.choice(["1024", "0", "64", "300"])   # round 5: the team form / chains that start with the windowed kernel
         monkeypatch.setenv("KGPU_POOL", pool)
         monkeypatch.setenv("KGPU_WINDOW", window_kib)
+        monkeypatch.setenv("KGPU_WINDOW_TEAM", team)
+        monkeypatch.setenv("KGPU_WINDOW_FIRST", first)
         tok = Tokenizer(sd.dict)
         for j in range(3):
-            _same(tok, orc, synth.mixed_case(sd, rng, sizes=(1, 5, 50, 120, 700, 4096)), f"seed {seed} chain {k}.{j} pool={pool} window={window_kib}")
+            _same(tok, orc, synth.mixed_case(sd, rng, sizes=(1, 5, 50, 120, 700, 4096)), f"seed {seed} chain {k}.{j} pool={pool} window={window_kib} team={team} first={first}")
 
 
 def test_default_chain_many_small_dictionaries(libs):

@@ -156,3 +156,71 @@ def test_bench_single_process_path_on_one_gpu():
         assert k in line, k
     assert line["n_gpus"] == 2 and line["sentences_total"] == 200_000 and line["gather"]["reassembled_step_equals_one_gpu"] is True
     assert line["value"] > 1e6
+
+
+def test_one_handle_per_device():
+    """Both multi-device forms with one dictionary handle per PHYSICAL device (advisor, round 4: everything above passes device 0 several times, so
+    hipDeviceEnablePeerAccess, the compaction kernels' stores into another device's memory and one pipeline thread per device have never executed).
+    Skipped on a one-GPU box -- which is every box this repository has been run on so far: the multi-device API is experimental until this has passed."""
+    import torch
+
+    from kanpyo_amd import Tokenizer, _lib, synth
+    from kanpyo_amd.dist import reassemble
+    from kanpyo_amd.tokenizer import TOKEN_DTYPE, pack_sentences
+    from oracle import oracle
+
+    L = _lib.lib()
+    ndev = L.kgpu_device_count()
+    if ndev < 2:
+        pytest.skip(f"{ndev} HIP device(s): the peer-access gather and the per-device pipelines need two")
+    G = min(ndev, 4)
+    oracle.build()
+    sd = synth.build_dict(20000, seed=11)
+    orc = oracle.OracleTokenizer.from_dict(sd.dict)
+    toks = [Tokenizer(sd.dict, device=g) for g in range(G)]
+    before = torch.cuda.current_device()
+    sents = synth.make_corpus(sd, 9000, 31, "cfg2") + synth.make_corpus(sd, 200, 32, "cfg3") + ["", "テ"]
+    utf8, offs = pack_sentences(sents)
+    exp = orc.tokenize_batch(utf8, offs, 8)
+    _check(toks, orc, utf8, offs)                                   # kgpu_tokenize_batch_multi: host buffers, one pipeline thread per device
+    _check(toks[:1] + toks[:1] + toks[1:2], orc, utf8, offs)        # a device twice and another once
+    assert torch.cuda.current_device() == before                    # the caller's current device is put back (advisor, round 4)
+    handles = (C.c_void_p * G)(*[t.handle for t in toks])
+    mh = C.c_void_p()
+    _lib.check(L.kgpu_multi_create(handles, G, 2, C.byref(mh)))     # peer access from every device to the root's memory
+    try:
+        root = torch.device("cuda", 0)
+        shards = []
+        for g in range(G):
+            dev = torch.device("cuda", g)
+            u, o = pack_sentences(sents[g::G])
+            n, total = len(o) - 1, int(o[-1])
+            cap = total + n + 1
+            shards.append(dict(u=torch.from_numpy(u.copy()).to(dev), o=torch.from_numpy(o.astype(np.int64)).to(dev), n=n, total=total, cap=cap,
+                               t8=torch.empty((cap, 2), dtype=torch.int32, device=root), first=torch.empty(2 * n, dtype=torch.int32, device=root),
+                               toff=torch.empty(n + 1, dtype=torch.int64, device=root), st=torch.empty(n + 16, dtype=torch.uint8, device=root)))
+        torch.cuda.synchronize()
+        arr = lambda key: (C.c_void_p * G)(*[s[key].data_ptr() for s in shards])
+        u64 = lambda key: (C.c_uint64 * G)(*[s[key] for s in shards])
+        for slot in (0, 1, 0):
+            _lib.check(L.kgpu_multi_tokenize_device(mh, slot, arr("u"), arr("o"), u64("n"), u64("total"), arr("t8"), u64("cap"), arr("first"), arr("toff"), arr("st")))
+            got = (C.c_uint64 * G)()
+            _lib.check(L.kgpu_multi_sync(mh, slot, got))
+            toks24, counts = [], []
+            for g, s in enumerate(shards):
+                toff = s["toff"].cpu().numpy().astype(np.uint64)
+                assert int(got[g]) == int(toff[-1])
+                t8 = np.ascontiguousarray(s["t8"][: int(got[g])].cpu().numpy())
+                first = np.ascontiguousarray(s["first"].cpu().numpy().astype(np.uint32))
+                out = np.empty(int(got[g]), dtype=TOKEN_DTYPE)
+                L.kgpu_expand_tokens(t8.ctypes.data, toff.ctypes.data, first.ctypes.data, s["n"], out.ctypes.data)
+                assert not s["st"][: s["n"]].any()
+                toks24.append(out.view(np.int32).reshape(-1, 6))
+                counts.append(np.diff(toff).astype(np.int64))
+            g_tok, g_off = reassemble(np.concatenate(toks24), np.concatenate(counts), len(sents), G)
+            assert np.array_equal(g_off.astype(np.uint64), exp.offsets)
+            assert np.array_equal(g_tok.reshape(-1), exp.tokens.view(np.int32).reshape(-1))
+    finally:
+        L.kgpu_multi_destroy(mh)
+        for t in toks:
+            t.close()

@@ -741,17 +741,16 @@ def test_long_batches_start_with_the_windowed_kernel(libs, monkeypatch):
         assert np.array_equal(bufs[2][:nt].cpu().numpy().reshape(-1), e.tokens.view(np.int32).reshape(-1))
     # the host-buffer entry point (chunks of its pipeline take the decision one by one)
     assert_same(tok, orc, docs * 3 + short + docs)
-    # and with the rule switched off the pool kernel routes as before: same records
-    monkeypatch.setenv("KGPU_WINDOW_FIRST", "0")
-    import subprocess
-    import sys
-
-    from conftest import ROOT
-
-    code = ("import numpy as np; from kanpyo_amd import Tokenizer, synth; from kanpyo_amd.tokenizer import pack_sentences; from oracle import oracle;"
-            "sd = synth.build_dict(20000, seed=5); tok = Tokenizer(sd.dict); orc = oracle.OracleTokenizer.from_dict(sd.dict);"
-            "docs = synth.make_corpus(sd, 40, 7, 'cfg5') + synth.make_corpus(sd, 30, 8, 'cfg2') + ['', 'ア' * 1500, 'あ'];"
-            "u, o = pack_sentences(docs); t, toff, st = tok.tokenize_packed(u, o); e = orc.tokenize_batch(u, o, 8);"
-            "assert np.array_equal(toff, e.offsets) and np.array_equal(t, e.tokens); r = tok.routing(); assert r['deferred'][0] >= 40, r; print('ok')")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)   # (the threshold is read once per process)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    # with the rule switched off the pool kernel routes as before, and with the two-wavefronts-per-sentence form forced on (or off) for the window-first
+    # chain the records are the same again (the knobs are read with the launch plan, when a context is created)
+    for env, need_deferred in (({"KGPU_WINDOW_FIRST": "0"}, True), ({"KGPU_WINDOW_TEAM": "2"}, False), ({"KGPU_WINDOW_TEAM": "0"}, False)):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tok2 = Tokenizer(sd.dict)
+        t2, toff2, st2 = tok2.tokenize_packed(utf8, offs)
+        assert np.array_equal(toff2, exp.offsets) and np.array_equal(t2, exp.tokens) and not st2.any(), env
+        r = tok2.routing()
+        assert (r["deferred"][0] >= 40) == need_deferred, (env, r)
+        tok2.close()
+        for k in env:
+            monkeypatch.delenv(k)

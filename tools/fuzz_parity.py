@@ -24,11 +24,13 @@ while time.time() < t_end:
     pool = rng.choice(["0", "8:2:64", "16:4:32", "40:4:32", "40:4:32", "40:8:20", "80:8:20", "80:10:64", "160:16:64", "80:8:20,160:4:64", "24:3:48"])
     window_kib = rng.choice(["0", "8", "10", "12", "12", "16", "24"])  # the windowed kernel behind the pools (0 = off: the general kernel takes its place)
     os.environ["KGPU_POOL"], os.environ["KGPU_WINDOW"] = pool, window_kib
+    os.environ["KGPU_WINDOW_TEAM"] = rng.choice(["-1", "-1", "0", "2", "2"])     # the two-wavefronts-per-sentence form of window-first chains: by the load / never / always
+    os.environ["KGPU_WINDOW_FIRST"] = rng.choice(["1024", "1024", "0", "64", "300"])  # average bytes per sentence from which a chain starts with the windowed kernel
     os.environ["KGPU_BYTE_TRIE"] = "1" if rng.random() < 0.15 else "0"  # (read at dictionary creation: KGPU_TEST_HOOKS_REREAD below)
     if rng.random() < 0.4:  # a dense little dictionary: wide buckets, many targets -- or keys of every UTF-8 width
         dd, mix = synth.dense_case(rng) if rng.random() < 0.6 else synth.width_case(rng)
         tok, orc = Tokenizer(dd), oracle.OracleTokenizer.from_dict(dd)
-        print(f"[{time.time() - (t_end - budget):6.1f}s] dense / width dictionary byte_trie={os.environ['KGPU_BYTE_TRIE']} pool={pool} window={window_kib} n={len(mix)}", flush=True)
+        print(f"[{time.time() - (t_end - budget):6.1f}s] dense / width dictionary byte_trie={os.environ['KGPU_BYTE_TRIE']} pool={pool} window={window_kib} team={os.environ['KGPU_WINDOW_TEAM']} first={os.environ['KGPU_WINDOW_FIRST']} n={len(mix)}", flush=True)
         utf8, offs = pack_sentences(mix)
         exp = orc.tokenize_batch(utf8, offs, 16)
         got_t, got_off, status = tok.tokenize_packed(utf8, offs)
@@ -40,7 +42,7 @@ while time.time() < t_end:
         continue
     sd = synth.build_dict(nkeys, seed=rng.randrange(1 << 30))
     tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
-    print(f"[{time.time() - (t_end - budget):6.1f}s] keys={nkeys} byte_trie={os.environ['KGPU_BYTE_TRIE']} pool={pool} window={window_kib}", flush=True)
+    print(f"[{time.time() - (t_end - budget):6.1f}s] keys={nkeys} byte_trie={os.environ['KGPU_BYTE_TRIE']} pool={pool} window={window_kib} team={os.environ['KGPU_WINDOW_TEAM']} first={os.environ['KGPU_WINDOW_FIRST']}", flush=True)
     for _ in range(3):
         mix = synth.mixed_case(sd, rng)
         utf8, offs = pack_sentences(mix)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, first GPU probe: VALU issue rate (ubench + PMC), streams x contexts on cfg 5 / cfg 3, five wavefronts per SIMD for the pool kernel
 set -u
-REPO=$(cd "$(dirname "$0")/.." && pwd)
+REPO=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$REPO"
 export KANPYO_SYNTH_CACHE=/tmp/kanpyo_synth
 O=$REPO/gpurun_out/p1; mkdir -p "$O"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, second GPU probe: the VALU issue rate (clean loop) with its PMC counters; five wavefronts per SIMD on shorter sentences (= a smaller LDS footprint per sentence)
 set -u
-REPO=$(cd "$(dirname "$0")/.." && pwd)
+REPO=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$REPO"
 export KANPYO_SYNTH_CACHE=/tmp/kanpyo_synth
 O=$REPO/gpurun_out/p2; mkdir -p "$O"

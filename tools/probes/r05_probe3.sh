@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, third GPU probe: VALU op classes, kernel concurrency, which unit of the CU is busy under the pool kernel (derived PMC metrics, one per pass)
 set -u
-REPO=$(cd "$(dirname "$0")/.." && pwd)
+REPO=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$REPO"
 export KANPYO_SYNTH_CACHE=/tmp/kanpyo_synth
 O=$REPO/gpurun_out/p3; mkdir -p "$O"

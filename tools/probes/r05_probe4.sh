@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, fourth GPU probe: cfg 5 with more hardware queues / streams, with the pool (router) launch left out, and a kernel timeline of the 8-stream run
 set -u
-REPO=$(cd "$(dirname "$0")/.." && pwd)
+REPO=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$REPO"
 export KANPYO_SYNTH_CACHE=/tmp/kanpyo_synth
 O=$REPO/gpurun_out/p4; mkdir -p "$O"

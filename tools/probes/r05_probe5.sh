@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, fifth GPU probe: does asking for 16 hardware queues cost cfg 2 anything; cfg 3 with more queues / streams
 set -u
-REPO=$(cd "$(dirname "$0")/.." && pwd)
+REPO=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$REPO"
 export KANPYO_SYNTH_CACHE=/tmp/kanpyo_synth
 O=$REPO/gpurun_out/p5; mkdir -p "$O"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5: the gpu tests on the new runtime (window-first chains, long streams, 16 hardware queues), then the three workloads with the defaults
 set -u
-REPO=$(cd "$(dirname "$0")/.." && pwd)
+REPO=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$REPO"
 export KANPYO_SYNTH_CACHE=/tmp/kanpyo_synth
 O=$REPO/gpurun_out/p6; mkdir -p "$O"
