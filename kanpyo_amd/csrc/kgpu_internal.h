@@ -129,7 +129,8 @@ struct LaunchPlan {
     int general_workgroups;
     uint32_t window_lds_bytes;  // > 0: the windowed kernel (kgpu_window.hip) behind the pools; 0: the general kernel serves what they route away
     int window_workgroups;
-    int window_team_workgroups;  // resident workgroups of the windowed kernel's two-wavefronts-per-sentence form on the whole chip (0: not available)
+    int window_team;             // wavefronts per sentence of the windowed kernel's team form (KGPU_WINDOW_TEAM_SIZE, default 2)
+    int window_team_workgroups;  // resident workgroups of that form on the whole chip (0: not available)
     int window_team_mode;        // KGPU_WINDOW_TEAM: 0 never, 2 whenever the chain starts with the windowed kernel, -1 (default) by the load
     uint32_t window_first_bytes; // KGPU_WINDOW_FIRST: a batch averaging this many bytes per sentence or more gets no pool launch in front (default 1024; 0 = never)
 };
@@ -145,7 +146,7 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
                     bool team_now = false /* a chain without pool launches: the windowed kernel's two-wavefronts-per-sentence form first, its ordinary form behind it */);
 int launch_tail_only(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int list_index, bool window_was_in_chain, void *stream);
 int window_workgroups_per_cu(uint32_t lds_bytes);
-int window_team_workgroups_per_cu(uint32_t lds_bytes);
+int window_team_workgroups_per_cu(uint32_t lds_bytes, int team);
 int launch_general_only(const DictView &d, const BatchArgs &a, void *stream);
 int launch_small_call(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, void *stream);  // pool kernel alone, one sentence per wavefront  // kgpu_lattice_dump: HBM-scratch kernel alone
 int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream);  // host_ctl: device pointer of the pinned result block

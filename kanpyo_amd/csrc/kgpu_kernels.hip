@@ -566,7 +566,7 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
             // a short list of long sentences: two wavefronts per sentence (kgpu_window.hip, TEAM), one workgroup each; what that form cannot hold goes on to
             // the ordinary form behind it
             WorkIO io{nullptr, nullptr, a.ovf[li], &ctl->ovf_count[li], nullptr};
-            int e = launch_tokenize_window(d, a, io, plan.window_lds_bytes, (int)std::min<uint64_t>(a.n, 1u << 30), 2, stream);
+            int e = launch_tokenize_window(d, a, io, plan.window_lds_bytes, (int)std::min<uint64_t>(a.n, 1u << 30), plan.window_team, stream);
             if (e) return e;
             in_list = a.ovf[li];
             in_count = &ctl->ovf_count[li];
@@ -691,7 +691,9 @@ LaunchPlan default_launch_plan(int device) {
         const int per_cu = kib ? window_workgroups_per_cu(t.window_lds_bytes) : 0;
         t.window_workgroups = cus * per_cu;
         if (per_cu <= 0) t.window_lds_bytes = 0;
-        t.window_team_workgroups = t.window_lds_bytes ? cus * std::max(0, window_team_workgroups_per_cu(t.window_lds_bytes)) : 0;
+        const char *ts = getenv("KGPU_WINDOW_TEAM_SIZE");
+        t.window_team = ts && atoi(ts) >= 2 && atoi(ts) <= 4 ? atoi(ts) : 2;
+        t.window_team_workgroups = t.window_lds_bytes ? cus * std::max(0, window_team_workgroups_per_cu(t.window_lds_bytes, t.window_team)) : 0;
         const char *tm = getenv("KGPU_WINDOW_TEAM");
         t.window_team_mode = tm ? atoi(tm) : -1;
         const char *wf = getenv("KGPU_WINDOW_FIRST");

@@ -1064,14 +1064,16 @@ int window_workgroups_per_cu(uint32_t lds_bytes) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_window<false, 1>, 64, (size_t)lds_bytes) != hipSuccess) return 0;
     return n;
 }
-// ... of the two-wavefronts-per-sentence form (0: it does not fit)
-int window_team_workgroups_per_cu(uint32_t lds_bytes) {
-    const uint32_t tb = team_lds_bytes(lds_bytes, 2);
-    if (tb > 64 * 1024) return 0;
+// ... of the form with `team` wavefronts per sentence (0: it does not fit)
+template <int TEAM>
+static int team_per_cu(uint32_t lds_bytes) {
+    const uint32_t tb = team_lds_bytes(lds_bytes, TEAM);
+    if (tb > 64 * 1024 && hipFuncSetAttribute((const void *)k_tokenize_window<false, TEAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb) != hipSuccess) return 0;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_window<false, 2>, 128, (size_t)tb) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_window<false, TEAM>, 64 * TEAM, (size_t)tb) != hipSuccess) return 0;
     return n;
 }
+int window_team_workgroups_per_cu(uint32_t lds_bytes, int team) { return team == 2 ? team_per_cu<2>(lds_bytes) : team == 3 ? team_per_cu<3>(lds_bytes) : team == 4 ? team_per_cu<4>(lds_bytes) : 0; }
 
 template <bool PROF, int TEAM>
 static int launch_window_inst(const WinArgs &wa, int n_workgroups, void *stream) {
@@ -1084,10 +1086,12 @@ static int launch_window_inst(const WinArgs &wa, int n_workgroups, void *stream)
     return (int)hipGetLastError();
 }
 
-// team: wavefronts per sentence (1, or 2: the host picks 2 when the work list is short against the chip's slots)
+// team: wavefronts per sentence (1; 2-4: the host picks that when the work list is short against the chip's slots)
 int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, int team, void *stream) {
     const WinArgs wa{d, a, io, lds_bytes};
     if (team == 2) return a.count_work ? launch_window_inst<true, 2>(wa, n_workgroups, stream) : launch_window_inst<false, 2>(wa, n_workgroups, stream);
+    if (team == 3) return a.count_work ? launch_window_inst<true, 3>(wa, n_workgroups, stream) : launch_window_inst<false, 3>(wa, n_workgroups, stream);
+    if (team == 4) return a.count_work ? launch_window_inst<true, 4>(wa, n_workgroups, stream) : launch_window_inst<false, 4>(wa, n_workgroups, stream);
     return a.count_work ? launch_window_inst<true, 1>(wa, n_workgroups, stream) : launch_window_inst<false, 1>(wa, n_workgroups, stream);
 }
 
