@@ -284,6 +284,13 @@ __device__ __forceinline__ uint32_t utf8_decode_lead(uint32_t b, uint32_t k, uin
 // ---- LDS access by absolute 32-bit LDS address (the sweep keeps ready-made addresses in its descriptors; going through `array + offset` makes the
 // compiler add the array's link-time base -- zero -- to every address, on the VALU)
 #define KGPU_LDS(T) __attribute__((address_space(3))) T
+// Stride of a target's row in the pair table, in half-words.  KGPU_PAIR_ODD (measurement build, round 5): an odd stride, so that the gather's lane-per-target
+// row writes do not all fall into the banks of a power-of-two stride (profiles/experiments/r05_pair_table_stride.txt: what it buys).
+#ifdef KGPU_PAIR_ODD
+#define KGPU_PSTRIDE(P) ((P) | 1u)
+#else
+#define KGPU_PSTRIDE(P) (P)
+#endif
 template <class T> __device__ __forceinline__ T lds_ld(uint32_t addr) { return *(const KGPU_LDS(T) *)(uintptr_t)addr; }
 template <class T> __device__ __forceinline__ void lds_st(uint32_t addr, T v) { *(KGPU_LDS(T) *)(uintptr_t)addr = v; }
 __device__ __forceinline__ uint2 lds_ld2(uint32_t addr) { const uint64_t v = lds_ld<uint64_t>(addr); return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); }
@@ -357,7 +364,7 @@ __device__ __forceinline__ void sweep_pass2(uint32_t lane, uint32_t tb, uint32_t
     const bool j0v = j < P, j1v = j + G < P;
     const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
     const uint2 e0 = lds_ld2(D1 + 8 * j), e1 = lds_ld2(D1 + 8 * j + 8 * G);
-    const uint32_t am = D2 + 2 * (__umul24(ti, P) + j);
+    const uint32_t am = D2 + 2 * (__umul24(ti, KGPU_PSTRIDE(P)) + j);
     const int32_t pc0 = lds_ld<int16_t>(am), pc1 = lds_ld<int16_t>(am + 2 * G);
     __builtin_amdgcn_sched_barrier(0);  // the five reads stay one round trip
     constexpr int32_t ABSENT = 0x7FFEFFFF;
@@ -376,7 +383,7 @@ __device__ __forceinline__ void sweep_pass1(uint32_t lane, uint32_t tb, uint32_t
     const bool j0v = j < P;
     const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
     const uint2 e0 = lds_ld2(D1 + 8 * j);
-    const int32_t pc0 = lds_ld<int16_t>(D2 + 2 * (__umul24(ti, P) + j));
+    const int32_t pc0 = lds_ld<int16_t>(D2 + 2 * (__umul24(ti, KGPU_PSTRIDE(P)) + j));
     __builtin_amdgcn_sched_barrier(0);
     const int32_t v0 = j0v ? (int32_t)e0.x + pc0 : 0x7FFEFFFF;
     const int32_t vmin = group_min_i32<3>(v0);

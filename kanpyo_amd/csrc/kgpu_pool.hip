@@ -390,7 +390,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             const uint32_t i = i0 + lane;
             const uint32_t v = i < C + 2 ? nb[i] : 0;    // targets starting at i
             const uint32_t w = i < C + 2 ? boff[i] : 0;  // predecessors ending at i
-            const uint32_t x = v * w;                    // relaxations at i (lattice.rs:122-125)
+            const uint32_t x = v * KGPU_PSTRIDE(w);      // relaxations at i (lattice.rs:122-125) = its pair costs (KGPU_PAIR_ODD: padded rows -- E then counts the padding too)
             const uint32_t vs = wave_incl_scan(v, lane), ws = wave_incl_scan(w, lane), xs = wave_incl_scan(x, lane);
             if (i < C + 2) { nb[i] = ncarry + vs - v; boff[i] = bcarry + ws - w; ebase[i] = ecarry + xs - x; }
             ncarry += __shfl(vs, 63, 64);
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                 const uint32_t q = nStart[t];
                 const uint32_t p0 = boff[q], P = boff[q + 1] - p0;
                 const uint32_t ti = t - nb[q];
-                const uint32_t base = ebase[q] - eb0 + ti * P;  // pair (ti, j) lives at ti*P + j
+                const uint32_t base = ebase[q] - eb0 + ti * KGPU_PSTRIDE(P);  // pair (ti, j) lives at ti*P + j
                 gather_target_row(bk + p0, P, conn_row(d, nLeft[t]), mpair + base);
             }
             wave_sync();
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                                     uint64_t ck = ~0ull;
                                     if (tvalid && jj < P) {
                                         const uint2 e = bk[p0 + jj];
-                                        const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + ti * P + jj];
+                                        const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + ti * KGPU_PSTRIDE(P) + jj];
                                         ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (e.y >> 16);
                                     }
                                     ck = group_min(ck, lg);

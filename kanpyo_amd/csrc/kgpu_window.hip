@@ -561,7 +561,7 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                 // would need targets x predecessors pair costs in LDS -- more than a window has.  It gets none (bit 31 of wideN): its step loads them itself.
                 const bool bigp = P > BIGP;
                 if (lane < nw && bigp) wideN[lane] |= 0x80000000u;
-                const uint32_t x = bigp ? 0u : v * P;
+                const uint32_t x = bigp ? 0u : v * KGPU_PSTRIDE(P);
                 const uint32_t xs = wave_incl_scan(x, lane);
                 if (lane <= nw) ebase[lane] = xs - x;
                 E = (uint32_t)__builtin_amdgcn_readlane((int)xs, 63);
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                     const uint32_t q = nStart[t];
                     const uint32_t p0 = boff[q], P = boff[q + 1] - p0;
                     const uint32_t ti = t - nb[q];
-                    const uint32_t base = ebase[q] - eb0 + ti * P;
+                    const uint32_t base = ebase[q] - eb0 + ti * KGPU_PSTRIDE(P);
                     if (!(wideN[q] >> 31)) gather_target_row(bk + p0, P, conn_row(d, nLeft[t]), mpair + base);
                 }
                 wave_sync();
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                                     int32_t cc[SLOWT];
 #pragma unroll
                                     for (int k = 0; k < (int)SLOWT; ++k)   // (no pair table for this position: the costs straight from the matrix, connection.rs:12-14)
-                                        cc[k] = (uint32_t)k < nt8 ? (nopair ? (int32_t)col[k][r] : (int32_t)mpair[eb + (tg + k) * P + jj]) : 0;
+                                        cc[k] = (uint32_t)k < nt8 ? (nopair ? (int32_t)col[k][r] : (int32_t)mpair[eb + (tg + k) * KGPU_PSTRIDE(P) + jj]) : 0;
 #pragma unroll
                                     for (int k = 0; k < (int)SLOWT; ++k)
                                         if ((uint32_t)k < nt8) {

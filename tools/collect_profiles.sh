@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 # the plain bench line: no GPU_MAX_HW_QUEUES in the environment -- the library sets it itself (config.streams says whether that took effect)
 (unset GPU_MAX_HW_QUEUES; python "$REPO/bench.py" > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err")
 # under rocprofv3 the profiler initialises the runtime before the library is loaded: there the variable comes from the environment
-export GPU_MAX_HW_QUEUES=8
+export GPU_MAX_HW_QUEUES=16
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python "$REPO/bench.py" --steps 20 --warmup 5 --no-cpu --no-extras > "$OUT/trace.json" 2> "$OUT/trace.err"
 cp "$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)" "$OUT/${TAG}_kernel_stats.csv"
@@ -28,12 +28,16 @@ done
 bash "$REPO/tools/pmc_passes.sh" "$OUT/pmc" python "$REPO/bench.py" --steps 2 --warmup 1 --queue 1 --no-cpu --no-extras > "$OUT/pmc.log" 2>&1
 python "$REPO/tools/pmc_summary.py" "$OUT/pmc" --json "$OUT/${TAG}_pmc_summary.json" > "$OUT/${TAG}_pmc_summary.txt"
 python "$REPO/tools/make_traffic_json.py" "$OUT/${TAG}_pmc_summary.json" "$OUT/pmc_traffic.json" "$TAG" > /dev/null
-BENCH_Q=1 bash "$REPO/tools/pmc_passes.sh" "$OUT/pmc_cfg5" python "$REPO/tools/bench_cfg.py" cfg5 1000 > "$OUT/pmc_cfg5.log" 2>&1
+# cfg 5: eight contexts = the ordinary (one wavefront per document) form of the windowed kernel; one context = its team form (two wavefronts per document)
+BENCH_Q=8 bash "$REPO/tools/pmc_passes.sh" "$OUT/pmc_cfg5" python "$REPO/tools/bench_cfg.py" cfg5 1000 > "$OUT/pmc_cfg5.log" 2>&1
 python "$REPO/tools/pmc_summary.py" "$OUT/pmc_cfg5" --json "$OUT/${TAG}_cfg5_pmc_summary.json" > "$OUT/${TAG}_cfg5_pmc_summary.txt"
+BENCH_Q=1 bash "$REPO/tools/pmc_passes.sh" "$OUT/pmc_cfg5_team" python "$REPO/tools/bench_cfg.py" cfg5 1000 > "$OUT/pmc_cfg5_team.log" 2>&1
+python "$REPO/tools/pmc_summary.py" "$OUT/pmc_cfg5_team" --json "$OUT/${TAG}_cfg5_team_pmc_summary.json" > "$OUT/${TAG}_cfg5_team_pmc_summary.txt"
 bash "$REPO/tools/pmc_phases.sh" "$OUT/phases" 1 2 3 4 5 6 7 0 > "$OUT/${TAG}_phase_counters.txt" 2>&1
 # the bench line once more, now that the counter files belong to this tree (traffic_stale false)
 cp "$OUT/pmc_traffic.json" "$OUT/pmc_instructions.json" "$REPO/profiles/"
 cp "$OUT/${TAG}_bench.json" "$OUT/${TAG}_bench_first.json"
 (cd "$REPO" && unset GPU_MAX_HW_QUEUES && python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench2.err")
-rm -rf "$OUT"/trace "$OUT"/trace_cfg5 "$OUT"/trace_cfg3 "$OUT"/pmc/pass*/ "$OUT"/pmc_cfg5/pass*/ "$OUT"/phases
+(cd "$REPO/kanpyo_amd/csrc" && make -s resource-usage 2>&1 | grep -E "Function Name|VGPRs:|SGPRs Spill|VGPRs Spill|ScratchSize|Occupancy|LDS Size" > "$OUT/${TAG}_resource_usage.txt")
+rm -rf "$OUT"/trace "$OUT"/trace_cfg5 "$OUT"/trace_cfg3 "$OUT"/pmc/pass*/ "$OUT"/pmc_cfg5/pass*/ "$OUT"/pmc_cfg5_team/pass*/ "$OUT"/phases
 echo done
