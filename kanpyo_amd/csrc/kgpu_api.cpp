@@ -615,7 +615,14 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
             team_now = team_mode == 2 || peak <= 2 * c->plan.window_team_workgroups;
         }
         c->last_team = team_now;
-        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, c->plan, pools_now, c->stop_after, c->stream, ef, window_now, c->last_tail, team_now);
+        // The pool's routing limit for THIS batch.  In a small batch of a mixed corpus (one sentence per wavefront slot) the pool launch lasts as long as its
+        // longest sentence, whose LDS x time grows with the square of its length: a chain whose last batch sent an eighth or more of its sentences on anyway
+        // routes from 24 pages instead of 32 there (cfg 3 at 4096 per batch: 17.8 -> 18.4 M sentences/s; at 65 536 per batch 32 is the better limit: 24.2 against
+        // 23.8; a pool-only workload must not see 24: cfg 2 loses 7 %, the dense dictionary 18 % -- profiles/experiments/r05_long_chains.txt).
+        // (The pool launch on the SHARED stream and only what follows on the long one -- pool kernels four wide -- was measured too: 17.5 -> 16.0.)
+        LaunchPlan pl = c->plan;
+        if (pools_now > 0 && c->win_share_q8 >= 32 && a.n <= 4u * 4096u && pl.pool_limit_auto) pl.pool_max_pages[0] = std::min<uint32_t>(pl.pool_max_pages[0], 24u);
+        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, pl, pools_now, c->stop_after, c->stream, ef, window_now, c->last_tail, team_now);
         if (e != hipSuccess) { set_error("k_tokenize launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     } else if (timed) HIPCHECK(hipEventRecord(ef, c->stream));
     if (timed) HIPCHECK(hipEventRecord(e1, c->stream));

@@ -125,6 +125,7 @@ struct LaunchPlan {
     uint32_t pool_bytes[2];
     uint32_t pool_waves[2];
     uint32_t pool_max_pages[2];  // of 64: larger reservations are routed to the next launch
+    bool pool_limit_auto;        // the shipped plan (no KGPU_POOL): the runtime may lower the routing limit per batch (kgpu_api.cpp: enqueue)
     int pool_workgroups[2];   // persistent grid per pool launch
     int general_workgroups;
     uint32_t window_lds_bytes;  // > 0: the windowed kernel (kgpu_window.hip) behind the pools; 0: the general kernel serves what they route away

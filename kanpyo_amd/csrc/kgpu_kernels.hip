@@ -656,7 +656,8 @@ LaunchPlan default_launch_plan(int device) {
     t.n_pools = 0;
     {
         const char *e = getenv("KGPU_POOL");
-        const char *q = e ? e : "40:4:40";
+        const char *q = e ? e : "40:4:32";
+        t.pool_limit_auto = e == nullptr;
         while (*q && t.n_pools < 2) {
             int kib = atoi(q), w = 8, mp = 64;
             const char *c = q;

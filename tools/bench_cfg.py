@@ -12,8 +12,8 @@ from kanpyo_amd.tokenizer import pack_sentences
 
 kind, n = sys.argv[1], int(sys.argv[2])
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
-sd = synth.build_dict()
-sents = synth.make_corpus(sd, n, 2 if kind == "cfg3" else 5 if kind == "cfg5" else 100, kind)
+sd = synth.build_dict(dense=(kind == "dense"))   # "dense": the dense-lattice variant of the dictionary under cfg 2-shaped text
+sents = synth.make_corpus(sd, n, 2 if kind == "cfg3" else 5 if kind == "cfg5" else 100, "cfg2" if kind == "dense" else kind)
 tok = Tokenizer(sd.dict)
 dev = torch.device("cuda", 0)
 bs = []

@@ -6,6 +6,7 @@ set -u
 OUT=$(realpath -m "$1"); TAG=$2
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$OUT"
+export KANPYO_SYNTH_CACHE=/tmp/kanpyo_synth   # (the synthetic dictionary is built once per box, not once per process)
 # the plain bench line: no GPU_MAX_HW_QUEUES in the environment -- the library sets it itself (config.streams says whether that took effect)
 (unset GPU_MAX_HW_QUEUES; python "$REPO/bench.py" > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err")
 # under rocprofv3 the profiler initialises the runtime before the library is loaded: there the variable comes from the environment
@@ -20,18 +21,21 @@ d = json.load(open(sys.argv[1])); r = d["roofline"]
 print(f"bench.py (same run, HIP events): value {d['value']:.0f} sentences/s, avg_kernel_ms {r['avg_kernel_ms']:.4f}, avg_launch_chain_ms {r['avg_launch_chain_ms']:.4f}, launches_timed {r['launches_timed']}")
 PY
 } > "$OUT/${TAG}_pool_dispatches.txt"
-for cfg in "cfg5 1000" "cfg3 100000"; do
-  set -- $cfg
-  BENCH_Q=8 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$1" -- python "$REPO/tools/bench_cfg.py" $1 $2 > "$OUT/trace_$1.log" 2>&1
-  cp "$(find "$OUT/trace_$1" -name "*kernel_stats.csv" | head -1)" "$OUT/${TAG}_$1_kernel_stats.csv"
+# cfg 5 through tools/window_timing.py (one 1000-document batch per context): eight contexts = eight launches in flight = the ordinary, one-wavefront-per-document
+# form of the windowed kernel (k_tokenize_window<false, 1>); one context = a lone batch = its team form (<false, 2>).  cfg 3 through tools/bench_cfg.py.
+for q in 8 1; do
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_cfg5_q$q" -- python "$REPO/tools/window_timing.py" cfg5 1000 $q > "$OUT/trace_cfg5_q$q.log" 2>&1
+  cp "$(find "$OUT/trace_cfg5_q$q" -name "*kernel_stats.csv" | head -1)" "$OUT/${TAG}_cfg5_q${q}_kernel_stats.csv"
 done
+BENCH_Q=8 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_cfg3" -- python "$REPO/tools/bench_cfg.py" cfg3 100000 > "$OUT/trace_cfg3.log" 2>&1
+cp "$(find "$OUT/trace_cfg3" -name "*kernel_stats.csv" | head -1)" "$OUT/${TAG}_cfg3_kernel_stats.csv"
 bash "$REPO/tools/pmc_passes.sh" "$OUT/pmc" python "$REPO/bench.py" --steps 2 --warmup 1 --queue 1 --no-cpu --no-extras > "$OUT/pmc.log" 2>&1
 python "$REPO/tools/pmc_summary.py" "$OUT/pmc" --json "$OUT/${TAG}_pmc_summary.json" > "$OUT/${TAG}_pmc_summary.txt"
 python "$REPO/tools/make_traffic_json.py" "$OUT/${TAG}_pmc_summary.json" "$OUT/pmc_traffic.json" "$TAG" > /dev/null
 # cfg 5: eight contexts = the ordinary (one wavefront per document) form of the windowed kernel; one context = its team form (two wavefronts per document)
-BENCH_Q=8 bash "$REPO/tools/pmc_passes.sh" "$OUT/pmc_cfg5" python "$REPO/tools/bench_cfg.py" cfg5 1000 > "$OUT/pmc_cfg5.log" 2>&1
+bash "$REPO/tools/pmc_passes.sh" "$OUT/pmc_cfg5" python "$REPO/tools/window_timing.py" cfg5 1000 8 > "$OUT/pmc_cfg5.log" 2>&1
 python "$REPO/tools/pmc_summary.py" "$OUT/pmc_cfg5" --json "$OUT/${TAG}_cfg5_pmc_summary.json" > "$OUT/${TAG}_cfg5_pmc_summary.txt"
-BENCH_Q=1 bash "$REPO/tools/pmc_passes.sh" "$OUT/pmc_cfg5_team" python "$REPO/tools/bench_cfg.py" cfg5 1000 > "$OUT/pmc_cfg5_team.log" 2>&1
+bash "$REPO/tools/pmc_passes.sh" "$OUT/pmc_cfg5_team" python "$REPO/tools/window_timing.py" cfg5 1000 1 > "$OUT/pmc_cfg5_team.log" 2>&1
 python "$REPO/tools/pmc_summary.py" "$OUT/pmc_cfg5_team" --json "$OUT/${TAG}_cfg5_team_pmc_summary.json" > "$OUT/${TAG}_cfg5_team_pmc_summary.txt"
 bash "$REPO/tools/pmc_phases.sh" "$OUT/phases" 1 2 3 4 5 6 7 0 > "$OUT/${TAG}_phase_counters.txt" 2>&1
 # the bench line once more, now that the counter files belong to this tree (traffic_stale false)
@@ -39,5 +43,5 @@ cp "$OUT/pmc_traffic.json" "$OUT/pmc_instructions.json" "$REPO/profiles/"
 cp "$OUT/${TAG}_bench.json" "$OUT/${TAG}_bench_first.json"
 (cd "$REPO" && unset GPU_MAX_HW_QUEUES && python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench2.err")
 (cd "$REPO/kanpyo_amd/csrc" && make -s resource-usage 2>&1 | grep -E "Function Name|VGPRs:|SGPRs Spill|VGPRs Spill|ScratchSize|Occupancy|LDS Size" > "$OUT/${TAG}_resource_usage.txt")
-rm -rf "$OUT"/trace "$OUT"/trace_cfg5 "$OUT"/trace_cfg3 "$OUT"/pmc/pass*/ "$OUT"/pmc_cfg5/pass*/ "$OUT"/pmc_cfg5_team/pass*/ "$OUT"/phases
+rm -rf "$OUT"/trace "$OUT"/trace_cfg5_q8 "$OUT"/trace_cfg5_q1 "$OUT"/trace_cfg3 "$OUT"/pmc/pass*/ "$OUT"/pmc_cfg5/pass*/ "$OUT"/pmc_cfg5_team/pass*/ "$OUT"/phases
 echo done
