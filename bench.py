@@ -911,7 +911,7 @@ def main():
             "avg_kernel_ms": avg_kernel_s * 1e3, "launches_timed": prof["launches"],
             "avg_kernel_what": f"HIP events on the ctx stream around the k_tokenize_pool launch of every 4th batch, {Q} batches in flight on the "
                                "chip, four of them running (a launch therefore lasts several times its share of the chip's work; see "
-                               "kernel_alone_ms and frac_at_job_rate); profiles/r04_kernel_stats.csv / r04_pool_dispatches.txt hold rocprofv3's durations of the same kernel for the same command",
+                               "kernel_alone_ms and frac_at_job_rate); profiles/r05_kernel_stats.csv / r05_pool_dispatches.txt hold rocprofv3's durations of the same kernel for the same command",
             "avg_launch_chain_ms": avg_chain_s * 1e3,
             "aux_kernels_avg_ms": prof["aux_ms"] / max(prof["launches"], 1),
             "launches_in_flight": Q,
