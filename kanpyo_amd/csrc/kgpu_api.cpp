@@ -628,7 +628,9 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
     if (timed) HIPCHECK(hipEventRecord(e1, c->stream));
     {
         c->h_ctl->pack_overflow = 0;  // set by the compaction's workgroups in the host copy directly; this context's previous batch has been synced
-        hipError_t e = (hipError_t)launch_scan_compact(a, c->h_ctl_dev, c->stream);
+        static const int scan_small = [] { const char *e = getenv("KGPU_SCAN_SMALL"); return e ? atoi(e) : -1; }();   // (measurement: 0 never, 1 always; default: behind chains with a windowed launch)
+        const bool small_wgs = scan_small >= 0 ? scan_small != 0 : (a.n && c->last_window && (c->last_pools == 0 || c->win_share_q8 >= 32));
+        hipError_t e = (hipError_t)launch_scan_compact(a, c->h_ctl_dev, c->stream, small_wgs);
         if (e != hipSuccess) { set_error("scan/compact launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     }
     if (timed) HIPCHECK(hipEventRecord(e2, c->stream));

@@ -150,7 +150,7 @@ int window_workgroups_per_cu(uint32_t lds_bytes);
 int window_team_workgroups_per_cu(uint32_t lds_bytes, int team);
 int launch_general_only(const DictView &d, const BatchArgs &a, void *stream);
 int launch_small_call(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, void *stream);  // pool kernel alone, one sentence per wavefront  // kgpu_lattice_dump: HBM-scratch kernel alone
-int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream);  // host_ctl: device pointer of the pinned result block
+int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream, bool small_workgroups = false);  // host_ctl: device pointer of the pinned result block
 LaunchPlan default_launch_plan(int device);
 int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
 

@@ -366,13 +366,15 @@ __global__ __launch_bounds__(64) void k_tokenize_general(DictView d, BatchArgs a
 // It is also the last reader of the launch's Control block: it publishes the block to the
 // pinned host copy (no D2H copy node) and zeroes the device copy for the next launch (no memset
 // node) -- two operations fewer per batch on a host-launch-bound stream.
+// (launched with 1024 threads behind a pool-only chain, with 256 or 64 behind a chain that holds a windowed launch: there every SIMD is full of 128-VGPR
+// wavefronts, and a workgroup of sixteen wavefronts waits until a whole CU has drained -- 180 us on the chain's critical path on cfg 5, round 5)
 __global__ __launch_bounds__(1024) void k_scan_counts(BatchArgs a, Control *host_ctl) {
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t carry_s;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nthr = blockDim.x;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (uint64_t base = 0; base < a.n; base += 1024) {
+    for (uint64_t base = 0; base < a.n; base += nthr) {
         const uint64_t i = base + tid;
         const uint32_t v = i < a.n ? a.tok_count[i] : 0;
         const uint32_t vs = wave_incl_scan(v, lane);
@@ -383,28 +385,28 @@ __global__ __launch_bounds__(1024) void k_scan_counts(BatchArgs a, Control *host
         const uint64_t carry = carry_s;
         if (i < a.n) a.tok_offsets[i] = carry + woff + vs - v;
         __syncthreads();
-        if (tid == 1023) carry_s = carry + woff + vs;
+        if (tid == nthr - 1) carry_s = carry + woff + vs;
         __syncthreads();
     }
     if (tid == 0) { a.tok_offsets[a.n] = carry_s; if (a.toff8) a.toff8[a.n] = carry_s; }   // (the mirrored table's last entry here, not in the compaction: an empty shard has no sentence to write it)
-    static_assert(sizeof(Control) % 4 == 0 && sizeof(Control) / 4 <= 1024, "Control is copied one dword per thread");
-    if (tid < sizeof(Control) / 4) {
+    static_assert(sizeof(Control) % 4 == 0, "Control is copied dword by dword");
+    for (uint32_t k = tid; k < sizeof(Control) / 4; k += nthr) {
         uint32_t *dc = (uint32_t *)a.ctl, *hc = (uint32_t *)host_ctl;
-        uint32_t v = dc[tid];
+        uint32_t v = dc[k];
         const uint32_t nt = (uint32_t)(offsetof(Control, n_tokens) / 4);
-        if (tid == nt) v = (uint32_t)carry_s;
-        if (tid == nt + 1) v = (uint32_t)(carry_s >> 32);
-        __hip_atomic_store(&hc[tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        dc[tid] = 0;
+        if (k == nt) v = (uint32_t)carry_s;
+        if (k == nt + 1) v = (uint32_t)(carry_s >> 32);
+        __hip_atomic_store(&hc[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        dc[k] = 0;
     }
 }
 
 // Staging (dequeue order) -> dense sentence order.  One wavefront per sentence,
 // dword-granular coalesced copy.
 __global__ __launch_bounds__(256) void k_compact(BatchArgs a) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const uint32_t lane = threadIdx.x & 63, wpb = blockDim.x >> 6;   // (four wavefronts per workgroup, or one behind a chain with a windowed launch: see k_scan_counts)
+    const uint64_t wave = (uint64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * wpb;
     for (uint64_t s = wave; s < a.n; s += nwaves) {
         const uint32_t cnt = a.tok_count[s];
         const uint64_t dst = a.tok_offsets[s];
@@ -419,9 +421,9 @@ __global__ __launch_bounds__(256) void k_compact(BatchArgs a) {
 // One wavefront per sentence, one 8-byte store per token: when a.out8 is pinned host memory these stores are the transfer.
 // (runs behind k_scan_counts, which has already published and zeroed the control block: the packing-overflow flag goes straight to the host copy)
 __global__ __launch_bounds__(256) void k_compact8(BatchArgs a, Control *host_ctl) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const uint32_t lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const uint64_t wave = (uint64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * wpb;
     for (uint64_t s = wave; s < a.n; s += nwaves) {
         const uint32_t cnt = a.tok_count[s];
         const uint64_t dst = a.tok_offsets[s];
@@ -611,7 +613,7 @@ int launch_general_only(const DictView &d, const BatchArgs &a, void *stream) {
     return (int)hipGetLastError();
 }
 
-int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream) {
+int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream, bool small_workgroups) {
     // Measured (tools/ab_scan.sh): records bound for mapped host memory (the large host call: a.toff8) 83.8 against 66.6 M sentences/s end to end in one
     // launch; the device-resident 24-byte path 92.8 against 96.9 -- there the separate kernels stay.  KGPU_SCAN_COMPACT=1 / 2 force one form (experiments),
     // KGPU_SCAN_WG the sentences per workgroup.
@@ -625,14 +627,17 @@ int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream) {
         else hipLaunchKernelGGL(k_scan_compact<false>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a, host_ctl, per_wg);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, host_ctl);
-    uint64_t blocks = (a.n + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    // small_workgroups: behind a chain that holds a windowed launch the chip is full of single-wavefront workgroups at four 128-VGPR wavefronts per SIMD -- a
+    // workgroup of one wavefront finds a place as soon as ANY of them ends, one of sixteen (or four) needs a CU (or a SIMD row) to drain
+    const unsigned scan_threads = !small_workgroups ? 1024u : a.n > 1024 ? 256u : 64u, wpb = small_workgroups ? 1u : 4u;
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(scan_threads), 0, (hipStream_t)stream, a, host_ctl);
+    uint64_t blocks = (a.n + wpb - 1) / wpb;
+    if (blocks > 2048 * (4 / wpb)) blocks = 2048 * (4 / wpb);
     if (blocks == 0) blocks = 1;
     // (measured: the compaction of 8-byte records into mapped host memory on a stream of its own, behind an event -- so that the context's
     // stream goes on with the next batch -- gives 46.8 instead of 68.6 M sentences/s end to end: one more stream than hardware queues)
-    if (a.out8) hipLaunchKernelGGL(k_compact8, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, host_ctl);
-    else hipLaunchKernelGGL(k_compact, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.out8) hipLaunchKernelGGL(k_compact8, dim3((unsigned)blocks), dim3(64 * wpb), 0, (hipStream_t)stream, a, host_ctl);
+    else hipLaunchKernelGGL(k_compact, dim3((unsigned)blocks), dim3(64 * wpb), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 
