@@ -615,22 +615,33 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
             team_now = team_mode == 2 || peak <= 2 * c->plan.window_team_workgroups;
         }
         c->last_team = team_now;
-        // The pool's routing limit for THIS batch.  In a small batch of a mixed corpus (one sentence per wavefront slot) the pool launch lasts as long as its
-        // longest sentence, whose LDS x time grows with the square of its length: a chain whose last batch sent an eighth or more of its sentences on anyway
-        // routes from 24 pages instead of 32 there (cfg 3 at 4096 per batch: 17.8 -> 18.4 M sentences/s; at 65 536 per batch 32 is the better limit: 24.2 against
-        // 23.8; a pool-only workload must not see 24: cfg 2 loses 7 %, the dense dictionary 18 % -- profiles/experiments/r05_long_chains.txt).
-        // (The pool launch on the SHARED stream and only what follows on the long one -- pool kernels four wide -- was measured too: 17.5 -> 16.0.)
+        // The pool's SHAPE for this batch.  A pool-only chain keeps four wavefronts on 40 KB (cfg 2 100.9 M sentences/s; two on 20 KB: 98.4-99.3, the dense dictionary
+        // 53.7 -> 50.8).  A chain that holds a windowed launch shares the chip with thousands of 10 KB single-wavefront workgroups that run for a millisecond: a
+        // workgroup of two wavefronts on 20 KB finds its LDS and its wavefront slots far sooner than one of four on 40 KB -- cfg 3 at 4096 per batch 18.5 -> 21.9 M
+        // sentences/s, at 65 536 23.9 -> 25.3 -- and in small batches (one sentence per wavefront slot: the pool launch lasts as long as its longest sentence) it
+        // routes a little earlier (56 of its 64 pages of 312 B instead of all).  profiles/experiments/r05_long_chains.txt, sections 5 and 8.
         LaunchPlan pl = c->plan;
-        if (pools_now > 0 && c->win_share_q8 >= 32 && a.n <= 4u * 4096u && pl.pool_limit_auto) pl.pool_max_pages[0] = std::min<uint32_t>(pl.pool_max_pages[0], 24u);
-        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, pl, pools_now, c->stop_after, c->stream, ef, window_now, c->last_tail, team_now);
+        if (pools_now > 0 && c->win_share_q8 >= 32 && pl.pool_limit_auto && pl.alt_pool_workgroups > 0) {
+            pl.pool_bytes[0] = pl.alt_pool_bytes; pl.pool_waves[0] = pl.alt_pool_waves; pl.pool_workgroups[0] = pl.alt_pool_workgroups;
+            pl.pool_max_pages[0] = a.n <= 4u * 4096u ? 56u : 64u;
+        }
+        // The windowed launch behind the pools: as many workgroups as the last batch's share of routed sentences suggests (+ a quarter), not the chip's 4096 -- the
+        // list is strided, so an estimate that is too small only makes a workgroup take a second sentence (the context's first batch gets the full grid).
+        static const int grid_mode = [] { const char *e = getenv("KGPU_WINDOW_GRID"); return e ? atoi(e) : -1; }();   // (measurement: 0 = always the full grid)
+        int window_grid = 0;
+        if (grid_mode != 0 && pools_now > 0 && window_now && c->rt.batches > 0)
+            window_grid = (int)std::min<uint64_t>(1u << 20, std::max<uint64_t>(256, ((a.n * c->win_share_q8) >> 8) * 5 / 4 + 64));
+        hipError_t e = (hipError_t)launch_tokenize(c->dict->view, a, pl, pools_now, c->stop_after, c->stream, ef, window_now, c->last_tail, team_now, window_grid);
         if (e != hipSuccess) { set_error("k_tokenize launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     } else if (timed) HIPCHECK(hipEventRecord(ef, c->stream));
+    // (the two small kernels behind a pool-only chain on a partner stream of each shared stream, so that the shared stream goes on with the next pool launch at once:
+    // measured with 16 hardware queues, cfg 2 100.5 -> 72.9 M sentences/s -- whatever lets a fifth pool launch start early loses, profiles/experiments/r05_long_chains.txt)
     if (timed) HIPCHECK(hipEventRecord(e1, c->stream));
     {
         c->h_ctl->pack_overflow = 0;  // set by the compaction's workgroups in the host copy directly; this context's previous batch has been synced
         static const int scan_small = [] { const char *e = getenv("KGPU_SCAN_SMALL"); return e ? atoi(e) : -1; }();   // (measurement: 0 never, 1 always; default: behind chains with a windowed launch)
-        const bool small_wgs = scan_small >= 0 ? scan_small != 0 : (a.n && c->last_window && (c->last_pools == 0 || c->win_share_q8 >= 32));
-        hipError_t e = (hipError_t)launch_scan_compact(a, c->h_ctl_dev, c->stream, small_wgs);
+        const bool small_wgs = scan_small >= 0 ? scan_small == 1 : (a.n && c->last_window && (c->last_pools == 0 || c->win_share_q8 >= 32));
+        hipError_t e = (hipError_t)launch_scan_compact(a, c->h_ctl_dev, c->stream, small_wgs, scan_small == 2);
         if (e != hipSuccess) { set_error("scan/compact launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     }
     if (timed) HIPCHECK(hipEventRecord(e2, c->stream));

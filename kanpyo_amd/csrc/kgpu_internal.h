@@ -125,7 +125,9 @@ struct LaunchPlan {
     uint32_t pool_bytes[2];
     uint32_t pool_waves[2];
     uint32_t pool_max_pages[2];  // of 64: larger reservations are routed to the next launch
-    bool pool_limit_auto;        // the shipped plan (no KGPU_POOL): the runtime may lower the routing limit per batch (kgpu_api.cpp: enqueue)
+    bool pool_limit_auto;        // the shipped plan (no KGPU_POOL): the runtime may pick the pool shape per batch (kgpu_api.cpp: enqueue)
+    uint32_t alt_pool_bytes, alt_pool_waves;   // ... the shape for chains that hold a windowed launch: smaller workgroups (20 KB, two wavefronts) find their LDS
+    int alt_pool_workgroups;                   // sooner on a chip full of 10 KB single-wavefront workgroups (0: not available)
     int pool_workgroups[2];   // persistent grid per pool launch
     int general_workgroups;
     uint32_t window_lds_bytes;  // > 0: the windowed kernel (kgpu_window.hip) behind the pools; 0: the general kernel serves what they route away
@@ -144,13 +146,14 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
                     void *event_after_first /* hipEvent_t recorded behind the first (dominant) launch, or null */,
                     bool window_now /* the windowed kernel behind the pools (plan.window_lds_bytes) */,
                     bool tail_now /* false: nothing behind a chain that has a work list (the host launches what is missing if a sentence needed it) */,
-                    bool team_now = false /* a chain without pool launches: the windowed kernel's two-wavefronts-per-sentence form first, its ordinary form behind it */);
+                    bool team_now = false /* a chain without pool launches: the windowed kernel's two-wavefronts-per-sentence form first, its ordinary form behind it */,
+                    int window_grid = 0 /* > 0: workgroups of the windowed launch behind the pools (the host's estimate of its work list; any grid is correct, the list is strided) */);
 int launch_tail_only(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int list_index, bool window_was_in_chain, void *stream);
 int window_workgroups_per_cu(uint32_t lds_bytes);
 int window_team_workgroups_per_cu(uint32_t lds_bytes, int team);
 int launch_general_only(const DictView &d, const BatchArgs &a, void *stream);
 int launch_small_call(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, void *stream);  // pool kernel alone, one sentence per wavefront  // kgpu_lattice_dump: HBM-scratch kernel alone
-int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream, bool small_workgroups = false);  // host_ctl: device pointer of the pinned result block
+int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream, bool small_workgroups = false, bool small_scan_only = false /* measurement */);  // host_ctl: device pointer of the pinned result block
 LaunchPlan default_launch_plan(int device);
 int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
 

@@ -531,10 +531,13 @@ int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
 // (the first one: the identity over [0, n)) and pushes what it does not serve onto the next launch's list.
 int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, int team, void *stream);  // kgpu_window.hip
 
-static int launch_window_over(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, const uint32_t *in_list, const unsigned int *in_count, int li, void *stream) {
+static int launch_window_over(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, const uint32_t *in_list, const unsigned int *in_count, int li, void *stream, int grid = 0) {
     WorkIO io{in_list, in_count, a.ovf[li], &a.ctl->ovf_count[li], nullptr};
     uint64_t wg = plan.window_workgroups;
     if (!in_list && a.n < wg) wg = a.n;
+    // behind the pools the list's length is on the device; a grid of the chip's full size is mostly workgroups that find nothing -- and each of them has to find a free
+    // slot on a chip full of long-running wavefronts before it can say so, which is what the launch (and the scan behind it) then waits for: the host's estimate instead
+    if (in_list && grid > 0 && (uint64_t)grid < wg) wg = (uint64_t)grid;
     return launch_tokenize_window(d, a, io, plan.window_lds_bytes, (int)(wg ? wg : 1), 1, stream);
 }
 static int launch_general_over(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, const uint32_t *in_list, const unsigned int *in_count, uint32_t stop_after, void *stream) {
@@ -546,7 +549,7 @@ static int launch_general_over(const DictView &d, const BatchArgs &a, const Laun
 }
 
 int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, int n_pools_now, uint32_t stop_after, void *stream,
-                    void *event_after_first, bool window_now, bool tail_now, bool team_now) {
+                    void *event_after_first, bool window_now, bool tail_now, bool team_now, int window_grid) {
     Control *ctl = a.ctl;
     const uint32_t *in_list = nullptr;
     const unsigned int *in_count = nullptr;
@@ -564,6 +567,7 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
     }
     if (event_after_first && (plan.n_pools == 0 || n_pools_now == 0) && hipEventRecord((hipEvent_t)event_after_first, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
     if (window_now && plan.window_lds_bytes && stop_after == 0) {
+        bool behind_team = false;
         if (team_now && !in_list && plan.window_team_workgroups > 0 && a.n) {
             // a short list of long sentences: two wavefronts per sentence (kgpu_window.hip, TEAM), one workgroup each; what that form cannot hold goes on to
             // the ordinary form behind it
@@ -573,8 +577,9 @@ int launch_tokenize(const DictView &d, const BatchArgs &a, const LaunchPlan &pla
             in_list = a.ovf[li];
             in_count = &ctl->ovf_count[li];
             ++li;
+            behind_team = true;
         }
-        int e = launch_window_over(d, a, plan, in_list, in_count, li, stream);
+        int e = launch_window_over(d, a, plan, in_list, in_count, li, stream, behind_team ? 256 : window_grid);   // (what a team hands on is rare: a small strided grid)
         if (e) return e;
         in_list = a.ovf[li];
         in_count = &ctl->ovf_count[li];
@@ -613,7 +618,7 @@ int launch_general_only(const DictView &d, const BatchArgs &a, void *stream) {
     return (int)hipGetLastError();
 }
 
-int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream, bool small_workgroups) {
+int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream, bool small_workgroups, bool small_scan_only) {
     // Measured (tools/ab_scan.sh): records bound for mapped host memory (the large host call: a.toff8) 83.8 against 66.6 M sentences/s end to end in one
     // launch; the device-resident 24-byte path 92.8 against 96.9 -- there the separate kernels stay.  KGPU_SCAN_COMPACT=1 / 2 force one form (experiments),
     // KGPU_SCAN_WG the sentences per workgroup.
@@ -629,7 +634,7 @@ int launch_scan_compact(const BatchArgs &a, Control *host_ctl, void *stream, boo
     }
     // small_workgroups: behind a chain that holds a windowed launch the chip is full of single-wavefront workgroups at four 128-VGPR wavefronts per SIMD -- a
     // workgroup of one wavefront finds a place as soon as ANY of them ends, one of sixteen (or four) needs a CU (or a SIMD row) to drain
-    const unsigned scan_threads = !small_workgroups ? 1024u : a.n > 1024 ? 256u : 64u, wpb = small_workgroups ? 1u : 4u;
+    const unsigned scan_threads = !(small_workgroups || small_scan_only) ? 1024u : a.n > 1024 ? 256u : 64u, wpb = small_workgroups ? 1u : 4u;
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(scan_threads), 0, (hipStream_t)stream, a, host_ctl);
     uint64_t blocks = (a.n + wpb - 1) / wpb;
     if (blocks > 2048 * (4 / wpb)) blocks = 2048 * (4 / wpb);
@@ -687,6 +692,11 @@ LaunchPlan default_launch_plan(int device) {
             while (*q && *q != ',') ++q;
             if (*q == ',') ++q;
         }
+    }
+    t.alt_pool_bytes = 20 * 1024; t.alt_pool_waves = 2;
+    {
+        const int per_cu = (t.pool_limit_auto && t.n_pools) ? pool_workgroups_per_cu(t.alt_pool_bytes, t.alt_pool_waves) : 0;
+        t.alt_pool_workgroups = per_cu > 0 ? cus * per_cu : 0;
     }
     // windowed kernel (everything the pools route away): KGPU_WINDOW="<KiB>" of LDS per single-wavefront workgroup, "0" = off (the general kernel then serves it all)
     {
