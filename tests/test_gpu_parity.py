@@ -754,3 +754,45 @@ def test_long_batches_start_with_the_windowed_kernel(libs, monkeypatch):
         tok2.close()
         for k in env:
             monkeypatch.delenv(k)
+
+
+def test_callers_own_stream_is_never_left(libs):
+    """A context created on the caller's stream keeps every launch on it -- window-first chains, the team form, chains with a large windowed share included (the
+    long streams are for contexts on the library's own streams): work the caller queues on that stream before and after a batch stays ordered with it."""
+    import torch
+
+    from kanpyo_amd import Tokenizer, synth
+    from kanpyo_amd.device import DeviceContext
+    from kanpyo_amd.tokenizer import pack_sentences
+
+    _, oracle = libs
+    sd = synth.build_dict(20000, seed=5)
+    tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    c = DeviceContext(tok, st.cuda_stream)
+    assert c.plan()["long_streams"] == 0
+    docs = synth.make_corpus(sd, 30, 7, "cfg5")
+    mix = synth.make_corpus(sd, 900, 8, "cfg3")
+    short = synth.make_corpus(sd, 500, 9, "cfg2")
+    for sents in (docs, mix, mix, short, docs):
+        u, o = pack_sentences(sents)
+        e = orc.tokenize_batch(u, o, 8)
+        n, cap = len(sents), int(o[-1]) + len(sents)
+        with torch.cuda.stream(st):   # the input is produced on the caller's stream, right in front of the batch: no synchronisation in between
+            d_u = torch.from_numpy(u.copy()).to(dev, non_blocking=False)
+            d_o = torch.from_numpy(o.astype(np.int64)).to(dev, non_blocking=False)
+            d_t = torch.empty((cap, 6), dtype=torch.int32, device=dev)
+            d_toff = torch.empty(n + 1, dtype=torch.int64, device=dev)
+            d_st = torch.empty(n, dtype=torch.uint8, device=dev)
+            c.tokenize(d_u.data_ptr(), d_o.data_ptr(), n, int(o[-1]), d_t.data_ptr(), cap, d_toff.data_ptr(), d_st.data_ptr())
+            total = d_toff[-1:].clone()   # queued on the same stream BEHIND the batch: must see its result without any host synchronisation
+        nt = c.sync()
+        assert nt == len(e.tokens)
+        p = c.profile()
+        if p["tail_reruns"] == 0 and p["arena_regrows"] == 0 and p["window_reruns"] == 0:   # (a batch the host had to complete at sync time is final only then)
+            assert int(total.cpu()[0]) == nt
+        assert np.array_equal(d_toff.cpu().numpy().astype(np.uint64), e.offsets)
+        assert np.array_equal(d_t[:nt].cpu().numpy().reshape(-1), e.tokens.view(np.int32).reshape(-1))
+    c.close()
+    tok.close()

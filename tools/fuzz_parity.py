@@ -21,9 +21,13 @@ t_end = time.time() + budget
 rounds = sentences = 0
 while time.time() < t_end:
     nkeys = rng.choice([6000, 12000, 20000, 60000])
-    pool = rng.choice(["0", "8:2:64", "16:4:32", "40:4:32", "40:4:32", "40:8:20", "80:8:20", "80:10:64", "160:16:64", "80:8:20,160:4:64", "24:3:48"])
+    pool = rng.choice(["0", "8:2:64", "16:4:32", "40:4:32", "40:4:32", "40:8:20", "80:8:20", "80:10:64", "160:16:64", "80:8:20,160:4:64", "24:3:48", "auto", "auto", "auto"])
     window_kib = rng.choice(["0", "8", "10", "12", "12", "16", "24"])  # the windowed kernel behind the pools (0 = off: the general kernel takes its place)
-    os.environ["KGPU_POOL"], os.environ["KGPU_WINDOW"] = pool, window_kib
+    os.environ["KGPU_WINDOW"] = window_kib
+    if pool == "auto":   # the shipped plan: no KGPU_POOL at all -- only then does the runtime pick the pool's shape by the chain (two wavefronts on 20 KB in front of a windowed launch)
+        os.environ.pop("KGPU_POOL", None)
+    else:
+        os.environ["KGPU_POOL"] = pool
     os.environ["KGPU_WINDOW_TEAM"] = rng.choice(["-1", "-1", "0", "2", "2"])     # the two-wavefronts-per-sentence form of window-first chains: by the load / never / always
     os.environ["KGPU_WINDOW_FIRST"] = rng.choice(["1024", "1024", "0", "64", "300"])  # average bytes per sentence from which a chain starts with the windowed kernel
     os.environ["KGPU_BYTE_TRIE"] = "1" if rng.random() < 0.15 else "0"  # (read at dictionary creation: KGPU_TEST_HOOKS_REREAD below)
