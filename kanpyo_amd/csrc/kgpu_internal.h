@@ -83,7 +83,7 @@ struct Control {
     unsigned int pack_overflow;       // compact records: a token did not fit kgpu_token8 (chars > 4095 or bytes > 262143): the host falls back to 24-byte records
     unsigned int window_fail;         // the windowed long-sentence kernel met a sentence it cannot hold AND had no list to hand it on to: the host reruns the batch with the HBM-lattice kernel
     unsigned int small_abort;         // ... a wavefront gave up waiting at the rendezvous: the host redoes the call on the general path
-    unsigned int pad2;
+    unsigned int win_ticket;          // the windowed kernel's ordinary form: next entry of its work list (its workgroups claim sentences one by one)
     unsigned int pad3;
     unsigned long long dump[8];       // kgpu_lattice_dump: arena offsets of the sentence's two slabs, B, C, N, 1 = valid, dp of EOS
 };

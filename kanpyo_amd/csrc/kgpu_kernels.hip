@@ -529,7 +529,7 @@ int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves);
 // Launch chain: the LDS page-pool kernel(s) -> the windowed kernel (whatever the pools route away: long sentences, lattices too dense for a
 // pool) -> the general kernel (what the windowed kernel hands back: the last resort).  Every launch is a persistent grid over its work list
 // (the first one: the identity over [0, n)) and pushes what it does not serve onto the next launch's list.
-int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, int team, void *stream);  // kgpu_window.hip
+int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, int team, void *stream, bool claim = false);  // kgpu_window.hip
 
 static int launch_window_over(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, const uint32_t *in_list, const unsigned int *in_count, int li, void *stream, int grid = 0) {
     WorkIO io{in_list, in_count, a.ovf[li], &a.ctl->ovf_count[li], nullptr};
@@ -538,7 +538,11 @@ static int launch_window_over(const DictView &d, const BatchArgs &a, const Launc
     // behind the pools the list's length is on the device; a grid of the chip's full size is mostly workgroups that find nothing -- and each of them has to find a free
     // slot on a chip full of long-running wavefronts before it can say so, which is what the launch (and the scan behind it) then waits for: the host's estimate instead
     if (in_list && grid > 0 && (uint64_t)grid < wg) wg = (uint64_t)grid;
-    return launch_tokenize_window(d, a, io, plan.window_lds_bytes, (int)(wg ? wg : 1), 1, stream);
+    // more sentences expected than workgroups: they are claimed one by one instead of every G-th being a workgroup's (kgpu_window.hip; KGPU_WINDOW_CLAIM=0 / 1 forces it)
+    static const int claim_mode = [] { const char *e = getenv("KGPU_WINDOW_CLAIM"); return e ? atoi(e) : -1; }();
+    const uint64_t expected = in_list ? (grid > 64 ? ((uint64_t)grid - 64) * 4 / 5 : 0) : a.n;
+    const bool claim = claim_mode >= 0 ? claim_mode != 0 : expected > wg;
+    return launch_tokenize_window(d, a, io, plan.window_lds_bytes, (int)(wg ? wg : 1), 1, stream, claim);
 }
 static int launch_general_over(const DictView &d, const BatchArgs &a, const LaunchPlan &plan, const uint32_t *in_list, const unsigned int *in_count, uint32_t stop_after, void *stream) {
     WorkIO io{in_list, in_count, nullptr, nullptr, nullptr};

@@ -164,7 +164,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
     const bool own_slice = W == 1;
     const uint32_t page = ((pool_bytes - POOL_HDR) / POOL_PAGES) & (own_slice ? ~7u : ~15u);
     auto pages_for = [&](uint32_t bytes) { return (bytes + page - 1) / page; };  // (a reciprocal multiply instead: measured, no difference)
-    if (threadIdx.x == 0) *bm = 0;
+    // the workgroup's sentences -- list entries blockIdx.x + k * gridDim.x -- are handed to its wavefronts by a ticket in LDS (the dword behind the bitmap): a
+    // wavefront that is through takes the next one, instead of every wavefront owning every W-th (with four or more sentences per wavefront -- batches of 16 384 and
+    // more -- the static form left the early finishers of a workgroup waiting for its slowest wavefront's whole share; no global atomic: that lost in round 2)
+    uint32_t *ticket = (uint32_t *)(pool + 8);
+    if (threadIdx.x == 0) { *bm = 0; *ticket = 0; }
 #ifdef KGPU_STEP_TIMING
     if (threadIdx.x == 0) { *(uint64_t *)(pool + 16) = 0; *(uint32_t *)(pool + 24) = 0; }
     const uint64_t tm_w0 = __builtin_amdgcn_s_memtime();
@@ -185,7 +189,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         KGPU_ARGS();
         uint64_t s = 0;
         // sentence i of the work list -> workgroup i mod G, wavefront (i / G) mod W
+#ifdef KGPU_POOL_STATIC   // measurement build: sentence i of the work list -> workgroup i mod G, wavefront (i / G) mod W, as before round 5
         if (!work_next_at(io, a, (uint64_t)blockIdx.x + (uint64_t)gridDim.x * (wave + (uint64_t)W * iter), s)) break;
+#else
+        (void)iter;
+        uint32_t tk = 0;
+        if (lane == 0) tk = atomicAdd(ticket, 1u);
+        tk = bcast32(tk);
+        if (!work_next_at(io, a, (uint64_t)blockIdx.x + (uint64_t)gridDim.x * tk, s)) break;
+#endif
         const uint64_t b0 = a.offsets[s];
         const uint64_t Bl = a.offsets[s + 1] - b0;
         const uint32_t pool_cap = page * POOL_PAGES;

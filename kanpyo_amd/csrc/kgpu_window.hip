@@ -4,8 +4,8 @@
 // positions at a time, ascending), every window with the phases of the LDS-resident pool kernel (kgpu_pool.hip) -- walk with
 // the text and the parked matches in LDS, node-parallel emit, one parallel gather of the connection costs per block, the
 // Viterbi chain at LDS latency -- and only what outlives a window leaves LDS:
-//   * per node 16 bytes to HBM {best predecessor, morph id, start char, start byte}: what the backtrace and the tokens need
-//     (src/lattice.rs:144-153, src/tokenizer.rs:22-43);
+//   * per node 4 + 8 bytes to HBM: its best predecessor in a dense array of its own (the backtrace reads every node's), {morph id, start char} for the
+//     tokens (src/lattice.rs:144-153, src/tokenizer.rs:22-43); the byte offsets come from the per-character records of the decode pass;
 //   * the bucket entries {end, dp, right id, node} of nodes that end beyond the window: those that end within the next
 //     2 WIN positions stay in LDS (the carry list: they are the seeds of the following window's buckets, exactly as BOS is the
 //     seed of the first, src/lattice.rs:156-164), the others -- unknown words of a long same-category run, up to 1024
@@ -14,7 +14,8 @@
 //     is relaxed by streaming them from the FIFO, 64 per step.
 // LDS-resident lattices (kgpu_pool.hip) do not scale to long sentences (LDS x time grows with the square of the length: DESIGN.md
 // section 8); this kernel's LDS is independent of the length and its HBM traffic is one write per node.  It serves everything the pool
-// kernel routes away -- from ~150 characters up to any length.  (Rounds 2-3 had a second long-sentence kernel that kept the whole lattice in
+// kernel routes away -- from ~125 characters up to any length -- and whole batches of long sentences, which start with it (kgpu_api.cpp: ctx_pick_chain);
+// for short work lists it runs as a TEAM of wavefronts per sentence (below).  (Rounds 2-3 had a second long-sentence kernel that kept the whole lattice in
 // HBM and staged blocks of it in LDS for the sweep: 44 bytes per node, ~70 per byte, read back several times.  On 190-512-character
 // sentences the two were level, on 2048-character documents this one is 1.6x faster: round 4 removed the other.)
 //
@@ -122,7 +123,7 @@ struct TeamState {
 };
 
 // PROF: device-side work counters + per-phase shader clocks (KGPU_PROFILE_WORK) -- a separate instantiation: the accumulators cost ~40 SGPRs
-struct WinArgs { DictView d; BatchArgs a; WorkIO io; uint32_t lds_bytes; };
+struct WinArgs { DictView d; BatchArgs a; WorkIO io; uint32_t lds_bytes; uint32_t claim; /* 1: the workgroups claim their sentences one by one (Control::win_ticket) */ };
 #ifndef KGPU_WIN_WPE
 #define KGPU_WIN_WPE 4
 #endif
@@ -221,7 +222,16 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
     for (uint32_t iter = 0;; ++iter) {
         KW_ARGS();
         uint64_t s = 0;
-        if (!work_next(io, a, iter, s)) break;
+        if (TEAM == 1 && kargs->claim) {
+            // the ordinary form over a list longer than its grid claims its sentences one by one (one atomic per sentence of a kernel that spends 100 us and more on
+            // each): the launch -- cfg 3 in batches of 65 536: five long sentences per workgroup -- no longer ends with the workgroup whose every-G-th share was the
+            // longest (25.5 -> 27.5 M sentences/s).  The host asks for it by the list's expected length: with a sentence per workgroup the static form is the better one
+            // (cfg 3 at 4096 per batch 21.8 against 21.2).
+            uint32_t tk = 0;
+            if (lane == 0) tk = atomicAdd(&a.ctl->win_ticket, 1u);
+            tk = bcast32(tk);
+            if (!work_next_at(io, a, tk, s)) break;
+        } else if (!work_next(io, a, iter, s)) break;
         const uint64_t b0 = a.offsets[s];
         const uint32_t B = (uint32_t)(a.offsets[s + 1] - b0);
         const uint8_t *text = a.utf8 + b0;
@@ -1087,8 +1097,8 @@ static int launch_window_inst(const WinArgs &wa, int n_workgroups, void *stream)
 }
 
 // team: wavefronts per sentence (1; 2-4: the host picks that when the work list is short against the chip's slots)
-int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, int team, void *stream) {
-    const WinArgs wa{d, a, io, lds_bytes};
+int launch_tokenize_window(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t lds_bytes, int n_workgroups, int team, void *stream, bool claim) {
+    const WinArgs wa{d, a, io, lds_bytes, (team <= 1 && claim) ? 1u : 0u};
     if (team == 2) return a.count_work ? launch_window_inst<true, 2>(wa, n_workgroups, stream) : launch_window_inst<false, 2>(wa, n_workgroups, stream);
     if (team == 3) return a.count_work ? launch_window_inst<true, 3>(wa, n_workgroups, stream) : launch_window_inst<false, 3>(wa, n_workgroups, stream);
     if (team == 4) return a.count_work ? launch_window_inst<true, 4>(wa, n_workgroups, stream) : launch_window_inst<false, 4>(wa, n_workgroups, stream);
