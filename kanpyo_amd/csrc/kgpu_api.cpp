@@ -732,15 +732,9 @@ extern "C" int kgpu_tokenize_device_compact(kgpu_ctx *c, const uint8_t *d_utf8, 
 
 // Host side of the 8-byte records: position / start are running sums over the sentence (include/kanpyo_gpu.h, kgpu_token8).
 extern "C" void kgpu_expand_tokens(const kgpu_token8 *in, const uint64_t *tok_offsets, const uint32_t *first, uint64_t n, kgpu_token *out) {
-    const uint64_t base = tok_offsets[0];
-    for (uint64_t s = 0; s < n; ++s) {
-        uint32_t pos = first[2 * s], st = first[2 * s + 1];
-        for (uint64_t k = tok_offsets[s] - base, e = tok_offsets[s + 1] - base; k < e; ++k) {
-            const uint32_t p = in[k].packed, chars = KGPU_T8_CHARS(p), bytes = KGPU_T8_BYTES(p);
-            out[k] = kgpu_token{in[k].id, KGPU_T8_CLS(p), pos, st, st + chars, bytes};
-            pos += bytes; st += chars;
-        }
-    }
+    const bool stream = n && expand_stream_wanted(tok_offsets[n] - tok_offsets[0]);
+    expand_tokens(in, tok_offsets, first, n, out, stream);
+    if (stream) expand_fence();
 }
 
 // The pending batch is over (completed or given up): the context is free, its share of the dictionary's long sentences in flight is returned.
@@ -1133,6 +1127,7 @@ struct PipeJob {
     size_t off_first = 0, off_toff = 0, off_status = 0;  // inside pin_out: records | first | token offsets | status
     std::atomic<int> tasks{0};                          // expansion tasks still reading pin_out
     bool active = false;
+    bool stream = false;                                // the call is large: its 24-byte records are written with non-temporal stores (kgpu_runtime.h: expand_tokens)
 };
 
 // memcpy of a large block with the workers' help (the calling thread's staging copy is what limits a large call otherwise)
@@ -1228,16 +1223,18 @@ static int pipe_finish(PipeJob &j, const uint8_t *utf8, const uint64_t *offsets,
     if (nt == 0) { if (!overflow) tok_offsets[j.lo] = tok_base; return KGPU_OK; }
     j.tasks.store(nt, std::memory_order_release);
     outstanding.fetch_add(nt, std::memory_order_acq_rel);
-    const bool ovf = overflow;
+    const bool ovf = overflow, jstream = j.stream;
     const uint64_t lo = j.lo, m = j.m;
     for (int t = 0; t < nt; ++t) {
         const uint64_t a = (uint64_t)t * SLICE, b = std::min(m, a + SLICE);
         std::atomic<int> *jt = &j.tasks, *out = &outstanding;
         workers().submit([=] {
             if (!ovf) {
-                kgpu_expand_tokens(rec + toff[a], toff + a, first + 2 * a, b - a, tokens + tok_base + toff[a]);
+                const bool stream = jstream;
+                expand_tokens(rec + toff[a], toff + a, first + 2 * a, b - a, tokens + tok_base + toff[a], stream);
                 for (uint64_t i = a; i < b; ++i) tok_offsets[lo + i] = tok_base + toff[i];
                 if (b == m) tok_offsets[lo + m] = tok_base + toff[m];
+                if (stream) expand_fence();
             }
             if (status) std::memcpy(status + lo + a, st + a, (size_t)(b - a));
             workers().task_done(*jt);
@@ -1624,6 +1621,7 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
         while (done + m < n && m < CHUNK_SENTS && (m == 0 || offsets[done + m + 1] - offsets[done] <= CHUNK_BYTES)) ++m;
         j.lo = done; j.m = m;
         const double t0 = now();
+        j.stream = expand_stream_wanted((uint64_t)n * 2);   // by the CALL's size (32 768 tokens ~ 16 384 sentences and more): a 4096-sentence call's records are read back at once
         if ((rc = pipe_submit(j, utf8, offsets, pinned_in))) break;
         t_submit += now() - t0;
         ++inflight;

@@ -45,27 +45,19 @@ void merge_plan(const MergeSrc *src, int G, uint64_t cnt, uint64_t slice, std::v
 
 // sentences [a, b) of the super-chunk: tok_offsets[j] (already pointing at the super-chunk's first entry), the 24-byte records (tokens = the caller's
 // whole array, or nullptr: offsets and status only), status bytes.  base = tokens in front of sentence a, in the caller's numbering.
-void merge_slice(const MergeSrc *src, int G, uint64_t a, uint64_t b, uint64_t base, kgpu_token *tokens, uint64_t *tok_offsets, uint8_t *status) {
+void merge_slice(const MergeSrc *src, int G, uint64_t a, uint64_t b, uint64_t base, kgpu_token *tokens, uint64_t *tok_offsets, uint8_t *status, bool stream) {
     const uint64_t Gu = (uint64_t)G;
     uint64_t g = a % Gu, k = a / Gu, run = base;
     for (uint64_t j = a; j < b; ++j) {
         const MergeSrc &sx = src[g];
         const uint64_t t0 = sx.toff[k], t1 = sx.toff[k + 1];
         tok_offsets[j] = run;
-        if (tokens) {
-            uint32_t pos = sx.first[2 * k], st = sx.first[2 * k + 1];
-            const kgpu_token8 *in = sx.rec + t0;
-            kgpu_token *out = tokens + run;
-            for (uint64_t q = 0, e = t1 - t0; q < e; ++q) {
-                const uint32_t p = in[q].packed, chars = KGPU_T8_CHARS(p), bytes = KGPU_T8_BYTES(p);
-                out[q] = kgpu_token{in[q].id, KGPU_T8_CLS(p), pos, st, st + chars, bytes};
-                pos += bytes; st += chars;
-            }
-        }
+        if (tokens) expand_tokens(sx.rec + t0, sx.toff + k, sx.first + 2 * k, 1, tokens + run, stream);   // (one sentence: the records of shard g's local sentence k)
         if (status) status[j] = sx.st[k];
         run += t1 - t0;
         if (++g == Gu) { g = 0; ++k; }
     }
+    if (stream) expand_fence();
 }
 
 // The caller's current device, restored on every exit path: the multi-device entry points visit every device on the calling thread.
@@ -277,7 +269,7 @@ extern "C" int kgpu_tokenize_batch_multi(kgpu_dict *const *dicts, int n_dicts, c
             const uint64_t a = (uint64_t)t * SLICE, b = std::min(cnt, a + SLICE), base = base0 + slice_base[(size_t)t];
             std::atomic<int> *st_ = &mc.slot_tasks[slot], *out_ = &outstanding;
             workers().submit([=] {
-                if (!ovf) merge_slice(src.data(), G, a, b, base, tokens, tok_offsets + lo, status ? status + lo : nullptr);
+                if (!ovf) merge_slice(src.data(), G, a, b, base, tokens, tok_offsets + lo, status ? status + lo : nullptr, expand_stream_wanted(chunk_tokens));
                 else if (status) { uint64_t g = a % (uint64_t)G, k = a / (uint64_t)G; for (uint64_t jx = a; jx < b; ++jx) { status[lo + jx] = src[(size_t)g].st[k]; if (++g == (uint64_t)G) { g = 0; ++k; } } }
                 workers().task_done(*st_);
                 workers().task_done(*out_);
@@ -403,13 +395,14 @@ extern "C" int kgpu_debug_merge_shards(int G, uint64_t cnt, const kgpu_token8 *c
         const int nt = (int)(slice_base.size() - 1);
         total = slice_base[(size_t)nt];
         const bool fits = tokens && total <= token_capacity;
+        const bool stream = expand_stream_wanted(total);
         tok_offsets[cnt] = total;
         std::atomic<int> left{nt};
         const MergeSrc *sp = src.data();
         for (int t = 0; t < nt; ++t) {
             const uint64_t a = (uint64_t)t * slice, b = std::min(cnt, a + slice), base = slice_base[(size_t)t];
             std::atomic<int> *l = &left;
-            workers().submit([=] { merge_slice(sp, G, a, b, base, fits ? tokens : nullptr, tok_offsets, status); workers().task_done(*l); });
+            workers().submit([=] { merge_slice(sp, G, a, b, base, fits ? tokens : nullptr, tok_offsets, status, stream); workers().task_done(*l); });
         }
         workers().wait_zero(left);
     }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -156,7 +157,53 @@ struct kgpu_ctx {
 };
 
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
 namespace kgpu {
+
+// Host side of the 8-byte records (include/kanpyo_gpu.h, kgpu_token8): n sentences' records -> 24-byte kgpu_token, position / start as running sums per
+// sentence.  stream: the 24-byte records go out with non-temporal stores (three 8-byte movnti per token; `out` 8-byte aligned) -- the expansion of a large
+// call writes hundreds of megabytes nobody reads back soon, and an ordinary store first READS every line it is about to overwrite: a third of the
+// expansion's memory traffic, and the expansion is a memory-bandwidth job.  The caller fences (expand_fence) before it publishes the result.
+inline void expand_tokens(const kgpu_token8 *in, const uint64_t *tok_offsets, const uint32_t *first, uint64_t n, kgpu_token *out, bool stream) {
+    const uint64_t base = tok_offsets[0];
+#if defined(__x86_64__)
+    if (stream && ((uintptr_t)out & 7u) == 0) {
+        for (uint64_t s = 0; s < n; ++s) {
+            uint32_t pos = first[2 * s], st = first[2 * s + 1];
+            for (uint64_t k = tok_offsets[s] - base, e = tok_offsets[s + 1] - base; k < e; ++k) {
+                const uint32_t p = in[k].packed, chars = KGPU_T8_CHARS(p), bytes = KGPU_T8_BYTES(p);
+                long long *o = (long long *)(out + k);
+                _mm_stream_si64(o, (long long)((uint64_t)(uint32_t)in[k].id | ((uint64_t)KGPU_T8_CLS(p) << 32)));
+                _mm_stream_si64(o + 1, (long long)((uint64_t)pos | ((uint64_t)st << 32)));
+                _mm_stream_si64(o + 2, (long long)((uint64_t)(st + chars) | ((uint64_t)bytes << 32)));
+                pos += bytes; st += chars;
+            }
+        }
+        return;
+    }
+#endif
+    for (uint64_t s = 0; s < n; ++s) {
+        uint32_t pos = first[2 * s], st = first[2 * s + 1];
+        for (uint64_t k = tok_offsets[s] - base, e = tok_offsets[s + 1] - base; k < e; ++k) {
+            const uint32_t p = in[k].packed, chars = KGPU_T8_CHARS(p), bytes = KGPU_T8_BYTES(p);
+            out[k] = kgpu_token{in[k].id, KGPU_T8_CLS(p), pos, st, st + chars, bytes};
+            pos += bytes; st += chars;
+        }
+    }
+}
+inline void expand_fence() {
+#if defined(__x86_64__)
+    _mm_sfence();
+#endif
+}
+constexpr uint64_t EXPAND_STREAM_MIN_TOKENS = 32768;   // from this many tokens (768 KB of records) in one chunk on: non-temporal stores
+inline bool expand_stream_wanted(uint64_t tokens) {       // (KGPU_EXPAND_STREAM=0 / 1: measurement, forces ordinary / non-temporal stores)
+    static const int mode = [] { const char *e = getenv("KGPU_EXPAND_STREAM"); return e ? atoi(e) : -1; }();
+    return mode >= 0 ? mode != 0 : tokens >= EXPAND_STREAM_MIN_TOKENS;
+}
 
 struct WorkerPool {
     std::mutex mu; std::condition_variable cv; std::deque<std::function<void()>> q; std::vector<std::thread> th;

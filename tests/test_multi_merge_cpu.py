@@ -98,3 +98,21 @@ def test_merge_throughput_eight_shards():
     r = merge_bench(8, 8192, 32, reps=10)
     print(json.dumps(r))
     assert r["sentences_per_s"] > 3e6
+
+
+@pytest.mark.parametrize("n,misalign", [(3, 0), (500, 0), (5000, 0), (5000, 4)])
+def test_expand_tokens_small_and_streamed(n, misalign):
+    """kgpu_expand_tokens (the public host-side expansion of kgpu_token8 records): below 32 768 tokens ordinary stores, above non-temporal ones (8-byte
+    aligned output only) -- the same records either way, also into an output that is only 4-byte aligned."""
+    import ctypes as C
+
+    rng = np.random.default_rng(n + misalign)
+    sh = fabricate(1, n, rng, max_tok=24, empty_rate=0.1)[0]
+    exp_tok, exp_off, _ = expected([sh], 1, n)
+    buf = np.zeros(len(exp_tok) * 24 + 64, dtype=np.uint8)
+    base = (-buf.ctypes.data) % 8 + misalign
+    out = buf[base:base + len(exp_tok) * 24]
+    L = _lib.lib()
+    first = np.ascontiguousarray(sh["first"].reshape(-1))
+    L.kgpu_expand_tokens(sh["rec"].ctypes.data, sh["toff"].ctypes.data, first.ctypes.data, n, out.ctypes.data)
+    assert np.array_equal(out.view(np.uint8), exp_tok.view(np.uint8).reshape(-1))
