@@ -108,6 +108,14 @@ def cpu_quota():
         return os.cpu_count() or 1
 
 
+def cgroup_cpu_stat():
+    """The cgroup's CPU accounting (cpu.stat: usage_usec, nr_throttled, throttled_usec ...), {} where there is none."""
+    try:
+        return {k: int(v) for k, v in (line.split() for line in open("/sys/fs/cgroup/cpu.stat"))}
+    except (OSError, ValueError):
+        return {}
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -1104,14 +1112,20 @@ def main():
 
             utf8_c, offs_c = pack_sentences(corpora[0][:20000])
             cc = {}
-            for nthr, calls in ((1, 400), (16, 300), (64, 300), (128, 200)):
+            for nthr, calls in ((1, 400), (16, 300), (64, 300), (128, 200), (128, 2000)):
                 concurrent_callers(tok, utf8_c, offs_c, nthr, 20)  # warm: contexts, pinned blocks
                 tok.routing(reset=True)
+                cs0 = cgroup_cpu_stat()
                 r = concurrent_callers(tok, utf8_c, offs_c, nthr, calls)
+                cs1 = cgroup_cpu_stat()
                 rt = tok.routing()
+                # the callers' own CPU time per call, and whether the cgroup's CPU quota throttled the process during the leg (a throttled period
+                # stops every thread for the rest of its 100 ms: that, not the device, is what a p99 of tens of milliseconds means here)
+                r["cpu_us_per_call"] = r.pop("caller_cpu_s") * 1e6 / max(r["calls"], 1)
+                r["quota_throttled_periods"] = cs1.get("nr_throttled", 0) - cs0.get("nr_throttled", 0) if cs0 else None
                 r["combined_calls"], r["combined_launches"], r["small_calls"] = rt["combined_calls"], rt["combined_launches"], rt["small_calls"]
                 r["sentences_per_launch"] = r["sentences"] / max(rt["small_calls"] - rt["combined_calls"] + rt["combined_launches"], 1)
-                cc[f"threads{nthr}"] = r
+                cc[f"threads{nthr}" + ("_sustained" if calls >= 1000 else "")] = r   # (sustained: several of the quota's 100 ms periods long)
             cc["what"] = ("kgpu_tokenize_batch with n = 1 in a loop from N native host threads over the first 20k cfg 2 sentences; closed loop, so "
                           "sentences/s = threads / mean latency (Little): calls that arrive while another thread's small launch is being assembled "
                           "join it (leader / follower, <= 15 us window, <= 128 sentences)")

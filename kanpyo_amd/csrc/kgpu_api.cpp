@@ -1269,12 +1269,19 @@ struct SmallReq {
 static std::atomic<uint64_t> g_st[8];  // launches, prep ns, launch-call ns, poll ns, hand-out ns, sentences
 static inline uint64_t now_ns() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
 extern "C" void kgpu_debug_small_trace(uint64_t out[8]) { for (int k = 0; k < 8; ++k) out[k] = g_st[k].exchange(0); }
+// ... and where the callers' CPU time goes (CLOCK_THREAD_CPUTIME_ID at the phase boundaries, ns summed over all threads): [0] calls that joined a batch,
+// [1] calls that led one, [2] entry + the combiner's lock, [3] a follower's wait, [4] the leader's window, [5] close + context, [6] assembling the launch,
+// [7] the launch call, [8] the poll, [9] handing the records out, [10] waking the followers, [11] hipSetDevice at the entry point
+static std::atomic<uint64_t> g_sc[16];
+static inline uint64_t cpu_ns() { timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
+static bool small_trace_on() { static const bool on = env_flag_now("KGPU_SMALL_TRACE"); return on; }
+extern "C" void kgpu_debug_small_cpu(uint64_t out[16]) { for (int k = 0; k < 16; ++k) out[k] = g_sc[k].exchange(0); }
 
 static unsigned cpu_budget();
 static void short_sleep_us(unsigned us);
 static int small_call(kgpu_dict *d, kgpu_ctx *c, SmallReq *const *reqs, size_t nreq) {
     static const bool trace = env_flag_now("KGPU_SMALL_TRACE");
-    const uint64_t tt0 = trace ? now_ns() : 0;
+    const uint64_t tt0 = trace ? now_ns() : 0, cc0 = trace ? cpu_ns() : 0;
     uint64_t n = 0, total = 0;
     for (size_t r = 0; r < nreq; ++r) { n += reqs[r]->n; total += reqs[r]->offsets[reqs[r]->n] - reqs[r]->offsets[0]; }
     int rc;
@@ -1316,12 +1323,12 @@ static int small_call(kgpu_dict *d, kgpu_ctx *c, SmallReq *const *reqs, size_t n
     a.fused_host = c->h_ctl_dev; a.fused_seq = seq;
     if (c->ctl_dirty) HIPCHECK(hipMemsetAsync(c->d_ctl, 0, sizeof(Control), c->stream));
     c->ctl_dirty = true;
-    const uint64_t tt1 = trace ? now_ns() : 0;
+    const uint64_t tt1 = trace ? now_ns() : 0, cc1 = trace ? cpu_ns() : 0;
     {
         hipError_t e = (hipError_t)launch_small_call(d->view, a, c->plan, c->stream);
         if (e != hipSuccess) { set_error("small-call launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     }
-    const uint64_t tt2 = trace ? now_ns() : 0;
+    const uint64_t tt2 = trace ? now_ns() : 0, cc2 = trace ? cpu_ns() : 0;
     // poll the sequence number (the kernel's last store); a stream query now and then catches a failed launch
     for (uint64_t spin = 0;; ++spin) {
         if (__atomic_load_n(&c->h_ctl->small_flag, __ATOMIC_ACQUIRE) == seq) break;
@@ -1344,8 +1351,9 @@ static int small_call(kgpu_dict *d, kgpu_ctx *c, SmallReq *const *reqs, size_t n
             else if (callers > 8) sched_yield();
         }
     }
-    const uint64_t tt3 = trace ? now_ns() : 0;
-    struct TraceOut { bool on; uint64_t t0, t1, t2, t3, n; ~TraceOut() { if (on) { const uint64_t t4 = now_ns(); g_st[0] += 1; g_st[1] += t1 - t0; g_st[2] += t2 - t1; g_st[3] += t3 - t2; g_st[4] += t4 - t3; g_st[5] += n; } } } trace_out{trace, tt0, tt1, tt2, tt3, n};
+    const uint64_t tt3 = trace ? now_ns() : 0, cc3 = trace ? cpu_ns() : 0;
+    struct TraceOut { bool on; uint64_t t0, t1, t2, t3, n, c0, c1, c2, c3; ~TraceOut() { if (on) { const uint64_t t4 = now_ns(), c4 = cpu_ns(); g_st[0] += 1; g_st[1] += t1 - t0; g_st[2] += t2 - t1; g_st[3] += t3 - t2; g_st[4] += t4 - t3; g_st[5] += n;
+        g_sc[6] += c1 - c0; g_sc[7] += c2 - c1; g_sc[8] += c3 - c2; g_sc[9] += c4 - c3; } } } trace_out{trace, tt0, tt1, tt2, tt3, n, cc0, cc1, cc2, cc3};
     c->ctl_dirty = false;  // the publishing wavefront zeroed the device block
     c->rt.batches++; c->rt.sentences += n;
     c->rt.deferred[0] += c->h_ctl->ovf_count[0]; c->rt.redone[0] += c->h_ctl->late_count[0];
@@ -1382,16 +1390,42 @@ static int small_call(kgpu_dict *d, kgpu_ctx *c, SmallReq *const *reqs, size_t n
 // arrive while another small call is being assembled join it: the first one in is the leader -- it keeps the batch open for a short
 // window (only while other callers are inside the entry point: a lone caller never waits), takes a pooled context, launches, and hands
 // every follower its own dense slice back.  Followers sleep on a condition variable meanwhile.
+// The combiner's lock: held for a push_back and two additions (tens of nanoseconds), taken by every caller -- and by a whole batch's followers at the same
+// instant, when the leader's one wake-up releases them into their next calls.  A pthread mutex puts each of them to sleep and wakes it again through the kernel:
+// measured with 128 callers, 40-48 us of (system) CPU per call in the lock alone -- more CPU than a 16-CPU cgroup quota grants, so the group spent most of each
+// 100 ms period throttled (profiles/experiments/r05_callers_cpu.txt).  Test-and-test-and-set with pause; a holder that lost its CPU is waited for with yields.
+struct SpinLock {
+    std::atomic<uint32_t> v{0};
+    void lock() {
+        // (a lost exchange backs off for twice as long, up to 32 pauses: two dozen threads that all saw the word free do not all write it again at the next release)
+        for (unsigned spins = 0, backoff = 1;;) {
+            if (v.load(std::memory_order_relaxed) == 0) {
+                if (v.exchange(1, std::memory_order_acquire) == 0) return;
+                for (unsigned k = 0; k < backoff; ++k) cpu_relax();
+                if (backoff < 32) backoff *= 2;
+            }
+            cpu_relax();
+            if (++spins >= 2048) { sched_yield(); spins = 0; }
+        }
+    }
+    void unlock() { v.store(0, std::memory_order_release); }
+    static void cpu_relax() {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+};
 struct Combiner {
     // A batch lives on the heap, shared by its leader and its followers (a follower may still be reading its own result when the leader returns).
     struct Batch {
         std::vector<SmallReq *> reqs; uint64_t n = 0, bytes = 0; bool closed = false;
         std::atomic<uint32_t> done{0};   // futex word: followers sleep on it, ONE wake-all syscall releases them (no shared condition variable: a
     };                                   // batch's completion wakes its own followers only, and nobody queues on a mutex to find out)
-    std::mutex mu;
+    // (each on a cache line of its own: every caller adds itself to `callers` on the way in and out, the lock's waiters read the lock word meanwhile)
+    alignas(64) SpinLock mu;
     std::shared_ptr<Batch> open;
-    std::atomic<int> callers{0};     // threads inside the small-call entry
-    std::atomic<int> in_flight{0};   // launches between close and completion
+    alignas(64) std::atomic<int> callers{0};     // threads inside the small-call entry
+    alignas(64) std::atomic<int> in_flight{0};   // launches between close and completion
 };
 int kgpu_dict::combiner_callers() const { return combiner ? combiner->callers.load(std::memory_order_relaxed) : 0; }
 static Combiner *combiner_new() { return new Combiner(); }
@@ -1446,23 +1480,29 @@ static int small_call_combined(kgpu_dict *d, SmallReq &me) {
     const uint64_t my_bytes = me.offsets[me.n] - me.offsets[0];
     struct CallerCount { std::atomic<int> &c; CallerCount(std::atomic<int> &c_) : c(c_) { c.fetch_add(1, std::memory_order_acq_rel); } ~CallerCount() { c.fetch_sub(1, std::memory_order_acq_rel); } } in(cb.callers);
     std::shared_ptr<Combiner::Batch> mine;
+    const bool trace = small_trace_on();
+    uint64_t k0 = trace ? cpu_ns() : 0;
     {
-        std::unique_lock<std::mutex> l(cb.mu);
+        std::unique_lock<SpinLock> l(cb.mu);
         std::shared_ptr<Combiner::Batch> b = cb.open;
         if (b && !b->closed && b->n + me.n <= SMALL_MAX_N && b->bytes + my_bytes <= SMALL_MAX_BYTES) {   // join the batch being assembled
             b->reqs.push_back(&me); b->n += me.n; b->bytes += my_bytes;
             l.unlock();
+            const uint64_t k1 = trace ? cpu_ns() : 0;
             while (b->done.load(std::memory_order_acquire) == 0) futex_wait(&b->done, 0);   // the leader has written my records and my rc before it sets the word
+            if (trace) { g_sc[0] += 1; g_sc[2] += k1 - k0; g_sc[3] += cpu_ns() - k1; }
             if (me.rc > 0 && me.err[0]) set_error("%s", me.err);
             return me.rc;
         }
         mine = std::make_shared<Combiner::Batch>();
+        mine->reqs.reserve(SMALL_MAX_N);   // (no reallocation under the lock later)
         mine->reqs.push_back(&me); mine->n = me.n; mine->bytes = my_bytes;
         cb.open = mine;   // (a batch another leader still holds open but that has no room for me stays its leader's: it closes it itself)
     }
     // Leader.  A lone caller launches at once.  With other callers inside the entry point the batch stays open for a short window -- and, when
     // the device already has its fill of small launches in flight, until one of them completes (or the batch is full): the batch size follows the
     // load (group commit), the number of launches per second stays what the streams carry.  Spinning: the waits are shorter than a futex sleep.
+    if (trace) { const uint64_t k1 = cpu_ns(); g_sc[1] += 1; g_sc[2] += k1 - k0; k0 = k1; }
     const unsigned win = combine_window_us();
     if (win && cb.callers.load(std::memory_order_acquire) > 1) {
         timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -1477,19 +1517,21 @@ static int small_call_combined(kgpu_dict *d, SmallReq &me) {
             const long long us = (t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000;
             const bool busy = cb.in_flight.load(std::memory_order_acquire) >= combine_max_in_flight();
             if ((us >= (long long)win && !busy) || us >= 400) break;   // (a four times longer window when callers exceed CPUs: measured, 64 threads 358 -> 301 k sentences/s, 128 unchanged)
-            std::lock_guard<std::mutex> g(cb.mu);
+            std::lock_guard<SpinLock> g(cb.mu);
             if (mine->n >= SMALL_MAX_N || mine->bytes + 256 > SMALL_MAX_BYTES) break;  // full
             if (!busy && (int)mine->reqs.size() >= cb.callers.load(std::memory_order_acquire)) break;  // everyone who is here is in
         }
     }
+    if (trace) { const uint64_t k1 = cpu_ns(); g_sc[4] += k1 - k0; k0 = k1; }
     {
-        std::lock_guard<std::mutex> g(cb.mu);
+        std::lock_guard<SpinLock> g(cb.mu);
         mine->closed = true;
         if (cb.open == mine) cb.open.reset();
     }
     cb.in_flight.fetch_add(1, std::memory_order_acq_rel);
     kgpu_ctx *c = nullptr;
     int rc = pool_get(d, &c);
+    if (trace) { const uint64_t k1 = cpu_ns(); g_sc[5] += k1 - k0; k0 = k1; }
     if (!rc) {
         rc = c->plan.n_pools ? small_call(d, c, mine->reqs.data(), mine->reqs.size()) : KGPU_OK;
         pool_put(d, c);
@@ -1498,8 +1540,10 @@ static int small_call_combined(kgpu_dict *d, SmallReq &me) {
     const int my_rc = rc ? rc : me.rc;
     if (rc) for (SmallReq *q : mine->reqs) { q->rc = rc; snprintf(q->err, sizeof q->err, "%s", kgpu_last_error()); }
     const bool had_followers = mine->reqs.size() > 1;
+    if (trace) k0 = cpu_ns();
     mine->done.store(1, std::memory_order_release);   // (followers may return -- and their SmallReq die -- from here on: nothing of theirs is touched below)
     if (had_followers) futex_wake_all(&mine->done);
+    if (trace) g_sc[10] += cpu_ns() - k0;
     if (my_rc > 0 && !rc && me.err[0]) set_error("%s", me.err);
     return my_rc;
 }
@@ -1571,7 +1615,9 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
     for (uint64_t i = 0; i < n; ++i)
         if (offsets[i + 1] < offsets[i]) { set_error("kgpu_tokenize_batch: offsets not monotone at %llu", (unsigned long long)i); return KGPU_ERR_INVALID_ARG; }
     if (offsets[n] - offsets[0] && !utf8) { set_error("kgpu_tokenize_batch: null utf8"); return KGPU_ERR_INVALID_ARG; }
+    const uint64_t kd0 = small_trace_on() ? cpu_ns() : 0;
     HIPCHECK(hipSetDevice(d->device));
+    if (kd0) g_sc[11] += cpu_ns() - kd0;   // (KGPU_SMALL_TRACE: the CPU time of hipSetDevice)
 
     if (n >= 1 && n <= SMALL_MAX_N && offsets[n] - offsets[0] <= SMALL_MAX_BYTES && !test_hooks().no_small_calls) {
         SmallReq me{utf8, offsets, n, tokens, token_capacity, tok_offsets, status, n_tokens};
@@ -1758,11 +1804,13 @@ extern "C" int kgpu_debug_concurrent_callers(kgpu_dict *d, const uint8_t *utf8, 
                                              const int *n_pattern, int n_pat, const kgpu_token *expect_tokens, const uint64_t *expect_offsets, double *stats) {
     if (!d || !offsets || !n_sentences || threads < 1 || threads > 1024 || calls_per_thread < 1 || !n_pattern || n_pat < 1 || !stats) { set_error("kgpu_debug_concurrent_callers: bad argument"); return KGPU_ERR_INVALID_ARG; }
     std::vector<std::vector<float>> lat((size_t)threads);
-    std::vector<uint64_t> bad((size_t)threads, 0), sent((size_t)threads, 0);
+    std::vector<uint64_t> bad((size_t)threads, 0), sent((size_t)threads, 0), cpu((size_t)threads, 0);   // cpu: the thread's own CPU time over its calls (ns)
     std::vector<int> rcs((size_t)threads, KGPU_OK);
     std::vector<std::string> errs((size_t)threads);
+    // The start gate sleeps (a futex word), it does not spin: a hundred threads yielding in a loop while the rest are created burn, each on its own CPU of the
+    // host, a good part of a 16-CPU cgroup quota's 100 ms period before the first call is made -- and the period's remainder is then spent throttled.
     std::atomic<int> ready{0};
-    std::atomic<bool> go{false};
+    std::atomic<uint32_t> go{0};
     auto now_us = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; };
     auto body = [&](int t) {
         const uint64_t npc = (uint64_t)std::max(1, n_pattern[t % n_pat]);
@@ -1774,7 +1822,9 @@ extern "C" int kgpu_debug_concurrent_callers(kgpu_dict *d, const uint8_t *utf8, 
         lat[(size_t)t].reserve((size_t)calls_per_thread);
         uint64_t at = ((uint64_t)t * 7919u) % n_sentences;
         ready.fetch_add(1);
-        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+        while (go.load(std::memory_order_acquire) == 0) futex_wait(&go, 0);
+        const uint64_t c0 = cpu_ns();
+        struct CpuOut { uint64_t &out, c0; ~CpuOut() { out = cpu_ns() - c0; } } cpu_out{cpu[(size_t)t], c0};
         for (int k = 0; k < calls_per_thread; ++k) {
             if (at + npc > n_sentences) at = 0;
             const uint64_t m = std::min(npc, n_sentences - at);
@@ -1795,10 +1845,11 @@ extern "C" int kgpu_debug_concurrent_callers(kgpu_dict *d, const uint8_t *utf8, 
     };
     std::vector<std::thread> th;
     try { for (int t = 0; t < threads; ++t) th.emplace_back(body, t); }
-    catch (...) { go.store(true); for (auto &x : th) x.join(); set_error("kgpu_debug_concurrent_callers: could not start %d threads", threads); return KGPU_ERR_INTERNAL; }
-    while (ready.load() < threads) std::this_thread::yield();
+    catch (...) { go.store(2); futex_wake_all(&go); for (auto &x : th) x.join(); set_error("kgpu_debug_concurrent_callers: could not start %d threads", threads); return KGPU_ERR_INTERNAL; }
+    while (ready.load() < threads) short_sleep_us(50);
     const double t0 = now_us();
-    go.store(true, std::memory_order_release);
+    go.store(1, std::memory_order_release);
+    futex_wake_all(&go);
     for (auto &x : th) x.join();
     const double wall = (now_us() - t0) * 1e-6;
     for (int t = 0; t < threads; ++t) if (rcs[(size_t)t]) { set_error("%s", errs[(size_t)t].c_str()); return rcs[(size_t)t]; }
@@ -1809,5 +1860,6 @@ extern "C" int kgpu_debug_concurrent_callers(kgpu_dict *d, const uint8_t *utf8, 
     double mean = 0; for (float x : all) mean += x;
     stats[0] = wall; stats[1] = all[all.size() / 2]; stats[2] = all[(size_t)((double)all.size() * 0.99)]; stats[3] = mean / (double)all.size();
     stats[4] = (double)nbad; stats[5] = (double)all.size(); stats[6] = (double)nsent;
+    { uint64_t c = 0; for (uint64_t x : cpu) c += x; stats[7] = (double)c * 1e-9; }   // CPU seconds of the calling threads, start gate and thread start-up left out
     return KGPU_OK;
 }

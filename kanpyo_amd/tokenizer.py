@@ -210,7 +210,7 @@ def concurrent_callers(tok: Tokenizer, utf8: np.ndarray, offsets: np.ndarray, th
                  et.ctypes.data if et is not None else None, eo.ctypes.data if eo is not None else None, stats.ctypes.data))
     return {"wall_s": float(stats[0]), "p50_us": float(stats[1]), "p99_us": float(stats[2]), "mean_us": float(stats[3]), "mismatching_calls": int(stats[4]),
             "calls": int(stats[5]), "sentences": int(stats[6]), "sentences_per_s": float(stats[6] / stats[0]) if stats[0] > 0 else 0.0,
-            "threads": int(threads), "n_pattern": [int(x) for x in pat]}
+            "threads": int(threads), "n_pattern": [int(x) for x in pat], "caller_cpu_s": float(stats[7])}
 
 
 TOKEN8_DTYPE = np.dtype([("id", "<i4"), ("packed", "<u4")])  # kgpu_token8
