@@ -81,7 +81,8 @@ def test_native_threads_share_launches_and_stay_bit_exact(env):
     np.random.default_rng(3).shuffle(sents)
     utf8, offs = pack_sentences(sents)
     exp = orc.tokenize_batch(utf8, offs, 8)
-    for threads, pattern, calls in ((32, (1, 1, 1, 2, 5, 1, 17, 1, 64, 1, 130, 1), 60), (64, (1,), 100), (8, (128, 1), 40)):
+    # (128 x n = 1: a batch's two dozen followers are released by one wake-up and reach the combiner's lock together)
+    for threads, pattern, calls in ((32, (1, 1, 1, 2, 5, 1, 17, 1, 64, 1, 130, 1), 60), (64, (1,), 100), (8, (128, 1), 40), (128, (1,), 60), (96, (1, 2, 1, 3), 40)):
         tok.routing(reset=True)
         r = concurrent_callers(tok, utf8, offs, threads, calls, pattern, expect=(exp.tokens, exp.offsets))
         assert r["mismatching_calls"] == 0 and r["calls"] == threads * calls, r
