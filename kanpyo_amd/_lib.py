@@ -37,7 +37,7 @@ def kernel_source_hash() -> str:
 
     h = hashlib.sha256()
     for name in ("kgpu_pool.hip", "kgpu_kernels.hip", "kgpu_window.hip", "kgpu_device.h", "kgpu_internal.h", "kgpu_chartrie.cpp",
-                 "kgpu_api.cpp", "kgpu_multi.cpp", "kgpu_runtime.h", "kgpu_lock.h", "kgpu_index_build.cpp", "../../include/kanpyo_gpu.h"):
+                 "kgpu_api.cpp", "kgpu_multi.cpp", "kgpu_runtime.h", "kgpu_index_build.cpp", "../../include/kanpyo_gpu.h"):
         with open(os.path.join(_HERE, "csrc", name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

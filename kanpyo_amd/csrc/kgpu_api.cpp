@@ -33,7 +33,6 @@
 #include <vector>
 
 #include "kgpu_runtime.h"
-#include "kgpu_lock.h"
 
 namespace kgpu {
 
@@ -1391,7 +1390,31 @@ static int small_call(kgpu_dict *d, kgpu_ctx *c, SmallReq *const *reqs, size_t n
 // arrive while another small call is being assembled join it: the first one in is the leader -- it keeps the batch open for a short
 // window (only while other callers are inside the entry point: a lone caller never waits), takes a pooled context, launches, and hands
 // every follower its own dense slice back.  Followers sleep on a condition variable meanwhile.
-// (the combiner's lock: kgpu_lock.h)
+// The combiner's lock: held for a push_back and two additions (tens of nanoseconds), taken by every caller -- and by a whole batch's followers at the same
+// instant, when the leader's one wake-up releases them into their next calls.  A pthread mutex puts each of them to sleep and wakes it again through the kernel:
+// measured with 128 callers, 40-48 us of (system) CPU per call in the lock alone -- more CPU than a 16-CPU cgroup quota grants, so the group spent most of each
+// 100 ms period throttled (profiles/experiments/r05_callers_cpu.txt).  Test-and-test-and-set with pause; a holder that lost its CPU is waited for with yields.
+struct SpinLock {
+    std::atomic<uint32_t> v{0};
+    void lock() {
+        // (a lost exchange backs off for twice as long, up to 32 pauses: two dozen threads that all saw the word free do not all write it again at the next release)
+        for (unsigned spins = 0, backoff = 1;;) {
+            if (v.load(std::memory_order_relaxed) == 0) {
+                if (v.exchange(1, std::memory_order_acquire) == 0) return;
+                for (unsigned k = 0; k < backoff; ++k) cpu_relax();
+                if (backoff < 32) backoff *= 2;
+            }
+            cpu_relax();
+            if (++spins >= 2048) { sched_yield(); spins = 0; }
+        }
+    }
+    void unlock() { v.store(0, std::memory_order_release); }
+    static void cpu_relax() {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+};
 struct Combiner {
     // A batch lives on the heap, shared by its leader and its followers (a follower may still be reading its own result when the leader returns).
     struct Batch {
@@ -1399,7 +1422,7 @@ struct Combiner {
         std::atomic<uint32_t> done{0};   // futex word: followers sleep on it, ONE wake-all syscall releases them (no shared condition variable: a
     };                                   // batch's completion wakes its own followers only, and nobody queues on a mutex to find out)
     // (each on a cache line of its own: every caller adds itself to `callers` on the way in and out, the lock's waiters read the lock word meanwhile)
-    alignas(64) kgpu::SpinThenParkLock mu;
+    alignas(64) SpinLock mu;
     std::shared_ptr<Batch> open;
     alignas(64) std::atomic<int> callers{0};     // threads inside the small-call entry
     alignas(64) std::atomic<int> in_flight{0};   // launches between close and completion
@@ -1460,7 +1483,7 @@ static int small_call_combined(kgpu_dict *d, SmallReq &me) {
     const bool trace = small_trace_on();
     uint64_t k0 = trace ? cpu_ns() : 0;
     {
-        std::unique_lock<kgpu::SpinThenParkLock> l(cb.mu);
+        std::unique_lock<SpinLock> l(cb.mu);
         std::shared_ptr<Combiner::Batch> b = cb.open;
         if (b && !b->closed && b->n + me.n <= SMALL_MAX_N && b->bytes + my_bytes <= SMALL_MAX_BYTES) {   // join the batch being assembled
             b->reqs.push_back(&me); b->n += me.n; b->bytes += my_bytes;
@@ -1494,14 +1517,14 @@ static int small_call_combined(kgpu_dict *d, SmallReq &me) {
             const long long us = (t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000;
             const bool busy = cb.in_flight.load(std::memory_order_acquire) >= combine_max_in_flight();
             if ((us >= (long long)win && !busy) || us >= 400) break;   // (a four times longer window when callers exceed CPUs: measured, 64 threads 358 -> 301 k sentences/s, 128 unchanged)
-            std::lock_guard<kgpu::SpinThenParkLock> g(cb.mu);
+            std::lock_guard<SpinLock> g(cb.mu);
             if (mine->n >= SMALL_MAX_N || mine->bytes + 256 > SMALL_MAX_BYTES) break;  // full
             if (!busy && (int)mine->reqs.size() >= cb.callers.load(std::memory_order_acquire)) break;  // everyone who is here is in
         }
     }
     if (trace) { const uint64_t k1 = cpu_ns(); g_sc[4] += k1 - k0; k0 = k1; }
     {
-        std::lock_guard<kgpu::SpinThenParkLock> g(cb.mu);
+        std::lock_guard<SpinLock> g(cb.mu);
         mine->closed = true;
         if (cb.open == mine) cb.open.reset();
     }
