@@ -152,7 +152,7 @@ def test_bench_single_process_path_on_one_gpu():
                         "--prewarm-seconds", "0.05", "--corpora", "1", "--queue", "4"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().split("\n")[-1])
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "config", "sentences_total", "gather", "per_rank", "corpora"):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "config", "sentences_total", "gather", "per_rank_sentences_per_s", "full_report"):
         assert k in line, k
     assert line["n_gpus"] == 2 and line["sentences_total"] == 200_000 and line["gather"]["reassembled_step_equals_one_gpu"] is True
     assert line["value"] > 1e6
