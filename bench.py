@@ -203,11 +203,11 @@ def main():
     # ---- workload
     if world == 1:
         corpora = [synth.make_corpus(sd, N_SENT, seed=1, kind="cfg2")]
-        label = "BASELINE configs[1] (cfg 2): 100k synthetic ~40-char sentences (seed 1), IPADIC-shaped 392k-record dictionary, batch 4096"
+        label = "BASELINE configs[1] (cfg 2): 100k synthetic ~40-char sentences, batch 4096, IPADIC-shaped 392k-record dictionary"
     else:
         ncorp = max(1, min(args.corpora if args.corpora > 0 else 100, 100, max(K, 1)))  # distinct seeds for every timed step (SURVEY 8d cfg 4)
         corpora = [synth.make_corpus(sd, N_SENT, seed=100 + k, kind="cfg2") for k in range(ncorp)]
-        label = f"BASELINE configs[3] (cfg 4): 100k-sentence corpora seeds 100..{99 + ncorp}, sentence i -> GPU i mod {world}, records gathered to rank 0"
+        label = f"BASELINE configs[3] (cfg 4): 100k-sentence corpora seeds 100..{99 + ncorp}, sentence i -> GPU i mod {world}, gathered to rank 0"
     wl = Workload(corpora, rank if world > 1 else 0, world)
     tok = Tokenizer(sd.dict, device=local_rank)
     cs = chunk_steps_for(wl.nb(0))
