@@ -235,6 +235,14 @@ int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint64_t *offse
  * the single-device call redoes that chunk with 24-byte records.  The caller's current HIP device is restored before the call returns. */
 int kgpu_tokenize_batch_multi(kgpu_dict *const *dicts, int n_dicts, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
                               kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets, uint8_t *status, uint64_t *n_tokens);
+/* ... with the records left as the devices produce them (round 6): `tokens8` receives the 8-byte kgpu_token8 records and first[2 i], first[2 i + 1] the
+ * (position, start) of sentence i's first token, both in the caller's ORIGINAL sentence order; kgpu_expand_tokens(tokens8 + tok_offsets[a], tok_offsets + a,
+ * first + 2 a, b - a, out) restores the 24-byte kgpu_token records of sentences [a, b) wherever and whenever the caller consumes them (or never: id, class,
+ * lengths are all in the 8-byte record).  The 24-byte form's expansion writes ~1 KB of host memory per 40-character sentence on the calling side and binds
+ * at about two devices' worth of records on 16 host CPUs; this form's merge moves a third of that (reference src/token.rs:10-18: a Token is id, class and
+ * three positions -- the positions are running sums of the lengths).  Same sharding, same status bytes, same errors, same EXPERIMENTAL note. */
+int kgpu_tokenize_batch_multi_compact(kgpu_dict *const *dicts, int n_dicts, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
+                                      kgpu_token8 *tokens8, uint64_t token_capacity, uint32_t *first, uint64_t *tok_offsets, uint8_t *status, uint64_t *n_tokens);
 
 /* Device-resident multi-device step with the result gather (the "trivial result gather over xGMI"): shard g -- n[g] sentences, packed
  * as kgpu_tokenize_device wants them -- is resident on dicts[g]'s device; its compaction kernel stores the 8-byte records (and the

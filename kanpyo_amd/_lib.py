@@ -25,7 +25,7 @@ SYMBOLS = [
     "kgpu_tokenize_batch", "kgpu_ctx_create", "kgpu_ctx_destroy", "kgpu_tokenize_device", "kgpu_tokenize_device_compact", "kgpu_expand_tokens", "kgpu_ctx_sync",
     "kgpu_ctx_set_profiling", "kgpu_ctx_set_ablation", "kgpu_ctx_get_profile", "kgpu_ctx_get_routing", "kgpu_ctx_get_plan", "kgpu_ctx_get_work", "kgpu_ctx_get_phase_cycles", "kgpu_index_build", "kgpu_free",
     "kgpu_host_alloc", "kgpu_host_free", "kgpu_lattice_dump", "kgpu_lattice_free",
-    "kgpu_dict_get_routing", "kgpu_tokenize_batch_multi", "kgpu_multi_create", "kgpu_multi_destroy", "kgpu_multi_tokenize_device", "kgpu_multi_sync",
+    "kgpu_dict_get_routing", "kgpu_tokenize_batch_multi", "kgpu_tokenize_batch_multi_compact", "kgpu_multi_create", "kgpu_multi_destroy", "kgpu_multi_tokenize_device", "kgpu_multi_sync",
 ]
 
 
@@ -153,6 +153,7 @@ def lib():
         L.kgpu_lattice_free.argtypes = [C.POINTER(LatticeOut)]
         L.kgpu_lattice_free.restype = None
         L.kgpu_tokenize_batch_multi.argtypes = [C.POINTER(vp), C.c_int, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, C.POINTER(C.c_uint64)]
+        L.kgpu_tokenize_batch_multi_compact.argtypes = [C.POINTER(vp), C.c_int, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, C.POINTER(C.c_uint64)]
         L.kgpu_multi_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp)]
         L.kgpu_multi_destroy.argtypes = [vp]
         L.kgpu_multi_destroy.restype = None

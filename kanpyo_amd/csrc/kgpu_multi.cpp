@@ -43,9 +43,12 @@ void merge_plan(const MergeSrc *src, int G, uint64_t cnt, uint64_t slice, std::v
     slice_base[(size_t)nt] = run;
 }
 
-// sentences [a, b) of the super-chunk: tok_offsets[j] (already pointing at the super-chunk's first entry), the 24-byte records (tokens = the caller's
-// whole array, or nullptr: offsets and status only), status bytes.  base = tokens in front of sentence a, in the caller's numbering.
-void merge_slice(const MergeSrc *src, int G, uint64_t a, uint64_t b, uint64_t base, kgpu_token *tokens, uint64_t *tok_offsets, uint8_t *status, bool stream) {
+// sentences [a, b) of the super-chunk: tok_offsets[j] (already pointing at the super-chunk's first entry), the records, status bytes.  base = tokens in
+// front of sentence a, in the caller's numbering.  Records: 24-byte kgpu_token into `tokens` (the caller's whole array), or -- the compact form,
+// kgpu_tokenize_batch_multi_compact -- the shards' 8-byte records as they are into `out8` plus every sentence's (position, start) of its first token into
+// `first_out` (pointing at the super-chunk's first sentence, like tok_offsets); both null: offsets and status only.
+void merge_slice(const MergeSrc *src, int G, uint64_t a, uint64_t b, uint64_t base, kgpu_token *tokens, uint64_t *tok_offsets, uint8_t *status, bool stream,
+                 kgpu_token8 *out8 = nullptr, uint32_t *first_out = nullptr) {
     const uint64_t Gu = (uint64_t)G;
     uint64_t g = a % Gu, k = a / Gu, run = base;
     for (uint64_t j = a; j < b; ++j) {
@@ -53,11 +56,15 @@ void merge_slice(const MergeSrc *src, int G, uint64_t a, uint64_t b, uint64_t ba
         const uint64_t t0 = sx.toff[k], t1 = sx.toff[k + 1];
         tok_offsets[j] = run;
         if (tokens) expand_tokens(sx.rec + t0, sx.toff + k, sx.first + 2 * k, 1, tokens + run, stream);   // (one sentence: the records of shard g's local sentence k)
+        if (out8) {
+            if (t1 > t0) std::memcpy(out8 + run, sx.rec + t0, (size_t)(t1 - t0) * sizeof(kgpu_token8));
+            first_out[2 * j] = sx.first[2 * k]; first_out[2 * j + 1] = sx.first[2 * k + 1];
+        }
         if (status) status[j] = sx.st[k];
         run += t1 - t0;
         if (++g == Gu) { g = 0; ++k; }
     }
-    if (stream) expand_fence();
+    if (stream && tokens) expand_fence();
 }
 
 // The caller's current device, restored on every exit path: the multi-device entry points visit every device on the calling thread.
@@ -196,12 +203,17 @@ void device_thread(MultiCall *pmc, int g) {
 
 }  // namespace
 
-extern "C" int kgpu_tokenize_batch_multi(kgpu_dict *const *dicts, int n_dicts, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
-                                         kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets, uint8_t *status, uint64_t *n_tokens) {
-    if (!dicts || n_dicts < 1 || n_dicts > 64 || !offsets || !tok_offsets || (token_capacity && !tokens)) { set_error("kgpu_tokenize_batch_multi: bad argument"); return KGPU_ERR_INVALID_ARG; }
+// Both host-buffer forms: tokens (24-byte records) or tokens8 + first (the compact form), never both.
+static int multi_impl(kgpu_dict *const *dicts, int n_dicts, const uint8_t *utf8, const uint64_t *offsets, uint64_t n, kgpu_token *tokens, kgpu_token8 *tokens8,
+                      uint32_t *first, uint64_t token_capacity, uint64_t *tok_offsets, uint8_t *status, uint64_t *n_tokens) {
+    const bool compact = tokens8 != nullptr || first != nullptr;
+    if (!dicts || n_dicts < 1 || n_dicts > 64 || !offsets || !tok_offsets || (token_capacity && !tokens && !tokens8) || (compact && n && !first)) {
+        set_error("kgpu_tokenize_batch_multi: bad argument");
+        return KGPU_ERR_INVALID_ARG;
+    }
     for (int g = 0; g < n_dicts; ++g) if (!dicts[g]) { set_error("kgpu_tokenize_batch_multi: null dictionary handle %d", g); return KGPU_ERR_INVALID_ARG; }
-    if (n_dicts == 1) return kgpu_tokenize_batch(dicts[0], utf8, offsets, n, tokens, token_capacity, tok_offsets, status, n_tokens);
-    DeviceGuard keep_callers_device;
+    DeviceGuard keep_callers_device;   // (above every path that touches a device: the one-dictionary shortcut included)
+    if (n_dicts == 1 && !compact) return kgpu_tokenize_batch(dicts[0], utf8, offsets, n, tokens, token_capacity, tok_offsets, status, n_tokens);
     for (uint64_t i = 0; i < n; ++i)
         if (offsets[i + 1] < offsets[i]) { set_error("kgpu_tokenize_batch_multi: offsets not monotone at %llu", (unsigned long long)i); return KGPU_ERR_INVALID_ARG; }
     if (offsets[n] - offsets[0] && !utf8) { set_error("kgpu_tokenize_batch_multi: null utf8"); return KGPU_ERR_INVALID_ARG; }
@@ -269,7 +281,7 @@ extern "C" int kgpu_tokenize_batch_multi(kgpu_dict *const *dicts, int n_dicts, c
             const uint64_t a = (uint64_t)t * SLICE, b = std::min(cnt, a + SLICE), base = base0 + slice_base[(size_t)t];
             std::atomic<int> *st_ = &mc.slot_tasks[slot], *out_ = &outstanding;
             workers().submit([=] {
-                if (!ovf) merge_slice(src.data(), G, a, b, base, tokens, tok_offsets + lo, status ? status + lo : nullptr, expand_stream_wanted(chunk_tokens));
+                if (!ovf) merge_slice(src.data(), G, a, b, base, tokens, tok_offsets + lo, status ? status + lo : nullptr, expand_stream_wanted(chunk_tokens), tokens8, first ? first + 2 * lo : nullptr);
                 else if (status) { uint64_t g = a % (uint64_t)G, k = a / (uint64_t)G; for (uint64_t jx = a; jx < b; ++jx) { status[lo + jx] = src[(size_t)g].st[k]; if (++g == (uint64_t)G) { g = 0; ++k; } } }
                 workers().task_done(*st_);
                 workers().task_done(*out_);
@@ -295,6 +307,23 @@ extern "C" int kgpu_tokenize_batch_multi(kgpu_dict *const *dicts, int n_dicts, c
     if (n_tokens) *n_tokens = tok_done;
     if (overflow) { set_error("token buffer too small: need %llu, capacity %llu", (unsigned long long)tok_done, (unsigned long long)token_capacity); return KGPU_ERR_CAPACITY; }
     return KGPU_OK;
+}
+
+extern "C" int kgpu_tokenize_batch_multi(kgpu_dict *const *dicts, int n_dicts, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
+                                         kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets, uint8_t *status, uint64_t *n_tokens) {
+    if (token_capacity && !tokens) { set_error("kgpu_tokenize_batch_multi: bad argument"); return KGPU_ERR_INVALID_ARG; }
+    return multi_impl(dicts, n_dicts, utf8, offsets, n, tokens, nullptr, nullptr, token_capacity, tok_offsets, status, n_tokens);
+}
+
+// The same call with the records left as the devices produce them: 8-byte kgpu_token8 + the first token's (position, start) per sentence, in the caller's
+// order.  The 24-byte expansion (kgpu_expand_tokens) writes ~1 KB of host memory per cfg 2 sentence and binds the 24-byte form at about two devices' worth
+// of records on 16 CPUs; here the merge moves a third of that and the expansion is the caller's choice (per consumer thread, per sentence, or never).
+extern "C" int kgpu_tokenize_batch_multi_compact(kgpu_dict *const *dicts, int n_dicts, const uint8_t *utf8, const uint64_t *offsets, uint64_t n,
+                                                 kgpu_token8 *tokens8, uint64_t token_capacity, uint32_t *first, uint64_t *tok_offsets, uint8_t *status, uint64_t *n_tokens) {
+    if (!first && n) { set_error("kgpu_tokenize_batch_multi_compact: bad argument"); return KGPU_ERR_INVALID_ARG; }
+    if (token_capacity && !tokens8) { set_error("kgpu_tokenize_batch_multi_compact: bad argument"); return KGPU_ERR_INVALID_ARG; }
+    static uint32_t none[2];
+    return multi_impl(dicts, n_dicts, utf8, offsets, n, nullptr, tokens8, first ? first : none, token_capacity, tok_offsets, status, n_tokens);
 }
 
 // ------------------------------------------------------------------------------------------------ device-resident form
@@ -380,10 +409,10 @@ extern "C" int kgpu_multi_sync(kgpu_multi *m, int slot, uint64_t *n_tokens) {
 // The merge of kgpu_tokenize_batch_multi over ONE super-chunk given as G shard blocks in host memory (what the shards' compaction kernels leave in
 // their mapped result blocks), through the same plan + worker-pool tasks: tests/test_multi_merge_cpu.py checks it against a plain loop and times it
 // (reps > 1: the same merge repeated, seconds = wall time of all repetitions).  Needs no GPU.
-extern "C" int kgpu_debug_merge_shards(int G, uint64_t cnt, const kgpu_token8 *const *rec, const uint32_t *const *first, const uint64_t *const *toff,
-                                       const uint8_t *const *st, uint64_t slice, int reps, kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets,
-                                       uint8_t *status, uint64_t *n_tokens, double *seconds) {
-    if (G < 1 || G > 64 || !rec || !first || !toff || !st || !tok_offsets || slice == 0 || reps < 1) { set_error("kgpu_debug_merge_shards: bad argument"); return KGPU_ERR_INVALID_ARG; }
+static int debug_merge(int G, uint64_t cnt, const kgpu_token8 *const *rec, const uint32_t *const *first, const uint64_t *const *toff,
+                       const uint8_t *const *st, uint64_t slice, int reps, kgpu_token *tokens, kgpu_token8 *tokens8, uint32_t *first_out, uint64_t token_capacity,
+                       uint64_t *tok_offsets, uint8_t *status, uint64_t *n_tokens, double *seconds) {
+    if (G < 1 || G > 64 || !rec || !first || !toff || !st || !tok_offsets || slice == 0 || reps < 1 || (tokens8 && !first_out)) { set_error("kgpu_debug_merge_shards: bad argument"); return KGPU_ERR_INVALID_ARG; }
     if (workers().start() == 0) { set_error("kgpu_debug_merge_shards: no worker threads"); return KGPU_ERR_INTERNAL; }
     std::vector<MergeSrc> src((size_t)G);
     for (int g = 0; g < G; ++g) src[(size_t)g] = MergeSrc{rec[g], first[g], toff[g], st[g]};
@@ -394,7 +423,7 @@ extern "C" int kgpu_debug_merge_shards(int G, uint64_t cnt, const kgpu_token8 *c
         merge_plan(src.data(), G, cnt, slice, slice_base);
         const int nt = (int)(slice_base.size() - 1);
         total = slice_base[(size_t)nt];
-        const bool fits = tokens && total <= token_capacity;
+        const bool fits = (tokens || tokens8) && total <= token_capacity;
         const bool stream = expand_stream_wanted(total);
         tok_offsets[cnt] = total;
         std::atomic<int> left{nt};
@@ -402,12 +431,24 @@ extern "C" int kgpu_debug_merge_shards(int G, uint64_t cnt, const kgpu_token8 *c
         for (int t = 0; t < nt; ++t) {
             const uint64_t a = (uint64_t)t * slice, b = std::min(cnt, a + slice), base = slice_base[(size_t)t];
             std::atomic<int> *l = &left;
-            workers().submit([=] { merge_slice(sp, G, a, b, base, fits ? tokens : nullptr, tok_offsets, status, stream); workers().task_done(*l); });
+            workers().submit([=] { merge_slice(sp, G, a, b, base, fits ? tokens : nullptr, tok_offsets, status, stream, fits ? tokens8 : nullptr, first_out); workers().task_done(*l); });
         }
         workers().wait_zero(left);
     }
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (n_tokens) *n_tokens = total;
-    if (tokens && total > token_capacity) { set_error("token buffer too small: need %llu, capacity %llu", (unsigned long long)total, (unsigned long long)token_capacity); return KGPU_ERR_CAPACITY; }
+    if ((tokens || tokens8) && total > token_capacity) { set_error("token buffer too small: need %llu, capacity %llu", (unsigned long long)total, (unsigned long long)token_capacity); return KGPU_ERR_CAPACITY; }
     return KGPU_OK;
+}
+extern "C" int kgpu_debug_merge_shards(int G, uint64_t cnt, const kgpu_token8 *const *rec, const uint32_t *const *first, const uint64_t *const *toff,
+                                       const uint8_t *const *st, uint64_t slice, int reps, kgpu_token *tokens, uint64_t token_capacity, uint64_t *tok_offsets,
+                                       uint8_t *status, uint64_t *n_tokens, double *seconds) {
+    return debug_merge(G, cnt, rec, first, toff, st, slice, reps, tokens, nullptr, nullptr, token_capacity, tok_offsets, status, n_tokens, seconds);
+}
+// ... with the compact form's output (kgpu_tokenize_batch_multi_compact's merge)
+extern "C" int kgpu_debug_merge_shards_compact(int G, uint64_t cnt, const kgpu_token8 *const *rec, const uint32_t *const *first, const uint64_t *const *toff,
+                                               const uint8_t *const *st, uint64_t slice, int reps, kgpu_token8 *tokens8, uint32_t *first_out, uint64_t token_capacity,
+                                               uint64_t *tok_offsets, uint8_t *status, uint64_t *n_tokens, double *seconds) {
+    if (!first_out) { set_error("kgpu_debug_merge_shards_compact: bad argument"); return KGPU_ERR_INVALID_ARG; }
+    return debug_merge(G, cnt, rec, first, toff, st, slice, reps, nullptr, tokens8, first_out, token_capacity, tok_offsets, status, n_tokens, seconds);
 }

@@ -158,10 +158,12 @@ class Tokenizer:
         return self.tokenize_batch([input])[0]
 
 
-def tokenize_packed_multi(tokenizers: Sequence[Tokenizer], utf8: np.ndarray, offsets: np.ndarray, token_capacity: int | None = None, out=None):
+def tokenize_packed_multi(tokenizers: Sequence[Tokenizer], utf8: np.ndarray, offsets: np.ndarray, token_capacity: int | None = None, out=None, compact: bool = False):
     """kgpu_tokenize_batch_multi: sentence i -> tokenizers[i mod G] (one Tokenizer per device; the same one may appear more than once), results in
     the caller's original order -- byte for byte what Tokenizer.tokenize_packed gives on one device.
-    -> (tokens[TOKEN_DTYPE], tok_offsets[uint64 n+1], status[uint8 n])."""
+    -> (tokens[TOKEN_DTYPE], tok_offsets[uint64 n+1], status[uint8 n]).
+    compact=True: kgpu_tokenize_batch_multi_compact -> (tokens8[TOKEN8_DTYPE], first[uint32 n x 2], tok_offsets, status); kanpyo_amd.device.expand_tokens
+    (kgpu_expand_tokens) restores the 24-byte records where they are consumed."""
     utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = offsets.size - 1
@@ -171,23 +173,30 @@ def tokenize_packed_multi(tokenizers: Sequence[Tokenizer], utf8: np.ndarray, off
     cap = int(token_capacity) if token_capacity is not None else total // 2 + n + 64
     L = _lib.lib()
     handles = (C.c_void_p * len(tokenizers))(*[t.handle for t in tokenizers])
+    first = np.zeros((max(n, 1), 2), dtype=np.uint32) if compact else None
     while True:
         if out is not None:
             tokens, toff, status = out
             cap = tokens.size
             token_capacity = cap
         else:
-            tokens = np.empty(cap, dtype=TOKEN_DTYPE)
+            tokens = np.empty(cap, dtype=TOKEN8_DTYPE if compact else TOKEN_DTYPE)
             toff = np.empty(n + 1, dtype=np.uint64)
             status = np.empty(max(n, 1), dtype=np.uint8)
         status[: max(n, 1)] = 0
         got = C.c_uint64(0)
-        rc = L.kgpu_tokenize_batch_multi(handles, len(tokenizers), utf8.ctypes.data if utf8.size else None, offsets.ctypes.data, n,
-                                         tokens.ctypes.data, cap, toff.ctypes.data, status.ctypes.data, C.byref(got))
+        u = utf8.ctypes.data if utf8.size else None
+        if compact:
+            rc = L.kgpu_tokenize_batch_multi_compact(handles, len(tokenizers), u, offsets.ctypes.data, n, tokens.ctypes.data, cap, first.ctypes.data,
+                                                     toff.ctypes.data, status.ctypes.data, C.byref(got))
+        else:
+            rc = L.kgpu_tokenize_batch_multi(handles, len(tokenizers), u, offsets.ctypes.data, n, tokens.ctypes.data, cap, toff.ctypes.data, status.ctypes.data, C.byref(got))
         if rc == _lib.KGPU_ERR_CAPACITY and token_capacity is None:
             cap = int(got.value) + 64
             continue
         _lib.check(rc)
+        if compact:
+            return tokens[: int(got.value)], first[:n], toff[: n + 1], status[:n]
         return tokens[: int(got.value)], toff[: n + 1], status[:n]
 
 
@@ -216,32 +225,41 @@ def concurrent_callers(tok: Tokenizer, utf8: np.ndarray, offsets: np.ndarray, th
 TOKEN8_DTYPE = np.dtype([("id", "<i4"), ("packed", "<u4")])  # kgpu_token8
 
 
-def merge_shards(shards, cnt: int, slice_sentences: int = 2048, reps: int = 1, token_capacity: int | None = None, want_tokens: bool = True):
-    """Measurement / test helper (kgpu_debug_merge_shards, not part of the public header; needs NO device): the host-side merge of
-    kgpu_tokenize_batch_multi over one super-chunk of `cnt` sentences.  shards[g] = (rec[TOKEN8_DTYPE], first[uint32 m x 2], toff[uint64 m + 1],
+def merge_shards(shards, cnt: int, slice_sentences: int = 2048, reps: int = 1, token_capacity: int | None = None, want_tokens: bool = True, compact: bool = False):
+    """Measurement / test helper (kgpu_debug_merge_shards[_compact], not part of the public header; needs NO device): the host-side merge of
+    kgpu_tokenize_batch_multi[_compact] over one super-chunk of `cnt` sentences.  shards[g] = (rec[TOKEN8_DTYPE], first[uint32 m x 2], toff[uint64 m + 1],
     status[uint8 m]) as shard g's compaction kernel leaves them; sentence j of the super-chunk is shard j mod G's local sentence j // G.
-    -> (rc, tokens, tok_offsets, status, n_tokens, seconds for all `reps` repetitions)."""
+    -> (rc, tokens, tok_offsets, status, n_tokens, seconds for all `reps` repetitions); compact: tokens = (tokens8, first[cnt x 2])."""
     G = len(shards)
     L = _lib.lib()
-    f = L.kgpu_debug_merge_shards
     vp = C.c_void_p
-    f.argtypes = [C.c_int, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp,
-                  C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
-    f.restype = C.c_int
     keep = [[np.ascontiguousarray(a, dtype=dt) for a, dt in zip(sh, (TOKEN8_DTYPE, np.uint32, np.uint64, np.uint8))] for sh in shards]
     arr = lambda k: (vp * G)(*[sh[k].ctypes.data for sh in keep])
     total = sum(int(sh[2][-1]) for sh in keep)
     cap = total if token_capacity is None else int(token_capacity)
-    tokens = np.zeros(max(cap, 1), dtype=TOKEN_DTYPE)
+    tokens = np.zeros(max(cap, 1), dtype=TOKEN8_DTYPE if compact else TOKEN_DTYPE)
     toff = np.zeros(cnt + 1, dtype=np.uint64)
     status = np.full(max(cnt, 1), 255, dtype=np.uint8)
     n_tok, secs = C.c_uint64(0), C.c_double(0)
+    if compact:
+        f = L.kgpu_debug_merge_shards_compact
+        f.argtypes = [C.c_int, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_uint64, C.c_int, vp, vp, C.c_uint64, vp, vp,
+                      C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        f.restype = C.c_int
+        first = np.full((max(cnt, 1), 2), 0xABABABAB, dtype=np.uint32)
+        rc = f(G, cnt, arr(0), arr(1), arr(2), arr(3), int(slice_sentences), int(reps), tokens.ctypes.data if want_tokens else None, first.ctypes.data, cap,
+               toff.ctypes.data, status.ctypes.data, C.byref(n_tok), C.byref(secs))
+        return rc, (tokens[: min(cap, total)], first[:cnt]), toff, status[:cnt], int(n_tok.value), float(secs.value)
+    f = L.kgpu_debug_merge_shards
+    f.argtypes = [C.c_int, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp,
+                  C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    f.restype = C.c_int
     rc = f(G, cnt, arr(0), arr(1), arr(2), arr(3), int(slice_sentences), int(reps), tokens.ctypes.data if want_tokens else None, cap, toff.ctypes.data,
            status.ctypes.data, C.byref(n_tok), C.byref(secs))
     return rc, tokens[: min(cap, total)], toff, status[:cnt], int(n_tok.value), float(secs.value)
 
 
-def merge_bench(G: int = 8, sentences_per_shard: int = 8192, tokens_per_sentence: int = 32, reps: int = 20) -> dict:
+def merge_bench(G: int = 8, sentences_per_shard: int = 8192, tokens_per_sentence: int = 32, reps: int = 20, compact: bool = False) -> dict:
     """The rate of that merge alone on this host's CPUs (bench.py's `multi_merge` entry): G synthetic shard blocks of a super-chunk, every sentence
     `tokens_per_sentence` records.  Per sentence the merge reads 8 t + 17 bytes and writes 24 t + 9 (t tokens): the 24-byte expansion is a
     memory-bandwidth job, so the rate is quoted beside a plain copy of the same number of bytes by the same worker threads' count of NumPy threads."""
@@ -258,10 +276,10 @@ def merge_bench(G: int = 8, sentences_per_shard: int = 8192, tokens_per_sentence
         rec["id"] = rng.integers(1, 390000, size=nt)
         rec["packed"] = 1 | (2 << 2) | (6 << 14)
         shards.append((rec, np.zeros((m, 2), dtype=np.uint32), toff, np.zeros(m, dtype=np.uint8)))
-    merge_shards(shards, cnt, reps=2)
-    rc, _, _, _, n_tok, secs = merge_shards(shards, cnt, reps=reps)
+    merge_shards(shards, cnt, reps=2, compact=compact)
+    rc, _, _, _, n_tok, secs = merge_shards(shards, cnt, reps=reps, compact=compact)
     _lib.check(rc)
-    moved = reps * (n_tok * 32 + cnt * 26)
+    moved = reps * ((n_tok * 16 + cnt * 34) if compact else (n_tok * 32 + cnt * 26))
     a = np.ones(n_tok * 24 // 8, dtype=np.uint64); b = np.empty_like(a)
     b[:] = a
     t0 = time.perf_counter()
@@ -269,7 +287,7 @@ def merge_bench(G: int = 8, sentences_per_shard: int = 8192, tokens_per_sentence
         b[:] = a
     copy_gbs = 5 * a.nbytes * 2 / (time.perf_counter() - t0) / 1e9
     return {"sentences_per_s": reps * cnt / secs, "G": G, "sentences_per_super_chunk": cnt, "tokens_per_sentence": n_tok / cnt,
-            "bytes_moved_GB_per_s": moved / secs / 1e9, "one_thread_copy_GB_per_s": copy_gbs,
-            "what": "kgpu_tokenize_batch_multi's merge alone (no device): G shards' 8-byte records -> the caller's order as 24-byte records + global offsets + "
+            "bytes_moved_GB_per_s": moved / secs / 1e9, "one_thread_copy_GB_per_s": copy_gbs, "record_bytes": 8 if compact else 24,
+            "what": "kgpu_tokenize_batch_multi" + ("_compact" if compact else "") + "'s merge alone (no device): G shards' 8-byte records -> the caller's order as " + ("8" if compact else "24") + "-byte records + global offsets + "
                     "status bytes; slice totals from the shards' offset tables on the calling thread, one worker-pool task per 2048 sentences walks the G "
                     "cursors (no division per sentence); the calling thread's own share is O(slices x G)"}

@@ -53,6 +53,43 @@ def test_sharded_call_equals_one_device_and_oracle(env, G, monkeypatch):
     _check(toks[:G], orc, utf8, offs)  # ~300 super-chunks of 7 G sentences through the eight slots
 
 
+@pytest.mark.parametrize("G", [1, 2, 3])
+def test_compact_sharded_call_expands_to_the_same_records(env, G, monkeypatch):
+    """kgpu_tokenize_batch_multi_compact: 8-byte records + firsts + offsets in the caller's order; kgpu_expand_tokens over them is byte for byte the
+    24-byte form's result and the oracle's, at G = 1 (the pipeline with one shard), 2 and 3, with many small super-chunks, ragged n and a bad sentence."""
+    from kanpyo_amd import _lib, synth
+    from kanpyo_amd.device import expand_tokens
+    from kanpyo_amd.tokenizer import TOKEN8_DTYPE, pack_sentences, tokenize_packed_multi
+
+    sd, toks, orc = env
+    sents = synth.make_corpus(sd, 5000, 13, "cfg2") + synth.make_corpus(sd, 200, 14, "cfg3") + ["", "すもももももももものうち", "テ"]
+    np.random.default_rng(40 + G).shuffle(sents)
+
+    def check(ss):
+        utf8, offs = pack_sentences(ss)
+        t8, first, toff, st = tokenize_packed_multi(toks[:G], utf8, offs, compact=True)
+        exp = orc.tokenize_batch(utf8, offs, 8)
+        assert t8.dtype == TOKEN8_DTYPE and np.array_equal(toff, exp.offsets) and not st.any()
+        assert np.array_equal(expand_tokens(t8, toff, first), exp.tokens)
+        return utf8, offs
+
+    utf8, offs = check(sents)
+    out = (np.empty(10, dtype=TOKEN8_DTYPE), np.empty(len(offs), dtype=np.uint64), np.empty(len(offs), dtype=np.uint8))
+    with pytest.raises(_lib.KgpuError) as e:
+        tokenize_packed_multi(toks[:G], utf8, offs, out=out, compact=True)
+    assert e.value.code == _lib.KGPU_ERR_CAPACITY
+    monkeypatch.setenv("KGPU_MULTI_CHUNK_SENTS", "7")
+    for n in (0, 1, 2, 3, 5, 64, 1000):
+        check(sents[:n])
+    raw = [s.encode("utf-8") for s in sents[:500]]
+    raw[17] = b"\xff\xfe broken"
+    o = np.concatenate([[0], np.cumsum([len(s) for s in raw])]).astype(np.uint64)
+    u = np.frombuffer(b"".join(raw), dtype=np.uint8)
+    t8, first, toff, st = tokenize_packed_multi(toks[:G], u, o, compact=True)
+    one_t, one_off, one_st = toks[0].tokenize_packed(u, o)
+    assert st[17] == 1 and np.array_equal(st, one_st) and np.array_equal(toff, one_off) and np.array_equal(expand_tokens(t8, toff, first), one_t)
+
+
 def test_same_handle_several_times_and_status_bytes(env):
     from kanpyo_amd.tokenizer import tokenize_packed_multi
 

@@ -92,12 +92,36 @@ def test_merge_capacity_and_offsets_only():
     assert rc == 0 and np.array_equal(off, exp_off) and np.array_equal(st, exp_st)
 
 
+@pytest.mark.parametrize("G,cnt,slice_", [(1, 100, 2048), (2, 4097, 2048), (3, 5000, 64), (8, 65536, 2048), (8, 7, 2), (64, 1000, 33)])
+def test_compact_merge_expands_to_the_same_records(G, cnt, slice_):
+    """kgpu_tokenize_batch_multi_compact's merge: the shards' 8-byte records + firsts in the caller's order; kgpu_expand_tokens over the merged arrays gives
+    exactly the 24-byte records of the other form (and the plain restatement)."""
+    from kanpyo_amd.device import expand_tokens
+
+    rng = np.random.default_rng(G * 7919 + cnt)
+    shards = fabricate(G, cnt, rng)
+    exp_tok, exp_off, exp_st = expected(shards, G, cnt)
+    rc, (tok8, first), off, st, n_tok, _ = merge_shards([(sh["rec"], sh["first"], sh["toff"], sh["st"]) for sh in shards], cnt, slice_, compact=True)
+    assert rc == 0, _lib.lib().kgpu_last_error()
+    assert n_tok == int(exp_off[-1]) and len(tok8) == n_tok and tok8.itemsize == 8
+    assert np.array_equal(off, exp_off) and np.array_equal(st, exp_st)
+    for g, sh in enumerate(shards):   # the firsts travel with their sentences
+        assert np.array_equal(first[g::G], sh["first"])
+    assert np.array_equal(expand_tokens(tok8, off, first), exp_tok)
+    rc, _, off2, st2, n2, _ = merge_shards([(sh["rec"], sh["first"], sh["toff"], sh["st"]) for sh in shards], cnt, slice_, token_capacity=1, compact=True)
+    if n_tok > 1:
+        assert rc == _lib.KGPU_ERR_CAPACITY and n2 == n_tok and np.array_equal(off2, exp_off) and np.array_equal(st2, exp_st)
+
+
 def test_merge_throughput_eight_shards():
     """G = 8, a super-chunk of 8 x 8192 sentences with cfg 2's ~32 tokens each: the rate of the merge alone on this box's CPUs (bench.py reports the
     same measurement as `multi_merge`); the assertion is only a floor far below any healthy box -- the 24-byte expansion is a memory-bandwidth job."""
     r = merge_bench(8, 8192, 32, reps=10)
     print(json.dumps(r))
     assert r["sentences_per_s"] > 3e6
+    rc = merge_bench(8, 8192, 32, reps=10, compact=True)   # the 8-byte-record form moves a third of the bytes
+    print(json.dumps(rc))
+    assert rc["record_bytes"] == 8 and rc["sentences_per_s"] > 3e6
 
 
 @pytest.mark.parametrize("n,misalign", [(3, 0), (500, 0), (5000, 0), (5000, 4)])
