@@ -50,11 +50,6 @@ constexpr uint32_t NONE16 = 0xFFFFu;
 #ifndef KGPU_EST_SLACK
 #define KGPU_EST_SLACK 768
 #endif
-#ifndef KGPU_PAIR_CAP
-#define KGPU_PAIR_CAP 1024
-#endif
-constexpr uint32_t PAIR_CAP = KGPU_PAIR_CAP;  // bytes of pair table a sentence reserves beyond its largest position: the sweep goes block by block
-                                     // (<= 64 targets each, one gather round), a block's pairs rarely need more
 
 // ---- DPP butterfly: min over aligned groups of 2^lg lanes, every lane gets it.
 // The key is one u64 (total ^ signbit) << 32 | predecessor node index, so one
@@ -396,47 +391,47 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         KGPU_TICK(3);
         KGPU_STOP(3)
         KGPU_ARGS();
-        // ---- phase 2: prefix sums: node numbering, bucket offsets, pair offsets ------
-        uint32_t ncarry = 1, bcarry = 0, ecarry = 0, maxpairs = 0;
+        // ---- phase 2: prefix sums: node numbering, bucket offsets, tile offsets ------
+        // A TILE is the unit of stage B: up to 8 targets x 8 predecessors of one start position, pair (ti, j) on lane 8 ti + j; a position with T
+        // targets and P predecessors is ceil(T / 8) x max(1, ceil(P / 8)) tiles (P = 0: one tile of absent candidates -- every target stays at INF).
+        uint32_t ncarry = 1, bcarry = 0, tcarry = 0;
+        uint64_t Esum = 0;
         for (uint32_t i0 = 0; i0 < C + 2; i0 += 64) {
             const uint32_t i = i0 + lane;
             const uint32_t v = i < C + 2 ? nb[i] : 0;    // targets starting at i
             const uint32_t w = i < C + 2 ? boff[i] : 0;  // predecessors ending at i
-            const uint32_t x = v * KGPU_PSTRIDE(w);      // relaxations at i (lattice.rs:122-125) = its pair costs (KGPU_PAIR_ODD: padded rows -- E then counts the padding too)
+            const uint32_t x = v ? ((v + 7u) >> 3) * max(1u, (w + 7u) >> 3) : 0u;  // tiles of position i
             const uint32_t vs = wave_incl_scan(v, lane), ws = wave_incl_scan(w, lane), xs = wave_incl_scan(x, lane);
-            if (i < C + 2) { nb[i] = ncarry + vs - v; boff[i] = bcarry + ws - w; ebase[i] = ecarry + xs - x; }
+            if (i < C + 2) { nb[i] = ncarry + vs - v; boff[i] = bcarry + ws - w; ebase[i] = tcarry + xs - x; }
             ncarry += __shfl(vs, 63, 64);
             bcarry += __shfl(ws, 63, 64);
-            ecarry += __shfl(xs, 63, 64);
-            maxpairs = max(maxpairs, x);
+            tcarry += __shfl(xs, 63, 64);
+            if constexpr (PROF) Esum += (uint64_t)v * w;  // relaxations at i (lattice.rs:122-125): the work counter E
         }
-#pragma unroll
-        for (int dd = 32; dd > 0; dd >>= 1) maxpairs = max(maxpairs, (uint32_t)__shfl_xor((int)maxpairs, dd, 64));
         // scalarise: the carve and the fit test below must be wave-uniform branches
-        const uint32_t N = bcast32(ncarry), Nb = bcast32(bcarry), E = bcast32(ecarry);
-        maxpairs = bcast32(maxpairs);
+        const uint32_t N = bcast32(ncarry), Nb = bcast32(bcarry), NT = bcast32(tcarry);
+        const uint32_t NTp = align_up(NT, 8);  // the list is padded to whole groups of eight with tiles that store nothing
 
-        // ---- LDS carve, part 2: node arrays, buckets, pair table ---------------------
+        // ---- LDS carve, part 2: buckets, node arrays, tile list ---------------------
         off = align_up(off, 8);
-        uint2 *bk = (uint2 *)(smem + off);          off += 8 * (Nb + 1);  // bucket (= edges[e]): {dp, right | node << 16}; [Nb]: sink for EOS
+        uint2 *bk = (uint2 *)(smem + off);          off += 8 * (Nb + 1);  // bucket (= edges[e]): {dp, 2 * right | node << 16}; [Nb]: sink for EOS
+        uint2 *node = (uint2 *)(smem + off);        off += 8 * N;   // {word cost (i16) | bucket slot of the node << 16, byte offset of the node's matrix row (left * rows * 2)};
+                                                                    // the sweep stores the best predecessor into the low half of .y once the node's costs are gathered
         int32_t *nSid = (int32_t *)(smem + off);    off += 4 * N;   // +id known, -id unknown, 0 dummy
-        uint32_t *nCS = (uint32_t *)(smem + off);   off += 4 * N;   // word cost (i16) | bucket slot of the node << 16   (all dwords before the half-words:
-        uint16_t *nLeft = (uint16_t *)(smem + off); off += 2 * N;   // left id until the node's block is gathered, then its best predecessor   every array naturally aligned whatever N is)
         uint16_t *nStart = (uint16_t *)(smem + off); off += 2 * N;
-        off = align_up(off, 4);
+        off = align_up(off, 8);
         const uint32_t off_emit_end = off;                          // everything above is written by emit
-        uint16_t *pre = nLeft;                                      // (a block's sweep writes pre[t] after its gather has read nLeft[t])
-        int16_t *mpair = (int16_t *)(smem + off);                   // pair table of one block; overlays the match buffer
+        uint2 *tiles = (uint2 *)(smem + off);                       // the tile list; overlays the match buffer (written after emit)
         if (N > 0xFFFF) { defer_s(s); break; }
-        // exact requirement: emit-written arrays stay below the match buffer; afterwards the pair table overlays it
-        const uint32_t need_emit = off_emit_end + mbytes + 16, need_full = off + min(2 * E, max(2 * maxpairs, PAIR_CAP));
-        if (need_emit > lds_bytes || off + 2 * maxpairs > lds_bytes) {
+        // exact requirement: emit-written arrays stay below the match buffer; afterwards the tile list overlays it
+        const uint32_t need_emit = off_emit_end + mbytes + 16, need_full = off + 8 * NTp;
+        if (need_emit > lds_bytes || need_full > lds_bytes) {
             // reservation too small: release, wait (holding nothing) for the exact size, redo
             pool_free(bm, pg, 0, npg, lane);
             if (lane == 0) atomicAdd(io.late_count, 1u);
             pg = NONE;
-            if (pages_for(max(need_emit, off + 2 * maxpairs)) > max_pages || attempt != 0) { defer_s(s); break; }
-            npg = min(max_pages, pages_for(max(need_emit, need_full)));
+            if (pages_for(max(need_emit, need_full)) > max_pages || attempt != 0) { defer_s(s); break; }
+            npg = pages_for(max(need_emit, need_full));
             pg = pool_wait_alloc(bm, npg, lane);
             if (pg == NONE) { defer_s(s); break; }
             continue;
@@ -448,7 +443,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         KGPU_ARGS();
         // ---- phase 3: emit nodes from the parked matches --------------------------------
         // 3a, lane = start position, LDS only: the node list in insertion order (lattice.rs:177-201) -- per node its
-        // morph id, start and (parked in nLeft) end position
+        // morph id, start and (parked in node[].y) end position
         for (uint32_t i = lane; i < C; i += 64) {
             uint32_t t = nb[i];
             const uint32_t nm = mcnt[i], span = uspan[i];
@@ -470,15 +465,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                     const uint2 w = *(const uint2 *)(mbuf + 2 * (i * MAXM + m));
                     id = w.x; end = i + (w.y & 255u); nrec = w.y >> 8;
                 }
-                for (uint32_t r = 0; r < nrec; ++r, ++t) { nSid[t] = (int32_t)(id + r); nStart[t] = (uint16_t)i; nLeft[t] = (uint16_t)end; }
+                for (uint32_t r = 0; r < nrec; ++r, ++t) { nSid[t] = (int32_t)(id + r); nStart[t] = (uint16_t)i; node[t].y = end; }
             }
             if (span)   // lattice.rs:87-97,190-201
-                for (uint32_t r = 0; r < ucnt; ++r, ++t) { nSid[t] = -(int32_t)(ufirst + r); nStart[t] = (uint16_t)i; nLeft[t] = (uint16_t)(i + span); }
+                for (uint32_t r = 0; r < ucnt; ++r, ++t) { nSid[t] = -(int32_t)(ufirst + r); nStart[t] = (uint16_t)i; node[t].y = i + span; }
         }
         wave_sync();
         // 3b, lane = node: its morph record (one gather per 64 nodes instead of one dependent load per record of the
         // busiest position), its slot in the bucket of the position it ends at.  The order inside a bucket is free:
         // the sweep breaks ties on the node index it carries.
+        const uint32_t rows2 = d.conn_rows * 2u;   // bytes per matrix row (connection.rs:12-14: element (right, left) at left * rows + right)
         for (uint32_t t0 = 1; t0 < N - 1; t0 += 256) {  // four nodes per lane: the four record gathers are in flight together
             uint32_t tt[4], ee[4];
             Morph8 mm[4];
@@ -487,145 +483,131 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                 tt[k] = t0 + 64 * k + lane;
                 const bool v = tt[k] < N - 1;
                 const int32_t sid = v ? nSid[tt[k]] : 1;
-                ee[k] = v ? nLeft[tt[k]] : 0u;
+                ee[k] = v ? node[tt[k]].y : 0u;
                 mm[k] = *(sid > 0 ? d.morph + (sid - 1) : d.unk_morph + (-sid - 1));
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (tt[k] < N - 1) {
                     const uint32_t slot = boff[ee[k]] + atomicAdd(&bfill[ee[k]], 1u);
-                    nLeft[tt[k]] = (uint16_t)mm[k].left; nCS[tt[k]] = (uint32_t)(uint16_t)mm[k].cost | (slot << 16);
-                    bk[slot].y = (uint32_t)(uint16_t)mm[k].right | (tt[k] << 16);
+                    node[tt[k]] = make_uint2((uint32_t)(uint16_t)mm[k].cost | (slot << 16), (uint32_t)(uint16_t)mm[k].left * rows2);
+                    bk[slot].y = ((uint32_t)(uint16_t)mm[k].right << 1) | (tt[k] << 16);   // ids are non-negative i16 (checked at create): 2 * right fits the half-word
                 }
             }
         }
         if (lane == 0) {
-            nLeft[N - 1] = (uint16_t)d.eos_left; nCS[N - 1] = Nb << 16;  // EOS: Morph(0,0,0), ranked id; its dp goes to the sink slot
+            node[N - 1] = make_uint2(Nb << 16, d.eos_left * rows2);  // EOS: Morph(0,0,0), ranked id; its dp goes to the sink slot
             nStart[N - 1] = (uint16_t)C; nSid[N - 1] = 0;
-            bk[0] = make_uint2(0u, d.bos_right);  // BOS: dp None -> 0 (lattice.rs:127), right_id 0 (ranked), node 0
+            bk[0] = make_uint2(0u, d.bos_right << 1);  // BOS: dp None -> 0 (lattice.rs:127), right_id 0 (ranked), node 0
+            bk[Nb].y = 0;                              // the sink: a position without predecessors gathers (and then ignores) a cost through it
+            node[0] = make_uint2(0u, NONE16);          // ... and no predecessor (the backtrace stops here)
         }
         wave_sync();
-        if (lane == 0) pre[0] = NONE16;
-        {   // the match buffer is dead now: give back the pages beyond pre + the whole pair table
+        {   // the match buffer is dead now: give back the pages beyond the tile list
             const uint32_t keep = pages_for(need_full);
             if (keep < npg) { pool_free(bm, pg, keep, npg, lane); npg = keep; }
         }
-        const uint32_t mcap = (npg * page - off) / 2;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(KGPU_LDS(uint8_t) *)pool;  // absolute LDS addresses, wave-uniform: SGPRs
+        const uint32_t a_node = bcast32(lds0 + (uint32_t)((uint8_t *)node - pool)), a_bk = bcast32(lds0 + (uint32_t)((uint8_t *)bk - pool));
+        // 3c, lane = start position: its tiles.  D0 = address of node[t0 + 8 a] (18 bits) | (Tt - 1) << 18 (3) | (max(Pt, 1) - 1) << 21 (3) | Pt << 24 (4) | first b << 28
+        // | last b << 29, D1 = address of bk[p0 + 8 b]; (a, b) = (target group, predecessor chunk), b fastest: a group's chunks are consecutive, the last one
+        // reduces and stores.
+        for (uint32_t q0 = 0; q0 <= C; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            if (q <= C) {
+                const uint32_t t0 = nb[q], T = nb[q + 1] - t0, p0 = boff[q], P = boff[q + 1] - p0;
+                uint32_t k = ebase[q];
+                const uint32_t kb = max(1u, (P + 7u) >> 3);
+                for (uint32_t ta = 0; ta < T; ta += 8) {
+                    const uint32_t w0 = (a_node + 8 * (t0 + ta)) | ((min(8u, T - ta) - 1u) << 18);
+                    for (uint32_t b = 0; b < kb; ++b, ++k) {
+                        const uint32_t Pt = min(8u, P - min(P, 8 * b));
+                        tiles[k] = make_uint2(w0 | ((max(Pt, 1u) - 1u) << 21) | (Pt << 24) | ((b == 0) << 28) | ((b == kb - 1) << 29), a_bk + 8 * (p0 + 8 * b));
+                    }
+                }
+            }
+        }
+        const uint32_t null0 = (a_node + 8 * (N - 1)) | (1u << 28);   // padding: a target group that is never reduced (its gather reads M[BOS][EOS]: always in the matrix)
+        if (lane < NTp - NT) tiles[NT + lane] = make_uint2(null0, a_bk);
+        wave_sync();
         KGPU_TICK(5);
         KGPU_STOP(5)
         KGPU_ARGS();
         uint64_t cyc_gather = 0;
-        // ---- phases 3b + 4, per block of positions whose pairs fit the pair table ----
-        uint32_t qa = 0;
-        while (qa <= C) {
-            // a block: as many positions (at most 64: one per lane) as keep the targets within one gather round (64) and
-            // the pairs within the table; the first position is taken whatever its size (the reservation covers the largest)
-            const uint32_t ql = qa + lane;
-            const bool inq = ql <= C;
-            const uint32_t nb0 = nb[inq ? ql : C], nb1 = nb[inq ? ql + 1 : C], eb_l = ebase[inq ? ql : C], eb1 = ebase[inq ? ql + 1 : C];
-            const uint32_t tA = bcast32(nb0), eb0 = bcast32(eb_l);
-            const uint64_t fits = __ballot(inq && (lane == 0 || (nb1 - tA <= 64u && eb1 - eb0 <= mcap)));
-            const uint32_t nq = ~fits ? (uint32_t)__ffsll((unsigned long long)~fits) - 1u : 64u;  // a prefix of the lanes: both sums are monotone (1..64)
-            const uint32_t qb = qa + nq;
-            const uint64_t tg0 = prof ? __builtin_amdgcn_s_memtime() : 0;
-            // -- 3b: gather every connection cost of the block into LDS (connection.rs:12-14).  Lane = target, four
-            // independent gathers in flight per lane, the last group of a row padded with a repeat of its final entry
-            // (ceil(P / 4) dependent rounds per target instead of P / 4 + P % 4).  Measured alternatives, all slower:
-            // eight lanes per target with eight loads in flight (more LDS bookkeeping per load than it saves in cache
-            // lines), 16 loads in flight per lane.
-            const uint32_t ta = tA, tb = bcast32(nb[qb]);
-            for (uint32_t t = ta + lane; t < tb; t += 64) {
-                const uint32_t q = nStart[t];
-                const uint32_t p0 = boff[q], P = boff[q + 1] - p0;
-                const uint32_t ti = t - nb[q];
-                const uint32_t base = ebase[q] - eb0 + ti * KGPU_PSTRIDE(P);  // pair (ti, j) lives at ti*P + j
-                gather_target_row(bk + p0, P, conn_row(d, nLeft[t]), mpair + base);
-            }
-            wave_sync();
-            if (prof) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
-            if (stop_after == 6) { qa = qb; continue; }  // ablation timing: every block's gather, no sweep (the KGPU_STOP(6) below then ends the sentence)
-
-            // -- 4: Viterbi sweep over the block (lattice.rs:116-142), LDS only: one dependent chain per position.  The step itself -- descriptors as
-            // ready-made LDS addresses broadcast with v_readlane, three straight-line bodies, two DPP group minima -- is sweep_position_fast (kgpu_device.h).
-            KGPU_TM(const uint64_t tm_s0 = __builtin_amdgcn_s_memtime();)
-            const uint32_t lds0 = (uint32_t)(uintptr_t)(KGPU_LDS(uint8_t) *)pool;  // absolute LDS addresses, wave-uniform: SGPRs
-            const uint32_t a_ncs = bcast32(lds0 + (uint32_t)((uint8_t *)nCS - pool)), a_bk = bcast32(lds0 + (uint32_t)((uint8_t *)bk - pool));
-            const uint32_t a_mp = bcast32(lds0 + (uint32_t)((uint8_t *)mpair - pool)), a_pre = bcast32(lds0 + (uint32_t)((uint8_t *)pre - pool));
-            {
-                // three descriptor words per position: d0 = address of nCS[t0] (18 bits) | T (7) << 18 | P (6) << 25 | slow << 31,
-                // d1 = address of bk[p0], d2 = address of the position's pair costs
-                uint32_t dT = 0, dP = 0, dt0 = 0, d0 = 1u << 31, d1 = 0, d2 = 0;
-                if (lane < nq) {
-                    dt0 = nb0;
-                    const uint32_t dp0 = boff[ql], deb = eb_l - eb0;
-                    dT = nb1 - dt0;
-                    dP = boff[ql + 1] - dp0;
-                    const bool fastq = dP <= 32 && dT - 1u < 127u;  // 1 <= T <= 127, P <= 32
-                    d0 = sweep_desc0(a_ncs, dt0, dT, dP, fastq);
-                    d1 = a_bk + 8 * dp0;
-                    d2 = a_mp + 2 * deb;
-                }
-                KGPU_TM(tmDesc += __builtin_amdgcn_s_memtime() - tm_s0;)
-                for (uint32_t r = 0; r < nq; ++r) {
-                    const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)r);
-                    const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)r);
-                    const uint32_t D2 = (uint32_t)__builtin_amdgcn_readlane((int)d2, (int)r);
-                    if (!(D0 >> 31)) {
-                        sweep_position_fast(lane, D0, D1, D2, a_ncs, a_pre, a_bk);   // kgpu_device.h: the step both LDS kernels share
-                    } else {
-                        KGPU_TM(tmSlowSteps += 1; const uint64_t tm_sl0 = __builtin_amdgcn_s_memtime();)
-                        const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)dT, (int)r);
-                        const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)dP, (int)r);
-                        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)dt0, (int)r);
-                        const uint32_t p0 = (D1 - a_bk) >> 3, eb = (D2 - a_mp) >> 1;
-                        if (P == 0) {
-                            // nothing ends here: every target stays at INF with no predecessor
-                            for (uint32_t t = t0 + lane; t < t0 + T; t += 64) {
-                                pre[t] = NONE16;
-                                bk[nCS[t] >> 16].x = (uint32_t)INF;
-                            }
-                        } else if (T) {  // any shape: loop over target groups and predecessor chunks
-                            uint32_t lg = P > 1 ? 32 - __clz(P - 1) : 0;
-                            if (lg > 6) lg = 6;
-                            const uint32_t jj0 = lane & ((1u << lg) - 1), tg = lane >> lg, TG = 64u >> lg;
-                            for (uint32_t tbase = 0; tbase < T; tbase += TG) {
-                                const uint32_t ti = tbase + tg;
-                                const bool tvalid = ti < T;
-                                const uint32_t cs = tvalid ? nCS[t0 + ti] : 0u;
-                                const int32_t cost = (int32_t)(int16_t)cs;
-                                const uint32_t sl = cs >> 16;
-                                uint64_t key = ~0ull;
-                                for (uint32_t jc = 0; jc < P; jc += 64) {
-                                    const uint32_t jj = jc + jj0;
-                                    uint64_t ck = ~0ull;
-                                    if (tvalid && jj < P) {
-                                        const uint2 e = bk[p0 + jj];
-                                        const int32_t v = (int32_t)e.x + (int32_t)mpair[eb + ti * KGPU_PSTRIDE(P) + jj];
-                                        ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (e.y >> 16);
-                                    }
-                                    ck = group_min(ck, lg);
-                                    key = ck < key ? ck : key;
-                                }
-                                if (tvalid && jj0 == 0) {
-                                    const int32_t tot = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u) + cost;
-                                    const bool ok = tot < INF;
-                                    pre[t0 + ti] = (uint16_t)(ok ? ((uint32_t)key & 0xFFFFu) : NONE16);
-                                    bk[sl].x = (uint32_t)(ok ? tot : INF);
-                                }
-                            }
-                        }
-                        wave_sync();
-                        KGPU_TM(tmSlow += __builtin_amdgcn_s_memtime() - tm_sl0;)
+        // ---- phase 4: stage B over the tile list (lattice.rs:116-142; connection.rs:12-14) ----
+        // Per tile, lane 8 ti + j holds the pair (target ti, predecessor j).  GATHER: the lane loads its own connection cost M[right(j)][left(ti)]
+        // from the matrix into a REGISTER (byte offset = the node's row offset + 2 * right: one add) -- no pair table in LDS, and a group of eight
+        // tiles is requested while the previous group is swept, so the matrix's latency is off the dependency chain.  SWEEP: dp of the predecessor
+        // + that cost, the running lexicographic minimum (total, then the bucket word whose upper half is the node index: strict '<' over ascending
+        // insertion order, lattice.rs:125,136) across a target group's chunks, and on its last chunk two DPP group minima, the word cost, .min(INF),
+        // the stores.  Lanes past Tt redo target Tt - 1 (same loads, same stores); lanes past Pt carry an absent candidate no real total reaches.
+        {
+            const uint32_t j = lane & 7u, j8 = 8u * j, tg8 = lane & 0x38u;   // lane = 8 ti + j
+            const uint8_t *connb = (const uint8_t *)d.conn;
+            constexpr int32_t ABSENT = 0x7FFEFFFF;
+            int32_t rv = ABSENT; uint32_t ry = 0xFFFFFFFFu;   // running minimum of the target group in progress
+            for (uint32_t w0 = 0; w0 < NTp; w0 += 64) {       // a window of 64 descriptors in registers, read out with v_readlane
+                const uint2 dd = w0 + lane < NTp ? tiles[w0 + lane] : make_uint2(null0, a_bk);
+                const uint32_t d0 = dd.x, d1 = dd.y;
+                const uint32_t ng = min(8u, (NTp - w0) >> 3);
+                auto gather8 = [&](int32_t (&c)[8], uint32_t g) {
+                    // every lane loads: lanes past Tt / Pt repeat the last target / predecessor of the tile (the same address as their neighbour's: the
+                    // same cache line) -- an exec-masked load would have to merge into the register's old value and so wait for the loads in flight
+                    uint32_t lb[8], yy[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)(8 * g + u));
+                        const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)(8 * g + u));
+                        lb[u] = lds_ld<uint32_t>((D0 & 0x3FFFFu) + min(tg8, (D0 >> 15) & 0x38u) + 4u);
+                        yy[u] = lds_ld<uint32_t>(D1 + min(j8, (D0 >> 18) & 0x38u) + 4u);
                     }
-                    // no fence per step: the LDS unit executes one wavefront's DS instructions in issue order, so the next
-                    // position's reads see these writes; a fence would make every step wait for the write acknowledgement
-                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_sched_barrier(0);  // the sixteen reads are one round trip
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) c[u] = *(const int16_t *)(connb + (lb[u] + (yy[u] & 0xFFFFu)));
+                };
+                auto sweep8 = [&](const int32_t (&c)[8], uint32_t g) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)(8 * g + u));
+                        const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)(8 * g + u));
+                        const uint32_t na = (D0 & 0x3FFFFu) + min(tg8, (D0 >> 15) & 0x38u);
+                        const uint32_t cs = lds_ld<uint32_t>(na);
+                        const uint2 e0 = lds_ld2(D1 + j8);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int32_t v0 = j < ((D0 >> 24) & 15u) ? (int32_t)e0.x + c[u] : ABSENT;
+                        if (__builtin_expect(!(D0 & (1u << 28)), 0)) {   // a further chunk of the target group: (total, bucket word) lexicographic, one 64-bit compare
+                            const bool take = (((int64_t)v0 << 32) | e0.y) < (((int64_t)rv << 32) | ry);
+                            rv = take ? v0 : rv; ry = take ? e0.y : ry;
+                        } else { rv = v0; ry = e0.y; }
+                        if (__builtin_expect((D0 & (1u << 29)) != 0, 1)) {
+                            const int32_t vmin = group_min_i32<3>(rv);
+                            const uint32_t nmin = group_min_u32<3>(rv == vmin ? ry : 0xFFFFFFFFu);
+                            const int32_t tot = vmin + (int32_t)(int16_t)cs;
+                            const bool ok = tot < INF;
+                            lds_st<uint16_t>(na + 4u, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
+                            lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
+                        }
+                        // no fence per tile: the LDS unit executes one wavefront's DS instructions in issue order, so the next
+                        // tile's reads see these writes; a fence would make every tile wait for the write acknowledgement
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                };
+                int32_t cA[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cB[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                const uint64_t tg0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+                gather8(cA, 0);
+                if (prof) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
+                for (uint32_t g = 0; g < ng; g += 2) {
+                    if (g + 1 < ng) gather8(cB, g + 1);
+                    if (stop_after != 6) sweep8(cA, g);   // (6: ablation timing -- every group's gather, no sweep; the KGPU_STOP(6) below then ends the sentence)
+                    if (g + 1 < ng) {
+                        if (g + 2 < ng) gather8(cA, g + 2);
+                        if (stop_after != 6) sweep8(cB, g + 1);
+                    }
                 }
+                if (stop_after == 6) { asm volatile("" :: "v"(cA[0]), "v"(cA[7]), "v"(cB[0]), "v"(cB[7])); }
             }
-            wave_sync();
-            KGPU_TM(tmS += __builtin_amdgcn_s_memtime() - tm_s0; tmSteps += qb - qa;)
-            qa = qb;
         }
+        wave_sync();
 
         KGPU_TICK(6);
         KGPU_STOP(6)
@@ -635,7 +617,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         uint32_t K = 0;
         if (lane == 0) {
             uint32_t pos = N - 1, pr;
-            while ((pr = pre[pos]) != NONE16 && K <= C) { path[K++] = (uint16_t)pos; pos = pr; }  // K <= C + 1 always; bound the walk anyway
+            while ((pr = node[pos].y & 0xFFFFu) != NONE16 && K <= C) { path[K++] = (uint16_t)pos; pos = pr; }  // K <= C + 1 always; bound the walk anyway
         }
         K = bcast32(K);
         // staging slot of the sentence: K <= C + 1 <= B + 1 tokens always fit at b0 + s
@@ -666,7 +648,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         if constexpr (PROF) {
             wT = wave_sum(wT);
             const uint64_t t7 = __builtin_amdgcn_s_memtime();
-            accW[0] += 1; accW[1] += B; accW[2] += C; accW[3] += wT; accW[4] += N - 1; accW[5] += E; accW[6] += K;
+            accW[0] += 1; accW[1] += B; accW[2] += C; accW[3] += wT; accW[4] += N - 1; accW[5] += bcast64(wave_sum64(Esum)); accW[6] += K;
             accP[0] += tick[1] - tick[0]; accP[1] += tick[2] - tick[1]; accP[2] += tick[3] - tick[2];
             accP[3] += tick[4] - tick[3]; accP[4] += tick[5] - tick[4]; accP[5] += cyc_gather;
             accP[6] += tick[6] - tick[5] - cyc_gather; accP[7] += t7 - tick[6]; accP[8] += 1;
