@@ -414,7 +414,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
 
         // ---- LDS carve, part 2: buckets, node arrays, tile list ---------------------
         off = align_up(off, 8);
-        uint2 *bk = (uint2 *)(smem + off);          off += 8 * (Nb + 1);  // bucket (= edges[e]): {dp, 2 * right | node << 16}; [Nb]: sink for EOS
+        uint2 *bk = (uint2 *)(smem + off);          off += 8 * (Nb + 2);  // bucket (= edges[e]): {dp, 2 * right | node << 16}; [Nb]: sink for EOS; [Nb + 1]: the absent candidate
         uint2 *node = (uint2 *)(smem + off);        off += 8 * N;   // {word cost (i16) | bucket slot of the node << 16, byte offset of the node's matrix row (left * rows * 2)};
                                                                     // the sweep stores the best predecessor into the low half of .y once the node's costs are gathered
         int32_t *nSid = (int32_t *)(smem + off);    off += 4 * N;   // +id known, -id unknown, 0 dummy
@@ -499,7 +499,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             node[N - 1] = make_uint2(Nb << 16, d.eos_left * rows2);  // EOS: Morph(0,0,0), ranked id; its dp goes to the sink slot
             nStart[N - 1] = (uint16_t)C; nSid[N - 1] = 0;
             bk[0] = make_uint2(0u, d.bos_right << 1);  // BOS: dp None -> 0 (lattice.rs:127), right_id 0 (ranked), node 0
-            bk[Nb].y = 0;                              // the sink: a position without predecessors gathers (and then ignores) a cost through it
+            bk[Nb + 1] = make_uint2(0x7FFEFFFFu, 0u);  // what a position without predecessors relaxes from: a total no real one reaches (real <= INF + 32767) that
+                                                       // cannot overflow when a connection cost and a word cost are added, and stays >= INF when they are negative
             node[0] = make_uint2(0u, NONE16);          // ... and no predecessor (the backtrace stops here)
         }
         wave_sync();
@@ -509,21 +510,20 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         }
         const uint32_t lds0 = (uint32_t)(uintptr_t)(KGPU_LDS(uint8_t) *)pool;  // absolute LDS addresses, wave-uniform: SGPRs
         const uint32_t a_node = bcast32(lds0 + (uint32_t)((uint8_t *)node - pool)), a_bk = bcast32(lds0 + (uint32_t)((uint8_t *)bk - pool));
-        // 3c, lane = start position: its tiles.  D0 = address of node[t0 + 8 a] (18 bits) | (Tt - 1) << 18 (3) | (max(Pt, 1) - 1) << 21 (3) | Pt << 24 (4) | first b << 28
-        // | last b << 29, D1 = address of bk[p0 + 8 b]; (a, b) = (target group, predecessor chunk), b fastest: a group's chunks are consecutive, the last one
-        // reduces and stores.
+        // 3c, lane = start position: its tiles.  D0 = address of node[t0 + 8 a] (18 bits) | (Tt - 1) << 18 (3) | (Pt - 1) << 21 (3) | first b << 28 | last b << 29,
+        // D1 = address of bk[p0 + 8 b]; (a, b) = (target group, predecessor chunk), b fastest: a group's chunks are consecutive, the last one reduces and
+        // stores.  A position without predecessors (P = 0) is one chunk of one absent candidate (bk[Nb + 1]): its targets stay at INF with no predecessor.
         for (uint32_t q0 = 0; q0 <= C; q0 += 64) {
             const uint32_t q = q0 + lane;
             if (q <= C) {
-                const uint32_t t0 = nb[q], T = nb[q + 1] - t0, p0 = boff[q], P = boff[q + 1] - p0;
+                const uint32_t t0 = nb[q], T = nb[q + 1] - t0, p0r = boff[q], Pr = boff[q + 1] - p0r;
+                const uint32_t p0 = Pr ? p0r : Nb + 1, P = Pr ? Pr : 1u;
                 uint32_t k = ebase[q];
-                const uint32_t kb = max(1u, (P + 7u) >> 3);
+                const uint32_t kb = (P + 7u) >> 3;
                 for (uint32_t ta = 0; ta < T; ta += 8) {
                     const uint32_t w0 = (a_node + 8 * (t0 + ta)) | ((min(8u, T - ta) - 1u) << 18);
-                    for (uint32_t b = 0; b < kb; ++b, ++k) {
-                        const uint32_t Pt = min(8u, P - min(P, 8 * b));
-                        tiles[k] = make_uint2(w0 | ((max(Pt, 1u) - 1u) << 21) | (Pt << 24) | ((b == 0) << 28) | ((b == kb - 1) << 29), a_bk + 8 * (p0 + 8 * b));
-                    }
+                    for (uint32_t b = 0; b < kb; ++b, ++k)
+                        tiles[k] = make_uint2(w0 | ((min(8u, P - 8 * b) - 1u) << 21) | ((b == 0) << 28) | ((b == kb - 1) << 29), a_bk + 8 * (p0 + 8 * b));
                 }
             }
         }
@@ -542,17 +542,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         // insertion order, lattice.rs:125,136) across a target group's chunks, and on its last chunk two DPP group minima, the word cost, .min(INF),
         // the stores.  Lanes past Tt redo target Tt - 1 (same loads, same stores); lanes past Pt carry an absent candidate no real total reaches.
         {
-            const uint32_t j = lane & 7u, j8 = 8u * j, tg8 = lane & 0x38u;   // lane = 8 ti + j
+            const uint32_t j8 = 8u * (lane & 7u), tg8 = lane & 0x38u;   // lane = 8 ti + j
             const uint8_t *connb = (const uint8_t *)d.conn;
-            constexpr int32_t ABSENT = 0x7FFEFFFF;
-            int32_t rv = ABSENT; uint32_t ry = 0xFFFFFFFFu;   // running minimum of the target group in progress
+            int32_t rv = 0; uint32_t ry = 0;   // running minimum of the target group in progress
+            struct Grp { int32_t c[8]; };   // per tile of a group: the lane's connection cost (addresses are recomputed by the sweep: the kernel stays within 96
+                                            // VGPRs, so that the small kernels of other batches' chains still find registers on a chip full of these wavefronts)
             for (uint32_t w0 = 0; w0 < NTp; w0 += 64) {       // a window of 64 descriptors in registers, read out with v_readlane
                 const uint2 dd = w0 + lane < NTp ? tiles[w0 + lane] : make_uint2(null0, a_bk);
                 const uint32_t d0 = dd.x, d1 = dd.y;
                 const uint32_t ng = min(8u, (NTp - w0) >> 3);
-                auto gather8 = [&](int32_t (&c)[8], uint32_t g) {
-                    // every lane loads: lanes past Tt / Pt repeat the last target / predecessor of the tile (the same address as their neighbour's: the
-                    // same cache line) -- an exec-masked load would have to merge into the register's old value and so wait for the loads in flight
+                auto gather8 = [&](Grp &G, uint32_t g) {
+                    // every lane loads: lanes past Tt / Pt repeat the tile's last target / predecessor (the same address as their neighbour's: the same
+                    // cache line; in the sweep a repeated candidate changes no minimum) -- no exec mask anywhere: a masked load would have to merge into
+                    // the register's old value and so wait for the loads in flight
                     uint32_t lb[8], yy[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -563,18 +565,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                     }
                     __builtin_amdgcn_sched_barrier(0);  // the sixteen reads are one round trip
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) c[u] = *(const int16_t *)(connb + (lb[u] + (yy[u] & 0xFFFFu)));
+                    for (int u = 0; u < 8; ++u) G.c[u] = *(const int16_t *)(connb + (lb[u] + (yy[u] & 0xFFFFu)));
                 };
-                auto sweep8 = [&](const int32_t (&c)[8], uint32_t g) {
+                auto sweep8 = [&](const Grp &G, uint32_t g) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)(8 * g + u));
-                        const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)(8 * g + u));
                         const uint32_t na = (D0 & 0x3FFFFu) + min(tg8, (D0 >> 15) & 0x38u);
                         const uint32_t cs = lds_ld<uint32_t>(na);
-                        const uint2 e0 = lds_ld2(D1 + j8);
+                        const uint2 e0 = lds_ld2((uint32_t)__builtin_amdgcn_readlane((int)d1, (int)(8 * g + u)) + min(j8, (D0 >> 18) & 0x38u));
                         __builtin_amdgcn_sched_barrier(0);
-                        const int32_t v0 = j < ((D0 >> 24) & 15u) ? (int32_t)e0.x + c[u] : ABSENT;
+                        const int32_t v0 = (int32_t)e0.x + G.c[u];
                         if (__builtin_expect(!(D0 & (1u << 28)), 0)) {   // a further chunk of the target group: (total, bucket word) lexicographic, one 64-bit compare
                             const bool take = (((int64_t)v0 << 32) | e0.y) < (((int64_t)rv << 32) | ry);
                             rv = take ? v0 : rv; ry = take ? e0.y : ry;
@@ -592,19 +593,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                         __builtin_amdgcn_wave_barrier();
                     }
                 };
-                int32_t cA[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cB[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                Grp GA, GB;
                 const uint64_t tg0 = prof ? __builtin_amdgcn_s_memtime() : 0;
-                gather8(cA, 0);
+                gather8(GA, 0);
                 if (prof) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
                 for (uint32_t g = 0; g < ng; g += 2) {
-                    if (g + 1 < ng) gather8(cB, g + 1);
-                    if (stop_after != 6) sweep8(cA, g);   // (6: ablation timing -- every group's gather, no sweep; the KGPU_STOP(6) below then ends the sentence)
+                    if (g + 1 < ng) gather8(GB, g + 1);
+                    if (stop_after != 6) sweep8(GA, g);   // (6: ablation timing -- every group's gather, no sweep; the KGPU_STOP(6) below then ends the sentence)
                     if (g + 1 < ng) {
-                        if (g + 2 < ng) gather8(cA, g + 2);
-                        if (stop_after != 6) sweep8(cB, g + 1);
+                        if (g + 2 < ng) gather8(GA, g + 2);
+                        if (stop_after != 6) sweep8(GB, g + 1);
                     }
                 }
-                if (stop_after == 6) { asm volatile("" :: "v"(cA[0]), "v"(cA[7]), "v"(cB[0]), "v"(cB[7])); }
+                if (stop_after == 6) { asm volatile("" :: "v"(GA.c[0]), "v"(GA.c[7]), "v"(GB.c[0]), "v"(GB.c[7])); }
             }
         }
         wave_sync();
