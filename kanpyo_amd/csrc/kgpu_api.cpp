@@ -423,6 +423,7 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
         d->view.da2_len = (uint32_t)ct.da.size();
         d->view.n_nb = (uint32_t)ct.nb_cp.size();
     }
+    conn.resize(conn.size() + 2, 0);   // the pool kernel reads a cost with a dword load at its (2-byte-aligned) address: the last element's load stays inside the allocation
     if ((rc = upload(d, first, &d->view.first)) ||
         (rc = upload(d, da, &d->view.da)) || (rc = upload(d, morphs, &d->view.morph)) ||
         (rc = upload(d, unk_morphs, &d->view.unk_morph)) || (rc = upload(d, conn, &d->view.conn)) ||

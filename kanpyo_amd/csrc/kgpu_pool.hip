@@ -545,7 +545,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             const uint32_t j8 = 8u * (lane & 7u), tg8 = lane & 0x38u;   // lane = 8 ti + j
             const uint8_t *connb = (const uint8_t *)d.conn;
             int32_t rv = 0; uint32_t ry = 0;   // running minimum of the target group in progress
-            struct Grp { int32_t c[8]; };   // per tile of a group: the lane's connection cost (addresses are recomputed by the sweep: the kernel stays within 96
+            struct Grp { uint32_t c[8]; };   // per tile of a group: the lane's connection cost (addresses are recomputed by the sweep: the kernel stays within 96
                                             // VGPRs, so that the small kernels of other batches' chains still find registers on a chip full of these wavefronts)
             for (uint32_t w0 = 0; w0 < NTp; w0 += 64) {       // a window of 64 descriptors in registers, read out with v_readlane
                 const uint2 dd = w0 + lane < NTp ? tiles[w0 + lane] : make_uint2(null0, a_bk);
@@ -564,8 +564,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                         yy[u] = lds_ld<uint32_t>(D1 + min(j8, (D0 >> 18) & 0x38u) + 4u);
                     }
                     __builtin_amdgcn_sched_barrier(0);  // the sixteen reads are one round trip
+                    // issued in the order the sweep consumes them (loads return in order: tile u then waits for its own cost only, vmcnt(15 - u) with the
+                    // next group's eight behind it), and on EVERY path -- a conditional gather makes the compiler's count of the loads in flight
+                    // conservative, and a sweep would wait for the next group's loads too
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) G.c[u] = *(const int16_t *)(connb + (lb[u] + (yy[u] & 0xFFFFu)));
+                    for (int u = 0; u < 8; ++u) {
+                        // (a dword load at the cost's 2-byte-aligned address; the sweep's add takes the low half, sign-extended.  A 16-bit load makes the
+                        // compiler extend the value in a separate instruction where it is carried round the loop -- behind a vmcnt(0); kgpu_dict_create pads
+                        // the matrix by four bytes)
+                        typedef uint32_t __attribute__((aligned(2))) u32_a2;
+                        G.c[u] = *(const u32_a2 *)(connb + (lb[u] + (yy[u] & 0xFFFFu)));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 };
                 auto sweep8 = [&](const Grp &G, uint32_t g) {
 #pragma unroll
@@ -575,7 +585,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                         const uint32_t cs = lds_ld<uint32_t>(na);
                         const uint2 e0 = lds_ld2((uint32_t)__builtin_amdgcn_readlane((int)d1, (int)(8 * g + u)) + min(j8, (D0 >> 18) & 0x38u));
                         __builtin_amdgcn_sched_barrier(0);
-                        const int32_t v0 = (int32_t)e0.x + G.c[u];
+                        const int32_t v0 = (int32_t)e0.x + (int32_t)(int16_t)G.c[u];
                         if (__builtin_expect(!(D0 & (1u << 28)), 0)) {   // a further chunk of the target group: (total, bucket word) lexicographic, one 64-bit compare
                             const bool take = (((int64_t)v0 << 32) | e0.y) < (((int64_t)rv << 32) | ry);
                             rv = take ? v0 : rv; ry = take ? e0.y : ry;
@@ -598,12 +608,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                 gather8(GA, 0);
                 if (prof) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
                 for (uint32_t g = 0; g < ng; g += 2) {
-                    if (g + 1 < ng) gather8(GB, g + 1);
+                    gather8(GB, (g + 1) & 7u);            // (past the window's last group: group 0 again, or padding -- loads nobody consumes, valid addresses)
                     if (stop_after != 6) sweep8(GA, g);   // (6: ablation timing -- every group's gather, no sweep; the KGPU_STOP(6) below then ends the sentence)
-                    if (g + 1 < ng) {
-                        if (g + 2 < ng) gather8(GA, g + 2);
-                        if (stop_after != 6) sweep8(GB, g + 1);
-                    }
+                    gather8(GA, (g + 2) & 7u);
+                    if (g + 1 < ng && stop_after != 6) sweep8(GB, g + 1);
                 }
                 if (stop_after == 6) { asm volatile("" :: "v"(GA.c[0]), "v"(GA.c[7]), "v"(GB.c[0]), "v"(GB.c[7])); }
             }
