@@ -415,7 +415,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         // ---- LDS carve, part 2: buckets, node arrays, tile list ---------------------
         off = align_up(off, 8);
         uint2 *bk = (uint2 *)(smem + off);          off += 8 * (Nb + 2);  // bucket (= edges[e]): {dp, 2 * right | node << 16}; [Nb]: sink for EOS; [Nb + 1]: the absent candidate
-        uint2 *node = (uint2 *)(smem + off);        off += 8 * N;   // {word cost (i16) | bucket slot of the node << 16, byte offset of the node's matrix row (left * rows * 2)};
+        uint2 *node = (uint2 *)(smem + off);        off += 8 * (N + 1);  // {word cost (i16) | bucket slot of the node << 16, byte offset of the node's matrix row (left * rows * 2)}; [N]: the padding tiles' target
                                                                     // the sweep stores the best predecessor into the low half of .y once the node's costs are gathered
         int32_t *nSid = (int32_t *)(smem + off);    off += 4 * N;   // +id known, -id unknown, 0 dummy
         uint16_t *nStart = (uint16_t *)(smem + off); off += 2 * N;
@@ -502,6 +502,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             bk[Nb + 1] = make_uint2(0x7FFEFFFFu, 0u);  // what a position without predecessors relaxes from: a total no real one reaches (real <= INF + 32767) that
                                                        // cannot overflow when a connection cost and a word cost are added, and stays >= INF when they are negative
             node[0] = make_uint2(0u, NONE16);          // ... and no predecessor (the backtrace stops here)
+            node[N] = make_uint2(0u, 0u);              // what a padding tile gathers for: row 0 of the matrix, never swept, so never overwritten
         }
         wave_sync();
         {   // the match buffer is dead now: give back the pages beyond the tile list
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                 }
             }
         }
-        const uint32_t null0 = (a_node + 8 * (N - 1)) | (1u << 28);   // padding: a target group that is never reduced (its gather reads M[BOS][EOS]: always in the matrix)
+        const uint32_t null0 = (a_node + 8 * N) | (1u << 28);   // padding: a target group that is never reduced (its gather reads M[BOS's right][0]: always in the matrix)
         if (lane < NTp - NT) tiles[NT + lane] = make_uint2(null0, a_bk);
         wave_sync();
         KGPU_TICK(5);
@@ -547,10 +548,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             int32_t rv = 0; uint32_t ry = 0;   // running minimum of the target group in progress
             struct Grp { uint32_t c[8]; };   // per tile of a group: the lane's connection cost (addresses are recomputed by the sweep: the kernel stays within 96
                                             // VGPRs, so that the small kernels of other batches' chains still find registers on a chip full of these wavefronts)
-            for (uint32_t w0 = 0; w0 < NTp; w0 += 64) {       // a window of 64 descriptors in registers, read out with v_readlane
-                const uint2 dd = w0 + lane < NTp ? tiles[w0 + lane] : make_uint2(null0, a_bk);
+            for (uint32_t w0 = 0; w0 < NTp; w0 += 56) {       // a window of 56 descriptors (seven groups) in registers, read out with v_readlane; lanes 56..63: padding
+                const uint2 dd = (lane < 56 && w0 + lane < NTp) ? tiles[w0 + lane] : make_uint2(null0, a_bk);
                 const uint32_t d0 = dd.x, d1 = dd.y;
-                const uint32_t ng = min(8u, (NTp - w0) >> 3);
+                const uint32_t ng = min(7u, (NTp - w0) >> 3);
                 auto gather8 = [&](Grp &G, uint32_t g) {
                     // every lane loads: lanes past Tt / Pt repeat the tile's last target / predecessor (the same address as their neighbour's: the same
                     // cache line; in the sweep a repeated candidate changes no minimum) -- no exec mask anywhere: a masked load would have to merge into
@@ -608,9 +609,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                 gather8(GA, 0);
                 if (prof) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
                 for (uint32_t g = 0; g < ng; g += 2) {
-                    gather8(GB, (g + 1) & 7u);            // (past the window's last group: group 0 again, or padding -- loads nobody consumes, valid addresses)
-                    if (stop_after != 6) sweep8(GA, g);   // (6: ablation timing -- every group's gather, no sweep; the KGPU_STOP(6) below then ends the sentence)
-                    gather8(GA, (g + 2) & 7u);
+                    gather8(GB, g + 1 < ng ? g + 1 : 7u);   // (past the window's last group: the padding lanes -- loads nobody consumes, from an address that is always valid;
+                                                            // NOT a group already swept: its nodes' row offsets have their best predecessors in the low half by now)
+                    if (stop_after != 6) sweep8(GA, g);     // (6: ablation timing -- every group's gather, no sweep; the KGPU_STOP(6) below then ends the sentence)
+                    gather8(GA, g + 2 < ng ? g + 2 : 7u);
                     if (g + 1 < ng && stop_after != 6) sweep8(GB, g + 1);
                 }
                 if (stop_after == 6) { asm volatile("" :: "v"(GA.c[0]), "v"(GA.c[7]), "v"(GB.c[0]), "v"(GB.c[7])); }

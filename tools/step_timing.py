@@ -36,9 +36,9 @@ tmS, steps, slow, slowsteps, sent, pool, N, desc = tot[:8]
 idle, life = tot[8], tot[9]
 ph = np.zeros(7)
 for c in ctxs: ph += np.array(list(c.work().values()), dtype=float)
-names = ["load", "decode", "walk", "scan", "emit", "gather+sweep", "backtrace+tokens"]
-print("  phases (shader cycles per sentence): " + ", ".join(f"{nm} {v / N:.0f}" for nm, v in zip(names, ph)) + f"; gather alone {(ph[5] - tmS) / N:.0f}")
+names = ["load", "decode", "walk", "scan", "emit + tiles", "stage B (tile gather + sweep)", "backtrace+tokens"]
+print("  phases (shader cycles per sentence): " + ", ".join(f"{nm} {v / N:.0f}" for nm, v in zip(names, ph)) )
 print(f"n={n} in flight={Q}: {6 * Q * n / dt / 1e6:.1f} M sentences/s; per sentence (shader cycles): whole {sent / N:.0f}, "
-      f"wait for pages {pool / N:.0f}, sweep {tmS / N:.0f} over {steps / N:.1f} steps = {tmS / steps:.0f} per step; "
+      f"wait for pages {pool / N:.0f}, "
       f"wavefront lifetime {life / N:.0f}, of which none (finished, its workgroup still alive) {idle / N:.0f} = {idle / max(life + idle, 1) * 100:.1f} % of the slot time; "
-      f"slow-path steps {slowsteps / steps * 100:.1f} % taking {slow / max(slowsteps, 1):.0f} each = {slow / tmS * 100:.0f} % of the sweep; descriptor set-up {desc / N:.0f}")
+      f"")
