@@ -57,6 +57,13 @@ void merge_slice(const MergeSrc *src, int G, uint64_t a, uint64_t b, uint64_t ba
         tok_offsets[j] = run;
         if (tokens) expand_tokens(sx.rec + t0, sx.toff + k, sx.first + 2 * k, 1, tokens + run, stream);   // (one sentence: the records of shard g's local sentence k)
         if (out8) {
+#if defined(__x86_64__)
+            if (stream) {   // (as the 24-byte expansion: hundreds of megabytes nobody reads back soon -- an ordinary store first reads every line it overwrites)
+                const long long *in = (const long long *)(sx.rec + t0);
+                long long *o = (long long *)(out8 + run);
+                for (uint64_t k = 0, e = t1 - t0; k < e; ++k) _mm_stream_si64(o + k, in[k]);
+            } else
+#endif
             if (t1 > t0) std::memcpy(out8 + run, sx.rec + t0, (size_t)(t1 - t0) * sizeof(kgpu_token8));
             first_out[2 * j] = sx.first[2 * k]; first_out[2 * j + 1] = sx.first[2 * k + 1];
         }
@@ -64,7 +71,7 @@ void merge_slice(const MergeSrc *src, int G, uint64_t a, uint64_t b, uint64_t ba
         run += t1 - t0;
         if (++g == Gu) { g = 0; ++k; }
     }
-    if (stream && tokens) expand_fence();
+    if (stream && (tokens || out8)) expand_fence();
 }
 
 // The caller's current device, restored on every exit path: the multi-device entry points visit every device on the calling thread.
