@@ -191,7 +191,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         uint32_t tk = 0;
         if (lane == 0) tk = atomicAdd(ticket, 1u);
         tk = bcast32(tk);
-        if (!work_next_at(io, a, (uint64_t)blockIdx.x + (uint64_t)gridDim.x * tk, s)) break;
+        // ticket tk of workgroup b -> list entry (tk / W) * (G W) + b W + tk % W: W CONSECUTIVE entries per workgroup and round -- neighbours in the text (their
+        // offsets and bytes share cache lines) and, when the list is ordered by length (k_order_by_length), sentences that finish together: a workgroup keeps its
+        // LDS until its last wavefront is through
+        if (!work_next_at(io, a, (uint64_t)(tk / W) * ((uint64_t)gridDim.x * W) + (uint64_t)blockIdx.x * W + tk % W, s)) break;
 #endif
         const uint64_t b0 = a.offsets[s];
         const uint64_t Bl = a.offsets[s + 1] - b0;
@@ -716,7 +719,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
     // control block and the sequence number the host is polling.
     if (a.fused_host) {
         const uint32_t total_waves = gridDim.x * W;
-        const uint64_t my = (uint64_t)blockIdx.x + (uint64_t)gridDim.x * wave;
+        const uint64_t my = (uint64_t)blockIdx.x * W + wave;
         __threadfence();  // release: status, token count, staged tokens of my sentence
         if (lane == 0) atomicAdd(&a.ctl->waves_done, 1u);
         bool met = false;

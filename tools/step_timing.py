@@ -16,6 +16,8 @@ if os.environ.get("STEP_LEN"):  # only sentences of lo..hi characters (how much 
     sents = [x for x in synth.make_corpus(sd, 40 * n, 1, kind) if lo <= len(x) <= hi][:n]
     assert len(sents) == n, len(sents)
     print("sentences of", lo, "..", hi, "characters, mean", sum(map(len, sents)) / n)
+if os.environ.get("STEP_SORT"):  # what ordering the batch by length would buy (upper bound: here the host sorts)
+    sents.sort(key=lambda x: len(x.encode("utf-8")))
 tok = Tokenizer(sd.dict); dev = torch.device("cuda", 0)
 utf8, offs = pack_sentences(sents); cap = int(offs[-1]) + n
 du, do = torch.from_numpy(utf8.copy()).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev)
