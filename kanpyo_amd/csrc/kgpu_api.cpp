@@ -553,11 +553,11 @@ static int next_event(kgpu_ctx *c, hipEvent_t *ev) {
 static int ctx_pick_chain(kgpu_ctx *c, uint64_t n, uint64_t total_bytes, bool dump) {
     const unsigned lim = c->plan.window_first_bytes;   // (KGPU_WINDOW_FIRST, read with the launch plan when the context is created)
     c->window_first = lim && n && c->plan.n_pools && c->plan.window_lds_bytes && !dump && c->stop_after == 0 && !c->no_window && total_bytes >= (uint64_t)lim * n;
-    if (c->own_stream) return KGPU_OK;
+    if (c->own_stream) { c->h2d_queued = false; return KGPU_OK; }
     hipStream_t want = c->short_stream;
     // ... and so does a pool-first chain whose last batch sent an eighth or more of its sentences on to the windowed kernel: its launches behind the pool
     // kernel are the long ones (cfg 3 in batches of 4096: 15.4 -> 17.5 M sentences/s on eight streams; a pool-ONLY chain loses there: cfg 2 101 -> 86)
-    if ((c->window_first || c->win_share_q8 >= 32) && planned_long_streams()) {
+    if ((c->window_first || c->long_share) && planned_long_streams()) {
         if (!c->long_stream) {
             kgpu_dict *d = c->dict;
             std::lock_guard<std::mutex> g(d->pool_mu);
@@ -571,10 +571,15 @@ static int ctx_pick_chain(kgpu_ctx *c, uint64_t n, uint64_t total_bytes, bool du
         if (c->long_stream) want = c->long_stream;
     }
     if (want != c->stream) {
-        HIPCHECK(hipEventRecord(c->switch_ev, c->stream));
-        HIPCHECK(hipStreamWaitEvent(want, c->switch_ev, 0));
+        // only what THIS call queued on the old stream (a host-buffer path's H2D copy) has to be in front of the batch; without it no ordering is needed (the
+        // context's previous batch is complete) -- and an event on a shared stream would put the batch behind the other contexts' whole backlog there
+        if (c->h2d_queued) {
+            HIPCHECK(hipEventRecord(c->switch_ev, c->stream));
+            HIPCHECK(hipStreamWaitEvent(want, c->switch_ev, 0));
+        }
         c->stream = want;
     }
+    c->h2d_queued = false;
     return KGPU_OK;
 }
 
@@ -622,7 +627,7 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
         // sentences/s, at 65 536 23.9 -> 25.3 -- and in small batches (one sentence per wavefront slot: the pool launch lasts as long as its longest sentence) it
         // routes a little earlier (56 of its 64 pages of 312 B instead of all).  profiles/experiments/r05_long_chains.txt, sections 5 and 8.
         LaunchPlan pl = c->plan;
-        if (pools_now > 0 && c->win_share_q8 >= 32 && pl.pool_limit_auto && pl.alt_pool_workgroups > 0) {
+        if (pools_now > 0 && c->long_share && pl.pool_limit_auto && pl.alt_pool_workgroups > 0) {
             pl.pool_bytes[0] = pl.alt_pool_bytes; pl.pool_waves[0] = pl.alt_pool_waves; pl.pool_workgroups[0] = pl.alt_pool_workgroups;
             pl.pool_max_pages[0] = a.n <= 4u * 4096u ? 56u : 64u;
         }
@@ -641,7 +646,7 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
     {
         c->h_ctl->pack_overflow = 0;  // set by the compaction's workgroups in the host copy directly; this context's previous batch has been synced
         static const int scan_small = [] { const char *e = getenv("KGPU_SCAN_SMALL"); return e ? atoi(e) : -1; }();   // (measurement: 0 never, 1 always; default: behind chains with a windowed launch)
-        const bool small_wgs = scan_small >= 0 ? scan_small == 1 : (a.n && c->last_window && (c->last_pools == 0 || c->win_share_q8 >= 32));
+        const bool small_wgs = scan_small >= 0 ? scan_small == 1 : (a.n && c->last_window && (c->last_pools == 0 || c->long_share));
         hipError_t e = (hipError_t)launch_scan_compact(a, c->h_ctl_dev, c->stream, small_wgs, scan_small == 2);
         if (e != hipSuccess) { set_error("scan/compact launch: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     }
@@ -840,8 +845,10 @@ extern "C" int kgpu_ctx_sync(kgpu_ctx *c, uint64_t *n_tokens) {
             else if (first_tail) c->dict->tail_batches.fetch_sub(8, std::memory_order_relaxed);
         }
     }
-    if (c->last.n && c->last_pools > 0)
+    if (c->last.n && c->last_pools > 0) {
         c->win_share_q8 = c->plan.window_lds_bytes ? (uint32_t)std::min<uint64_t>(256, (uint64_t)c->h_ctl->ovf_count[c->last_pools - 1] * 256 / c->last.n) : 0u;
+        c->long_share = c->long_share ? c->win_share_q8 >= 16 : c->win_share_q8 >= 32;   // (entered at an eighth, left below a sixteenth: a share that hovers around the limit does not flap between streams)
+    }
     if (c->last.n && c->last_pools == 0 && c->last_window && c->plan.n_pools) {
         // a chain that started with the windowed kernel: what it left arms the general kernel behind it, as above
         if (c->h_ctl->ovf_count[c->last_team ? 1 : 0] > 0) c->dict->tail_batches.store(64, std::memory_order_relaxed);
@@ -1027,6 +1034,7 @@ static int host_job_submit(HostJob &j, const uint8_t *utf8, const uint64_t *offs
         return rc;
     hipError_t e;
     if (total && (e = hipMemcpyAsync(c->in_utf8.p, utf8 + base, (size_t)total, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { set_error("H2D utf8: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
+    c->h2d_queued = true;
     if ((e = hipMemcpyAsync(c->in_off.p, j.rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { set_error("H2D offsets: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     if ((rc = kgpu_tokenize_device(c, (const uint8_t *)c->in_utf8.p, (const uint64_t *)c->in_off.p, n, total,
                                    (kgpu_token *)c->out_tok.p, cap, (uint64_t *)c->out_off.p, (uint8_t *)c->out_status.p)))
@@ -1173,6 +1181,7 @@ static int pipe_submit(PipeJob &j, const uint8_t *utf8, const uint64_t *offsets,
     hipError_t e;
     uint8_t *dblk = (uint8_t *)c->in_block.p;
     if (pinned_in) {
+        c->h2d_queued = true;
         if ((e = hipMemcpyAsync(dblk, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
             (total && (e = hipMemcpyAsync(dblk + in_off_bytes, utf8 + base, (size_t)total, hipMemcpyHostToDevice, c->stream)) != hipSuccess)) {
             set_error("H2D input: %s", hipGetErrorString(e)); return KGPU_ERR_HIP;
@@ -1180,6 +1189,7 @@ static int pipe_submit(PipeJob &j, const uint8_t *utf8, const uint64_t *offsets,
     } else {
         std::memcpy(c->pin_in.h, off, (size_t)(n + 1) * 8);
         if (total) parallel_copy((uint8_t *)c->pin_in.h + in_off_bytes, utf8 + base, (size_t)total);
+        c->h2d_queued = true;
         if ((e = hipMemcpyAsync(dblk, c->pin_in.h, in_off_bytes + (size_t)total, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { set_error("H2D input block: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     }
     uint8_t *po = (uint8_t *)c->pin_out.d;
@@ -1723,6 +1733,7 @@ extern "C" int kgpu_lattice_dump(kgpu_dict *d, const uint8_t *utf8, uint64_t len
     auto fail = [&](hipError_t e, const char *what) { set_error("kgpu_lattice_dump: %s: %s", what, hipGetErrorString(e)); c->ctl_dirty = true; give_back(); return KGPU_ERR_HIP; };
     hipError_t e;
     if (len && (e = hipMemcpyAsync(c->in_utf8.p, utf8, (size_t)len, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return fail(e, "H2D");
+    c->h2d_queued = true;
     if ((e = hipMemcpyAsync(c->in_off.p, offs, 16, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return fail(e, "H2D");
     for (;;) {
         BatchArgs a{};

@@ -167,6 +167,7 @@ int shard_submit(MultiCall &mc, int g, uint64_t c) {
     }
     hipError_t e;
     uint8_t *dblk = (uint8_t *)ctx->in_block.p;
+    ctx->h2d_queued = true;
     if ((e = hipMemcpyAsync(dblk, ctx->pin_in.h, in_off_bytes + (size_t)total, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) { set_error("H2D input block: %s", hipGetErrorString(e)); return KGPU_ERR_HIP; }
     uint8_t *po = (uint8_t *)ctx->pin_out.d;
     return tokenize_device_impl(ctx, dblk + in_off_bytes, (const uint64_t *)dblk, m, total, nullptr, (kgpu_token8 *)po, (uint32_t *)(po + j.off_first), po + j.off_status,

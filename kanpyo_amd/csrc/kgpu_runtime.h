@@ -111,6 +111,8 @@ struct kgpu_ctx {
     int counted_long = 0;               // what the pending batch added to kgpu_dict::long_sentences_in_flight
     uint32_t win_share_q8 = 0;          // share of the last pool-first batch's sentences that the pools routed to the windowed kernel (x256): an eighth or more
                                         // and the next batch runs on the context's long stream too (cfg 3: a third of the sentences, three quarters of the characters)
+    bool long_share = false;            // ... with hysteresis: entered at win_share_q8 >= 32, left below 16
+    bool h2d_queued = false;            // a host-buffer path has queued this batch's H2D copy on `stream` (ctx_pick_chain orders the batch behind it if it switches streams)
     hipEvent_t switch_ev = nullptr;     // orders a batch behind what was queued on the stream the context used before
     hipEvent_t done_ev = nullptr;  // recorded behind the batch's last kernel: contexts may share a stream
     Control *d_ctl = nullptr;
