@@ -12,7 +12,7 @@ done
 python - "$OUT" $STOPS <<'PY'
 import csv, glob, sys
 from collections import defaultdict
-names = {1: "load", 2: "decode", 3: "walk", 4: "scan", 5: "emit", 6: "gather", 7: "sweep", 0: "all"}
+names = {1: "load", 2: "decode", 3: "walk", 4: "scan", 5: "emit", 6: "gather", 7: "sweep", 0: "all"}  # (round 6: 5 = emit + tile list, 6 = the tile gathers alone, 7 = + the sweep)
 prev = defaultdict(float)
 stops = [int(x) for x in sys.argv[2:]]
 first = True
