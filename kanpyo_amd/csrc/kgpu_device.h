@@ -284,13 +284,6 @@ __device__ __forceinline__ uint32_t utf8_decode_lead(uint32_t b, uint32_t k, uin
 // ---- LDS access by absolute 32-bit LDS address (the sweep keeps ready-made addresses in its descriptors; going through `array + offset` makes the
 // compiler add the array's link-time base -- zero -- to every address, on the VALU)
 #define KGPU_LDS(T) __attribute__((address_space(3))) T
-// Stride of a target's row in the pair table, in half-words.  KGPU_PAIR_ODD (measurement build, round 5): an odd stride, so that the gather's lane-per-target
-// row writes do not all fall into the banks of a power-of-two stride (profiles/experiments/r05_pair_table_stride.txt: what it buys).
-#ifdef KGPU_PAIR_ODD
-#define KGPU_PSTRIDE(P) ((P) | 1u)
-#else
-#define KGPU_PSTRIDE(P) (P)
-#endif
 template <class T> __device__ __forceinline__ T lds_ld(uint32_t addr) { return *(const KGPU_LDS(T) *)(uintptr_t)addr; }
 template <class T> __device__ __forceinline__ void lds_st(uint32_t addr, T v) { *(KGPU_LDS(T) *)(uintptr_t)addr = v; }
 __device__ __forceinline__ uint2 lds_ld2(uint32_t addr) { const uint64_t v = lds_ld<uint64_t>(addr); return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); }
@@ -343,97 +336,98 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t k) {  // over the 64 l
     return k;
 }
 
-// ---- THE Viterbi sweep step of the LDS kernels (kgpu_pool.hip, kgpu_window.hip): one start position, lattice.rs:116-142.
-// What a step costs is its dependent chain and its taken branches, not its arithmetic (measured on one wavefront alone: LDS write -> read 86 cycles,
-// three dependent DPP minima 43, a taken branch 32, an exec-masked block 64, descriptor read-out + scalar dispatch 52 -- tools/ubench).  So:
-//  * per-position descriptors are ready-made LDS byte addresses: D0 = address of nCS[t0] (18 bits) | T (7) << 18 | P (6) << 25 (bit 31 set / D0 == 0:
-//    not for this routine), D1 = address of the position's bucket bk[p0] (entries {dp, right | node << 16}), D2 = address of its pair costs (pair
-//    (ti, j) at ti * P + j, int16); a_ncs / a_pre / a_bk: the arrays' own addresses (pre[] is parallel to nCS[], half as wide);
-//  * three straight-line bodies chosen by ONE scalar compare chain: P <= 8 (pair (ti, j) on lane ti * 8 + j, eight targets per pass), P <= 16 (the same
-//    lanes take predecessors j and j + 8), P <= 32 (16 lanes per target, four targets per pass);
-//  * every load is unconditional and unclamped (an index past the arrays reads someone else's LDS or zero and is deselected afterwards); an absent
-//    candidate is a total no real one reaches (real <= INF + 32767) that still cannot overflow when the word cost is added -- so P = 0 needs no case;
-//  * no exec-masked region and no sinks: target groups past T redo target T - 1 -- same loads, same result, same stores to the same addresses;
-//  * two DPP group minima: the total, then -- strict '<' over ascending insertion order (lattice.rs:125,136) -- the WHOLE second bucket word among the
-//    ties: the node index is its upper half, so the minimum picks the smallest node, and a half-word store writes it;
-//  * tot < INF after the add = .min(INF) then strict '<' (lattice.rs:135-136); no fence: one wavefront's DS instructions execute in issue order.
-template <uint32_t LG>
-__device__ __forceinline__ void sweep_pass2(uint32_t lane, uint32_t tb, uint32_t T, uint32_t P, uint32_t acs, uint32_t apre, uint32_t a_bk, uint32_t D1, uint32_t D2) {
-    constexpr uint32_t G = 1u << LG;
-    const uint32_t j = lane & (G - 1u), ti = min(tb + (lane >> LG), T - 1u);
-    const bool j0v = j < P, j1v = j + G < P;
-    const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
-    const uint2 e0 = lds_ld2(D1 + 8 * j), e1 = lds_ld2(D1 + 8 * j + 8 * G);
-    const uint32_t am = D2 + 2 * (__umul24(ti, KGPU_PSTRIDE(P)) + j);
-    const int32_t pc0 = lds_ld<int16_t>(am), pc1 = lds_ld<int16_t>(am + 2 * G);
-    __builtin_amdgcn_sched_barrier(0);  // the five reads stay one round trip
-    constexpr int32_t ABSENT = 0x7FFEFFFF;
-    const int32_t v0 = j0v ? (int32_t)e0.x + pc0 : ABSENT;
-    const int32_t v1 = j1v ? (int32_t)e1.x + pc1 : ABSENT;
-    const int32_t vmin = group_min_i32<LG>(min(v0, v1));
-    const uint32_t n0 = v0 == vmin ? e0.y : 0xFFFFFFFFu, n1 = v1 == vmin ? e1.y : 0xFFFFFFFFu;
-    const uint32_t nmin = group_min_u32<LG>(min(n0, n1));
-    const int32_t tot = vmin + (int32_t)(int16_t)cs;
-    const bool ok = tot < INF;
-    lds_st<uint16_t>(apre + 2 * ti, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
-    lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
+// ---- STAGE B of the LDS kernels (kgpu_pool.hip, kgpu_window.hip) over a list of TILES: lattice.rs:116-142 with the connection costs of connection.rs:12-14.
+// A tile is up to 8 targets x 8 predecessors of one start position, pair (ti, j) on lane 8 ti + j; a position with T targets and P predecessors is
+// ceil(T / 8) x ceil(P / 8) tiles -- (a, b) = (target group, predecessor chunk), b fastest: a group's chunks are consecutive, the last one reduces and stores.
+// Descriptor (two words, built once per position by the kernel): D0 = LDS address of node[t0 + 8 a] (18 bits) | 8 (Tt - 1) << 18 (6 bits) | 8 (Pt - 1) << 24 (6) |
+// first chunk << 30 | last chunk << 31 (the two byte offsets ready-made: one s_bfe each where they are used), D1 = LDS address of bk[p0 + 8 b].  node[t] = {word cost (i16) | bucket slot of the node << 16, byte offset of the node's
+// matrix row (left * rows * 2)}; bk[] = bucket entries {dp, 2 * right | node index << 16} (the node index relative to whatever base the kernel uses).
+//   GATHER: the lane loads its own connection cost M[right(j)][left(ti)] from the matrix into a REGISTER (byte offset = row offset + 2 * right: one add) -- no
+//     pair table in LDS -- and a group of eight tiles is requested while the previous group is swept: the matrix's latency is off the dependency chain.
+//   SWEEP: dp of the predecessor + that cost; across a target group's chunks the running lexicographic minimum (total, then the bucket word whose upper half
+//     is the node index: strict '<' over ascending insertion order, lattice.rs:125,136); on the last chunk two DPP group minima, the word cost, .min(INF)
+//     (tot < INF after the add = .min(INF) then strict '<', lattice.rs:135-136), the stores: dp into the node's bucket slot, the best predecessor into the
+//     LOW HALF of node[t].y (the row offset is dead once the node's costs are gathered; 0xFFFF = none).
+// No exec mask anywhere: lanes past Tt / Pt repeat the tile's last target / predecessor -- the same loads (the same cache line as their neighbour's), the same
+// stores to the same addresses, and a repeated candidate changes no minimum.  (A masked load would have to merge into the register's old value and so wait for
+// every load in flight.)  What a step costs is its instruction count and its dependent chain (tools/ubench: LDS write -> read 86 cycles, three dependent DPP
+// minima 43, a taken branch 32): no fence per tile -- one wavefront's DS instructions execute in issue order.
+struct TileGroup { uint32_t c[8]; };   // per tile of a group: the lane's connection cost (a dword loaded at the cost's 2-byte-aligned address; the low half counts)
+constexpr uint32_t TILE_FIRST = 1u << 30, TILE_LAST = 1u << 31;
+__device__ __forceinline__ uint32_t tile_desc0(uint32_t a_node_t, uint32_t Tt, uint32_t Pt, bool first, bool last) {
+    return a_node_t | ((Tt - 1u) << 21) | ((Pt - 1u) << 27) | (first ? TILE_FIRST : 0u) | (last ? TILE_LAST : 0u);
 }
-__device__ __forceinline__ void sweep_pass1(uint32_t lane, uint32_t tb, uint32_t T, uint32_t P, uint32_t acs, uint32_t apre, uint32_t a_bk, uint32_t D1, uint32_t D2) {
-    const uint32_t j = lane & 7u, ti = min(tb + (lane >> 3), T - 1u);   // P <= 8 (87 % of the positions on the cfg 2 corpus): one candidate per lane
-    const bool j0v = j < P;
-    const uint32_t cs = lds_ld<uint32_t>(acs + 4 * ti);
-    const uint2 e0 = lds_ld2(D1 + 8 * j);
-    const int32_t pc0 = lds_ld<int16_t>(D2 + 2 * (__umul24(ti, KGPU_PSTRIDE(P)) + j));
-    __builtin_amdgcn_sched_barrier(0);
-    const int32_t v0 = j0v ? (int32_t)e0.x + pc0 : 0x7FFEFFFF;
-    const int32_t vmin = group_min_i32<3>(v0);
-    const uint32_t nmin = group_min_u32<3>(v0 == vmin ? e0.y : 0xFFFFFFFFu);
-    const int32_t tot = vmin + (int32_t)(int16_t)cs;
-    const bool ok = tot < INF;
-    lds_st<uint16_t>(apre + 2 * ti, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
-    lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
-}
-// One position with 1 <= T <= 127 targets and P <= 32 predecessors, described by (D0, D1, D2) as above.
-__device__ __forceinline__ void sweep_position_fast(uint32_t lane, uint32_t D0, uint32_t D1, uint32_t D2, uint32_t a_ncs, uint32_t a_pre, uint32_t a_bk) {
-    const uint32_t acs = D0 & 0x3FFFFu, T = (D0 >> 18) & 127u, P = D0 >> 25;
-    const uint32_t apre = a_pre + ((acs - a_ncs) >> 1);  // pre[t0]
-    if (P <= 8) {
-        sweep_pass1(lane, 0u, T, P, acs, apre, a_bk, D1, D2);
-        if (T > 8) for (uint32_t tb = 8; tb < T; tb += 8) sweep_pass1(lane, tb, T, P, acs, apre, a_bk, D1, D2);
-    } else if (P <= 16) {
-        sweep_pass2<3>(lane, 0u, T, P, acs, apre, a_bk, D1, D2);
-        if (T > 8) for (uint32_t tb = 8; tb < T; tb += 8) sweep_pass2<3>(lane, tb, T, P, acs, apre, a_bk, D1, D2);
-    } else {
-        for (uint32_t tb = 0; tb < T; tb += 4) sweep_pass2<4>(lane, tb, T, P, acs, apre, a_bk, D1, D2);
+// d0 / d1: a window of descriptors, one per lane; the group's tiles are lanes i0 .. i0 + 7.  Issued in the order the sweep consumes them (loads return in
+// order: tile u then waits for its own cost only, vmcnt(15 - u) with the next group's eight behind it) and on EVERY path -- a conditional gather makes the
+// compiler's count of the loads in flight conservative and a sweep would wait for the next group's loads too.  The kernel's matrix copy is padded by four
+// bytes (kgpu_dict_create): a 16-bit load would get its sign extension as a separate instruction behind vmcnt(0) where the value is carried round the loop.
+__device__ __forceinline__ void tile_gather8(TileGroup &G, uint32_t d0, uint32_t d1, uint32_t i0, uint32_t tg8, uint32_t j8, const uint8_t *connb) {
+    uint32_t lb[8], yy[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)(i0 + u));
+        const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)(i0 + u));
+        lb[u] = lds_ld<uint32_t>((D0 & 0x3FFFFu) + min(tg8, (D0 >> 18) & 0x3Fu) + 4u);
+        yy[u] = lds_ld<uint32_t>(D1 + min(j8, (D0 >> 24) & 0x3Fu) + 4u);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the sixteen reads are one round trip
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        typedef uint32_t __attribute__((aligned(2))) u32_a2;
+        G.c[u] = *(const u32_a2 *)(connb + (lb[u] + (yy[u] & 0xFFFFu)));
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
-// The three descriptor words of a position for sweep_position_fast (fast = 1 <= T <= 127 and P <= 32 and nothing else in the way; else bit 31).
-__device__ __forceinline__ uint32_t sweep_desc0(uint32_t a_ncs, uint32_t t0, uint32_t T, uint32_t P, bool fast) {
-    return (a_ncs + 4 * t0) | (fast ? (T << 18) | (P << 25) : 1u << 31);
-}
-
-// ---- the connection-cost gather of one target (connection.rs:12-14): M[right(j)][left(t)] for the P predecessors of its position into the LDS pair
-// table, eight independent gathers in flight per lane (two groups of four, the second only where the row goes on; the last group of a row padded
-// with a repeat of its final entry: ceil(P / 8) dependent rounds).  bk: the position's bucket (its .y carries the right id),
-// col: the target's row of the matrix, out: the target's row of the pair table.
-__device__ __forceinline__ void gather_target_row(const uint2 *bk, uint32_t P, const int16_t *col, int16_t *out) {
-    for (uint32_t j = 0; j < P; j += 8) {
-        const uint32_t j1 = min(j + 1, P - 1), j2 = min(j + 2, P - 1), j3 = min(j + 3, P - 1);
-        const bool more = j + 4 < P;
-        const uint32_t j4 = j + 4, j5 = min(j + 5, P - 1), j6 = min(j + 6, P - 1), j7 = min(j + 7, P - 1);
-        const uint32_t r0 = bk[j].y & 0xFFFFu, r1 = bk[j1].y & 0xFFFFu, r2 = bk[j2].y & 0xFFFFu, r3 = bk[j3].y & 0xFFFFu;
-        uint32_t r4 = 0, r5 = 0, r6 = 0, r7 = 0;
-        if (more) { r4 = bk[j4].y & 0xFFFFu; r5 = bk[j5].y & 0xFFFFu; r6 = bk[j6].y & 0xFFFFu; r7 = bk[j7].y & 0xFFFFu; }
-        const int16_t c0 = col[r0], c1 = col[r1], c2 = col[r2], c3 = col[r3];
-        int16_t c4 = 0, c5 = 0, c6 = 0, c7 = 0;
-        if (more) { c4 = col[r4]; c5 = col[r5]; c6 = col[r6]; c7 = col[r7]; }
-        out[j] = c0; out[j1] = c1; out[j2] = c2; out[j3] = c3;
-        if (more) { out[j4] = c4; out[j5] = c5; out[j6] = c6; out[j7] = c7; }
+// cnt: tiles of the group to sweep (8, or fewer at the end of a list that is not padded: GUARD); rv / ry: the running minimum of the target group in progress.
+template <bool GUARD>
+__device__ __forceinline__ void tile_sweep8(const TileGroup &G, uint32_t d0, uint32_t d1, uint32_t i0, uint32_t cnt, uint32_t tg8, uint32_t j8, uint32_t a_bk, int32_t &rv, uint32_t &ry) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (GUARD && (uint32_t)u >= cnt) break;
+        const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)(i0 + u));
+        const uint32_t na = (D0 & 0x3FFFFu) + min(tg8, (D0 >> 18) & 0x3Fu);
+        const uint32_t cs = lds_ld<uint32_t>(na);
+        const uint2 e0 = lds_ld2((uint32_t)__builtin_amdgcn_readlane((int)d1, (int)(i0 + u)) + min(j8, (D0 >> 24) & 0x3Fu));
+        __builtin_amdgcn_sched_barrier(0);
+        const int32_t v0 = (int32_t)e0.x + (int32_t)(int16_t)G.c[u];
+        if (__builtin_expect(!(D0 & TILE_FIRST), 0)) {   // a further chunk of the target group: (total, bucket word) lexicographic, one 64-bit compare
+            const bool take = (((int64_t)v0 << 32) | e0.y) < (((int64_t)rv << 32) | ry);
+            rv = take ? v0 : rv; ry = take ? e0.y : ry;
+        } else { rv = v0; ry = e0.y; }
+        if (__builtin_expect((D0 & TILE_LAST) != 0, 1)) {
+            const int32_t vmin = group_min_i32<3>(rv);
+            const uint32_t nmin = group_min_u32<3>(rv == vmin ? ry : 0xFFFFFFFFu);
+            const int32_t tot = vmin + (int32_t)(int16_t)cs;
+            const bool ok = tot < INF;
+            lds_st<uint16_t>(na + 4u, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
+            lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
-// The row of the (frequency-ranked) connection matrix a target with left id L reads (connection.rs:12-14).  Layouts that put the pairs of one gather
-// instruction into fewer cache lines -- 8 x 8 tiles (rounds 2-3), the transpose -- measure the same as this one (profiles/experiments/r04_matrix_layouts.txt).
-__device__ __forceinline__ const int16_t *conn_row(const DictView &d, uint32_t L) { return d.conn + (size_t)d.conn_rows * L; }
+// Tiles [ta, tb) of the list at `tiles` (LDS), in order.  PADDED: tb - ta is a multiple of eight (the kernel padded its list with tiles that store nothing),
+// no per-tile guard.  null_tile: what the lanes past the end hold -- a descriptor whose gather address is always valid and that is never swept (a gather past
+// the last group reads it: NOT a group already swept, whose nodes' row offsets have their best predecessors in the low half by now).  sweep_on = false:
+// measurement (every group's gather, no sweep).
+template <bool PADDED>
+__device__ __forceinline__ void tiles_run(const uint2 *tiles, uint32_t ta, uint32_t tb, uint2 null_tile, uint32_t lane, uint32_t a_bk, const uint8_t *connb, bool sweep_on) {
+    const uint32_t j8 = 8u * (lane & 7u), tg8 = lane & 0x38u;   // lane = 8 ti + j
+    int32_t rv = 0; uint32_t ry = 0;
+    for (uint32_t w0 = ta; w0 < tb; w0 += 56) {       // a window of 56 descriptors (seven groups) in registers, read out with v_readlane; lanes 56..63: padding
+        const uint2 dd = (lane < 56 && w0 + lane < tb) ? tiles[w0 + lane] : null_tile;
+        const uint32_t d0 = dd.x, d1 = dd.y;
+        const uint32_t nt = min(56u, tb - w0), ng = (nt + 7u) >> 3;
+        TileGroup GA, GB;
+        tile_gather8(GA, d0, d1, 0u, tg8, j8, connb);
+        for (uint32_t g = 0; g < ng; g += 2) {
+            tile_gather8(GB, d0, d1, g + 1 < ng ? 8 * (g + 1) : 56u, tg8, j8, connb);
+            if (sweep_on) tile_sweep8<!PADDED>(GA, d0, d1, 8 * g, nt - 8 * g, tg8, j8, a_bk, rv, ry);
+            tile_gather8(GA, d0, d1, g + 2 < ng ? 8 * (g + 2) : 56u, tg8, j8, connb);
+            if (g + 1 < ng && sweep_on) tile_sweep8<!PADDED>(GB, d0, d1, 8 * (g + 1), nt - 8 * (g + 1), tg8, j8, a_bk, rv, ry);
+        }
+        if (!sweep_on) asm volatile("" :: "v"(GA.c[0]), "v"(GA.c[7]), "v"(GB.c[0]), "v"(GB.c[7]));
+    }
+}
 
 // Work-list plumbing shared by the kernels of a launch chain: launch k takes its sentence ids
 // from list `in_list` (nullptr = identity over [0, n)) and pushes the ones it does not

@@ -514,9 +514,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         }
         const uint32_t lds0 = (uint32_t)(uintptr_t)(KGPU_LDS(uint8_t) *)pool;  // absolute LDS addresses, wave-uniform: SGPRs
         const uint32_t a_node = bcast32(lds0 + (uint32_t)((uint8_t *)node - pool)), a_bk = bcast32(lds0 + (uint32_t)((uint8_t *)bk - pool));
-        // 3c, lane = start position: its tiles.  D0 = address of node[t0 + 8 a] (18 bits) | (Tt - 1) << 18 (3) | (Pt - 1) << 21 (3) | first b << 28 | last b << 29,
-        // D1 = address of bk[p0 + 8 b]; (a, b) = (target group, predecessor chunk), b fastest: a group's chunks are consecutive, the last one reduces and
-        // stores.  A position without predecessors (P = 0) is one chunk of one absent candidate (bk[Nb + 1]): its targets stay at INF with no predecessor.
+        // 3c, lane = start position: its tiles (the descriptors of kgpu_device.h: tile_desc0); (a, b) = (target group, predecessor chunk), b fastest.  A position
+        // without predecessors (P = 0) is one chunk of one absent candidate (bk[Nb + 1]): its targets stay at INF with no predecessor.
         for (uint32_t q0 = 0; q0 <= C; q0 += 64) {
             const uint32_t q = q0 + lane;
             if (q <= C) {
@@ -524,102 +523,23 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                 const uint32_t p0 = Pr ? p0r : Nb + 1, P = Pr ? Pr : 1u;
                 uint32_t k = ebase[q];
                 const uint32_t kb = (P + 7u) >> 3;
-                for (uint32_t ta = 0; ta < T; ta += 8) {
-                    const uint32_t w0 = (a_node + 8 * (t0 + ta)) | ((min(8u, T - ta) - 1u) << 18);
+                for (uint32_t ta = 0; ta < T; ta += 8)
                     for (uint32_t b = 0; b < kb; ++b, ++k)
-                        tiles[k] = make_uint2(w0 | ((min(8u, P - 8 * b) - 1u) << 21) | ((b == 0) << 28) | ((b == kb - 1) << 29), a_bk + 8 * (p0 + 8 * b));
-                }
+                        tiles[k] = make_uint2(tile_desc0(a_node + 8 * (t0 + ta), min(8u, T - ta), min(8u, P - 8 * b), b == 0, b == kb - 1), a_bk + 8 * (p0 + 8 * b));
             }
         }
-        const uint32_t null0 = (a_node + 8 * N) | (1u << 28);   // padding: a target group that is never reduced (its gather reads M[BOS's right][0]: always in the matrix)
+        const uint32_t null0 = (a_node + 8 * N) | TILE_FIRST;   // padding: a target group that is never reduced (its gather reads M[BOS's right][0]: always in the matrix)
         if (lane < NTp - NT) tiles[NT + lane] = make_uint2(null0, a_bk);
         wave_sync();
         KGPU_TICK(5);
         KGPU_STOP(5)
         KGPU_ARGS();
         uint64_t cyc_gather = 0;
-        // ---- phase 4: stage B over the tile list (lattice.rs:116-142; connection.rs:12-14) ----
-        // Per tile, lane 8 ti + j holds the pair (target ti, predecessor j).  GATHER: the lane loads its own connection cost M[right(j)][left(ti)]
-        // from the matrix into a REGISTER (byte offset = the node's row offset + 2 * right: one add) -- no pair table in LDS, and a group of eight
-        // tiles is requested while the previous group is swept, so the matrix's latency is off the dependency chain.  SWEEP: dp of the predecessor
-        // + that cost, the running lexicographic minimum (total, then the bucket word whose upper half is the node index: strict '<' over ascending
-        // insertion order, lattice.rs:125,136) across a target group's chunks, and on its last chunk two DPP group minima, the word cost, .min(INF),
-        // the stores.  Lanes past Tt redo target Tt - 1 (same loads, same stores); lanes past Pt carry an absent candidate no real total reaches.
+        // ---- phase 4: stage B over the tile list (kgpu_device.h: tiles_run -- the gather into registers, the sweep; lattice.rs:116-142, connection.rs:12-14) ----
         {
-            const uint32_t j8 = 8u * (lane & 7u), tg8 = lane & 0x38u;   // lane = 8 ti + j
-            const uint8_t *connb = (const uint8_t *)d.conn;
-            int32_t rv = 0; uint32_t ry = 0;   // running minimum of the target group in progress
-            struct Grp { uint32_t c[8]; };   // per tile of a group: the lane's connection cost (addresses are recomputed by the sweep: the kernel stays within 96
-                                            // VGPRs, so that the small kernels of other batches' chains still find registers on a chip full of these wavefronts)
-            for (uint32_t w0 = 0; w0 < NTp; w0 += 56) {       // a window of 56 descriptors (seven groups) in registers, read out with v_readlane; lanes 56..63: padding
-                const uint2 dd = (lane < 56 && w0 + lane < NTp) ? tiles[w0 + lane] : make_uint2(null0, a_bk);
-                const uint32_t d0 = dd.x, d1 = dd.y;
-                const uint32_t ng = min(7u, (NTp - w0) >> 3);
-                auto gather8 = [&](Grp &G, uint32_t g) {
-                    // every lane loads: lanes past Tt / Pt repeat the tile's last target / predecessor (the same address as their neighbour's: the same
-                    // cache line; in the sweep a repeated candidate changes no minimum) -- no exec mask anywhere: a masked load would have to merge into
-                    // the register's old value and so wait for the loads in flight
-                    uint32_t lb[8], yy[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)(8 * g + u));
-                        const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)(8 * g + u));
-                        lb[u] = lds_ld<uint32_t>((D0 & 0x3FFFFu) + min(tg8, (D0 >> 15) & 0x38u) + 4u);
-                        yy[u] = lds_ld<uint32_t>(D1 + min(j8, (D0 >> 18) & 0x38u) + 4u);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);  // the sixteen reads are one round trip
-                    // issued in the order the sweep consumes them (loads return in order: tile u then waits for its own cost only, vmcnt(15 - u) with the
-                    // next group's eight behind it), and on EVERY path -- a conditional gather makes the compiler's count of the loads in flight
-                    // conservative, and a sweep would wait for the next group's loads too
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        // (a dword load at the cost's 2-byte-aligned address; the sweep's add takes the low half, sign-extended.  A 16-bit load makes the
-                        // compiler extend the value in a separate instruction where it is carried round the loop -- behind a vmcnt(0); kgpu_dict_create pads
-                        // the matrix by four bytes)
-                        typedef uint32_t __attribute__((aligned(2))) u32_a2;
-                        G.c[u] = *(const u32_a2 *)(connb + (lb[u] + (yy[u] & 0xFFFFu)));
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                };
-                auto sweep8 = [&](const Grp &G, uint32_t g) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)(8 * g + u));
-                        const uint32_t na = (D0 & 0x3FFFFu) + min(tg8, (D0 >> 15) & 0x38u);
-                        const uint32_t cs = lds_ld<uint32_t>(na);
-                        const uint2 e0 = lds_ld2((uint32_t)__builtin_amdgcn_readlane((int)d1, (int)(8 * g + u)) + min(j8, (D0 >> 18) & 0x38u));
-                        __builtin_amdgcn_sched_barrier(0);
-                        const int32_t v0 = (int32_t)e0.x + (int32_t)(int16_t)G.c[u];
-                        if (__builtin_expect(!(D0 & (1u << 28)), 0)) {   // a further chunk of the target group: (total, bucket word) lexicographic, one 64-bit compare
-                            const bool take = (((int64_t)v0 << 32) | e0.y) < (((int64_t)rv << 32) | ry);
-                            rv = take ? v0 : rv; ry = take ? e0.y : ry;
-                        } else { rv = v0; ry = e0.y; }
-                        if (__builtin_expect((D0 & (1u << 29)) != 0, 1)) {
-                            const int32_t vmin = group_min_i32<3>(rv);
-                            const uint32_t nmin = group_min_u32<3>(rv == vmin ? ry : 0xFFFFFFFFu);
-                            const int32_t tot = vmin + (int32_t)(int16_t)cs;
-                            const bool ok = tot < INF;
-                            lds_st<uint16_t>(na + 4u, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
-                            lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
-                        }
-                        // no fence per tile: the LDS unit executes one wavefront's DS instructions in issue order, so the next
-                        // tile's reads see these writes; a fence would make every tile wait for the write acknowledgement
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                };
-                Grp GA, GB;
-                const uint64_t tg0 = prof ? __builtin_amdgcn_s_memtime() : 0;
-                gather8(GA, 0);
-                if (prof) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
-                for (uint32_t g = 0; g < ng; g += 2) {
-                    gather8(GB, g + 1 < ng ? g + 1 : 7u);   // (past the window's last group: the padding lanes -- loads nobody consumes, from an address that is always valid;
-                                                            // NOT a group already swept: its nodes' row offsets have their best predecessors in the low half by now)
-                    if (stop_after != 6) sweep8(GA, g);     // (6: ablation timing -- every group's gather, no sweep; the KGPU_STOP(6) below then ends the sentence)
-                    gather8(GA, g + 2 < ng ? g + 2 : 7u);
-                    if (g + 1 < ng && stop_after != 6) sweep8(GB, g + 1);
-                }
-                if (stop_after == 6) { asm volatile("" :: "v"(GA.c[0]), "v"(GA.c[7]), "v"(GB.c[0]), "v"(GB.c[7])); }
-            }
+            const uint64_t tg0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+            tiles_run<true>(tiles, 0u, NTp, make_uint2(null0, a_bk), lane, a_bk, (const uint8_t *)d.conn, stop_after != 6);   // (6: ablation timing -- the gathers alone)
+            if (prof && stop_after == 6) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
         }
         wave_sync();
 

@@ -50,9 +50,7 @@ constexpr uint32_t NCH_LOG = 13, NCHUNKS = 32;   // node records: chunks of 8192
 constexpr uint32_t FCH_LOG = 12, FCHUNKS = 16;   // far entries: chunks of 4096 (64 KB), at most 65536 waiting at once
 constexpr uint32_t WIDE_MIN = 96;          // FIFO entries at one end position from which they are streamed instead of staged in LDS
 constexpr uint32_t NONE16 = 0xFFFFu;
-constexpr uint32_t BIGP = 64;               // a position with more predecessors than this gets no pair table: its connection costs are loaded inside its (any-shape) step
 constexpr uint32_t SLOWT = 4;               // targets relaxed together on the any-shape path (registers: a 64-bit key and a row pointer each)
-constexpr uint32_t PAIR_MIN = 1024;        // bytes of pair table a window wants beyond its largest position
 constexpr uint32_t CCAP = 384;             // team mode: entries of a carry list (two banks of them in the workgroup's shared LDS)
 constexpr uint32_t SEED_MARK = 0xC0000000u, SEED_FAR = 0x20000000u;   // team mode: a seed's dp is not known when its bucket slot is filled -- the slot holds
                                            // SEED_MARK | index into the carry bank (| SEED_FAR: offset into the FIFO from its head) until the sweep starts
@@ -167,7 +165,7 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
     uint8_t *ltext = lds + off0;                 off0 += LTEXT;
     uint32_t *cbw = (uint32_t *)(lds + off0);    off0 += 4 * (WIN + 2);   // byte offset of the window's characters (and one past)
     uint32_t *nb = (uint32_t *)(lds + off0);     off0 += 4 * (WIN + 2);   // nodes starting at position q -> first local node index
-    uint32_t *ebase = (uint32_t *)(lds + off0);  off0 += 4 * (WIN + 2);   // first pair index per position
+    uint32_t *ebase = (uint32_t *)(lds + off0);  off0 += 4 * (WIN + 2);   // first tile index per position
     uint32_t *fbase = (uint32_t *)(lds + off0);  off0 += 4 * (WIN + 2);   // first far-out slot per position
     uint32_t *boff = (uint32_t *)(lds + off0);   off0 += 4 * (REL + 2);   // bucket count -> offset, per relative end position
     uint32_t *bfill = (uint32_t *)(lds + off0);  off0 += 4 * (REL + 2);
@@ -371,7 +369,7 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                 team->go = go ? 1u : 0u; team->C = C; team->slab_lo = (uint32_t)(uintptr_t)sa.ptr; team->slab_hi = (uint32_t)((uintptr_t)sa.ptr >> 32);
                 team->s_done = 0; team->v_done = 0; team->finished = 0; team->failed = 0; team->why = 0; team->eos_pre = NONE; team->wT = 0; team->wE = 0;
                 team->w0 = 0; team->gw = 1; team->ncarry = 1; team->fhead = 0; team->ftail = 0; team->last_far_end = 0; team->fhead_end = 0xFFFFFFFFu; team->wbyte0 = 0; team->wlim = WIN;
-                bank_dp[1][0] = 0u; bank_y[1][0] = d.bos_right; bank_rel[1][0] = 0;   // BOS: node 0, ends at 0, dp None -> 0 (lattice.rs:127,156-164): what "window -1" carries
+                bank_dp[1][0] = 0u; bank_y[1][0] = d.bos_right << 1; bank_rel[1][0] = 0;   // BOS: node 0, ends at 0, dp None -> 0 (lattice.rs:127,156-164): what "window -1" carries
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
@@ -391,7 +389,7 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
         uint32_t wT = 0, wE = 0;
         bool failed = false;
         uint32_t why = 0;  // which limit a failed sentence ran into (Control::phase[why] counts them: KGPU_WINDOW_TRACE)
-        if constexpr (TEAM == 1) if (lane == 0) { carry8(1)[0] = make_uint2(0u, d.bos_right); crel(1)[0] = 0; }  // BOS: node 0, ends at 0, dp None -> 0 (lattice.rs:127,156-164)
+        if constexpr (TEAM == 1) if (lane == 0) { carry8(1)[0] = make_uint2(0u, d.bos_right << 1); crel(1)[0] = 0; }  // BOS: node 0, ends at 0, dp None -> 0 (lattice.rs:127,156-164)
         uint32_t wbyte0 = 0;  // first byte of the next window's characters
         uint2 pf_rec = make_uint2(0u, 0u);
         uint32_t pf_t0 = 0, pf_t1 = 0;
@@ -547,8 +545,8 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
 
             KW_T(3);
             KW_ARGS();
-            // -- scan: node numbering (insertion order, lattice.rs:105-110), bucket offsets, pair offsets, far-out slots
-            uint32_t N, Nb, E, NF, maxpairs;
+            // -- scan: node numbering (insertion order, lattice.rs:105-110), bucket offsets, tile offsets, far-out slots
+            uint32_t N, Nb, NT, NF;
             {
                 const uint32_t v = lane < nw ? cnt : 0u, fo = lane < nw ? nfar : 0u;
                 const uint32_t vs = wave_incl_scan(v, lane), fs = wave_incl_scan(fo, lane);
@@ -565,41 +563,34 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                 }
                 Nb = bc;
                 wave_sync();
-                // relaxations: targets x (LDS predecessors + streamed ones)
+                // stage B: tiles (kgpu_device.h) for every position whose predecessors are all in LDS; a position with STREAMED predecessors (wideN: the end of a
+                // long same-category run -- six unknown words per start position end there, lattice.rs:66-84) keeps the any-shape step, which loads its costs itself;
+                // a position nothing ends at has no step at all
                 const uint32_t P = lane < nw ? boff[lane + 1] - boff[lane] : 0u;
-                // a position with a very large bucket (the end of a long same-category run: six unknown words per start position end there, lattice.rs:66-84)
-                // would need targets x predecessors pair costs in LDS -- more than a window has.  It gets none (bit 31 of wideN): its step loads them itself.
-                const bool bigp = P > BIGP;
-                if (lane < nw && bigp) wideN[lane] |= 0x80000000u;
-                const uint32_t x = bigp ? 0u : v * KGPU_PSTRIDE(P);
+                const bool tiled = lane < nw && wideN[lane] == 0 && v != 0 && P != 0;
+                const uint32_t x = tiled ? ((v + 7u) >> 3) * ((P + 7u) >> 3) : 0u;
                 const uint32_t xs = wave_incl_scan(x, lane);
                 if (lane <= nw) ebase[lane] = xs - x;
-                E = (uint32_t)__builtin_amdgcn_readlane((int)xs, 63);
-                wEw = (lane < nw) ? v * (P + (wideN[lane] & 0x7FFFFFFFu)) : 0u;
-                maxpairs = x;
-#pragma unroll
-                for (int dd = 32; dd > 0; dd >>= 1) maxpairs = max(maxpairs, (uint32_t)__shfl_xor((int)maxpairs, dd, 64));
-                maxpairs = bcast32(maxpairs);
+                NT = (uint32_t)__builtin_amdgcn_readlane((int)xs, 63);
+                wEw = (lane < nw) ? v * (P + wideN[lane]) : 0u;   // relaxations: targets x (LDS predecessors + streamed ones)
             }
-            // -- LDS carve: node arrays, buckets (+ far-out slots + sink), far-out ends, pair table (overlays the match buffer)
+            // -- LDS carve: buckets (+ far-out slots + sink), node arrays (+ the padding tiles' target), far-out ends, the tile list (overlays the match buffer)
             uint32_t off = off0;
             uint2 *bk = (uint2 *)(lds + off);            off += 8 * (Nb + NF + 1);
-            uint8_t *brel = lds + off;                   off += align_up(Nb, 4);   // relative end position of every bucket slot (the flush carries slot by slot)
+            uint8_t *brel = lds + off;                   off += align_up(Nb, 8);   // relative end position of every bucket slot (the flush carries slot by slot)
+            uint2 *node = (uint2 *)(lds + off);          off += 8 * (N + 1);       // {word cost | bucket slot << 16, row offset of the left id -> (low half) best predecessor}: kgpu_device.h
             int32_t *nSid = (int32_t *)(lds + off);      off += 4 * N;
-            uint32_t *nCS = (uint32_t *)(lds + off);     off += 4 * N;
             uint32_t *farEnd = (uint32_t *)(lds + off);  off += 4 * NF;
-            uint16_t *nLeft = (uint16_t *)(lds + off);   off += 2 * N;
             uint16_t *nStart = (uint16_t *)(lds + off);  off += 2 * N;
-            off = align_up(off, 4);
-            uint16_t *pre = nLeft;
-            int16_t *mpair = (int16_t *)(lds + off);
-            const uint32_t pair_need = min(2 * E, max(2 * maxpairs, PAIR_MIN));
+            off = align_up(off, 8);
+            uint2 *tiles = (uint2 *)(lds + off);
+            const uint32_t pair_need = 8 * NT;
             // What this window needs of the LDS (the three layouts that must fit: emit, sweep, flush), and from it the length that WOULD fill 7/8 of the
             // budget at this lattice density: the part above the fixed arrays grows with the positions.  A window that does not fit is redone that long
             // (it has been walked and counted for nothing -- round 3 halved it, and doubled back after every success: through a dense stretch every
             // other window was thrown away); the next window starts that long as well.
             const uint32_t lds_used = max(max(off + cbytes(ncarry) + mbytes + 16, off + pair_need),
-                                          off0 + 8 * (Nb + NF + 1) + align_up(Nb, 4) + cbytes(Nb - boff[nw]) + (lds_bytes - moff));
+                                          off0 + 8 * (Nb + NF + 1) + align_up(Nb, 8) + cbytes(Nb - boff[nw]) + (lds_bytes - moff));
             const uint32_t lds_base = off0 + mbytes + 16;
             const uint32_t fit_len = (nw * (lds_bytes - lds_base) * 7u) / (max(lds_used, lds_base + 1u) - lds_base) / 8u;   // (63 x 160 KB x 7 < 2^32)
             if (N > 0x7FFF || NF >= 0x7FFF || Nb + NF > 0xFFF0 || lds_used > lds_bytes) {
@@ -609,13 +600,12 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
             }
             if ((uint64_t)gw + N >= ((uint64_t)NCHUNKS << NCH_LOG)) { failed = true; why = 3; break; }
             if (TEAM > 1 && Nb - boff[nw] > CCAP) { failed = true; why = 7; break; }   // the carry list does not fit a bank: the single-wavefront form takes the sentence
-            const uint32_t mcap = (lds_bytes - off) / 2;
             if constexpr (TEAM == 1) if (w0 + nw <= C) prefetch(w0 + nw, wbyte_next);  // the next window's stage: in flight while this one is emitted and relaxed
             wave_sync();
 
             KW_T(4);
             KW_ARGS();
-            // -- emit 3a (lane = start position, LDS only): the node list in insertion order; nLeft = relative end, or 0x8000 | far-out slot
+            // -- emit 3a (lane = start position, LDS only): the node list in insertion order; node[].y = relative end, or 0x8000 | far-out slot
             if (lane < nwc) {
                 uint32_t t = nb[lane], fslot = fbase[lane];
                 const uint32_t nm_all = mcnt[lane], nm = min(nm_all, WMAXM), span = uspan[lane];
@@ -629,8 +619,8 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                 }
                 auto put = [&](int32_t sid, uint32_t rel) {
                     nSid[t] = sid; nStart[t] = (uint16_t)lane;
-                    if (rel - lane <= NEARLEN) nLeft[t] = (uint16_t)rel;
-                    else { nLeft[t] = (uint16_t)(0x8000u | fslot); farEnd[fslot] = w0 + rel; ++fslot; }
+                    if (rel - lane <= NEARLEN) node[t].y = rel;
+                    else { node[t].y = 0x8000u | fslot; farEnd[fslot] = w0 + rel; ++fslot; }
                     ++t;
                 };
                 for (uint32_t m = 0; m < nm; ++m) {
@@ -658,7 +648,7 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
             }
             if (nw > nwc && lane == nwc) {  // EOS: Morph(0,0,0), its dp goes to the sink slot
                 const uint32_t t = nb[lane];
-                nSid[t] = 0; nStart[t] = (uint16_t)lane; nLeft[t] = (uint16_t)0x7FFF;
+                nSid[t] = 0; nStart[t] = (uint16_t)lane; node[t].y = 0x7FFFu;
             }
             wave_sync();
             // -- seeds into their buckets: carried entries, then the staged FIFO entries
@@ -679,6 +669,7 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                 }
             }
             // -- emit 3b (lane = node): morph record, bucket slot
+            const uint32_t rows2 = d.conn_rows * 2u;   // bytes per matrix row (connection.rs:12-14)
             for (uint32_t t0 = 0; t0 < N; t0 += 256) {
                 uint32_t tt[4], ee[4];
                 Morph8 mm[4];
@@ -687,7 +678,7 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                     tt[k] = t0 + 64 * k + lane;
                     const bool v = tt[k] < N;
                     const int32_t sid = v ? nSid[tt[k]] : 1;
-                    ee[k] = v ? nLeft[tt[k]] : 0u;
+                    ee[k] = v ? node[tt[k]].y : 0u;
                     mm[k] = sid == 0 ? Morph8{(int16_t)d.eos_left, 0, 0, 0} : *(sid > 0 ? d.morph + (sid - 1) : d.unk_morph + (-sid - 1));
                 }
 #pragma unroll
@@ -697,8 +688,8 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                         if (ee[k] == 0x7FFFu) slot = Nb + NF;                                   // EOS: the sink
                         else if (ee[k] & 0x8000u) slot = Nb + (ee[k] & 0x7FFFu);                 // ends beyond the LDS buckets: a far-out slot
                         else { slot = boff[ee[k]] + atomicAdd(&bfill[ee[k]], 1u); brel[slot] = (uint8_t)ee[k]; }
-                        nLeft[tt[k]] = (uint16_t)mm[k].left; nCS[tt[k]] = (uint32_t)(uint16_t)mm[k].cost | (slot << 16);
-                        bk[slot] = make_uint2((uint32_t)INF, (uint32_t)(uint16_t)mm[k].right | ((gw + tt[k] - rb) << 16));
+                        node[tt[k]] = make_uint2((uint32_t)(uint16_t)mm[k].cost | (slot << 16), (uint32_t)(uint16_t)mm[k].left * rows2);
+                        bk[slot] = make_uint2((uint32_t)INF, ((uint32_t)(uint16_t)mm[k].right << 1) | ((gw + tt[k] - rb) << 16));   // (2 * right: ids are non-negative i16)
                     }
                 }
             }
@@ -748,149 +739,120 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
             }
             KW_T(5);
             KW_ARGS();
-            // -- gather + sweep, block by block (the pool kernel's step: kgpu_pool.hip)
+            // -- stage B: the tile list (lane = start position), then gather + sweep (kgpu_device.h: tiles_run), position by position in order
             const uint32_t lds0 = (uint32_t)(uintptr_t)(KGPU_LDS(uint8_t) *)lds;
-            const uint32_t a_ncs = bcast32(lds0 + (uint32_t)((uint8_t *)nCS - lds)), a_bk = bcast32(lds0 + (uint32_t)((uint8_t *)bk - lds));
-            const uint32_t a_mp = bcast32(lds0 + (uint32_t)((uint8_t *)mpair - lds)), a_pre = bcast32(lds0 + (uint32_t)((uint8_t *)pre - lds));
-            uint32_t qa = 0;
-            while (qa < nw) {
-                const uint32_t ql = qa + lane;
-                const bool inq = ql < nw;
-                const uint32_t nb0 = nb[inq ? ql : nw], nb1 = nb[inq ? ql + 1 : nw], eb_l = ebase[inq ? ql : nw], eb1 = ebase[inq ? ql + 1 : nw];
-                const uint32_t tA = bcast32(nb0), eb0 = bcast32(eb_l);
-                const uint64_t fits = __ballot(inq && (lane == 0 || (nb1 - tA <= 64u && eb1 - eb0 <= mcap)));
-                const uint32_t nq = ~fits ? (uint32_t)__ffsll((unsigned long long)~fits) - 1u : 64u;
-                const uint32_t qb = qa + nq;
-                const uint32_t ta = tA, tb = bcast32(nb[qb]);
-                for (uint32_t t = ta + lane; t < tb; t += 64) {   // gather M[right(j)][left(t)] of the block's pairs (connection.rs:12-14)
-                    const uint32_t q = nStart[t];
-                    const uint32_t p0 = boff[q], P = boff[q + 1] - p0;
-                    const uint32_t ti = t - nb[q];
-                    const uint32_t base = ebase[q] - eb0 + ti * KGPU_PSTRIDE(P);
-                    if (!(wideN[q] >> 31)) gather_target_row(bk + p0, P, conn_row(d, nLeft[t]), mpair + base);
+            const uint32_t a_node = bcast32(lds0 + (uint32_t)((uint8_t *)node - lds)), a_bk = bcast32(lds0 + (uint32_t)((uint8_t *)bk - lds));
+            uint64_t slowmask;   // positions with streamed predecessors: the any-shape step below, between the runs of tiles
+            uint32_t eb_l;       // lane q: first tile of position q; lane nw: the end of the list
+            {
+                const bool inq = lane < nw;
+                const uint32_t t0 = nb[inq ? lane : nw], T = inq ? nb[lane + 1] - t0 : 0u, p0 = boff[inq ? lane : nw], P = inq ? boff[lane + 1] - p0 : 0u;
+                const uint32_t wn = inq ? wideN[lane] : 0u;
+                eb_l = ebase[min(lane, nw)];
+                slowmask = __ballot(inq && wn != 0 && T != 0);
+                if (inq && wn == 0 && T) {
+                    if (P == 0) {   // nothing ends here (lattice.rs:121-140 with an empty edges[pos]): its targets stay at INF (set by emit) with no predecessor -- no step
+                        for (uint32_t k = 0; k < T; ++k) node[t0 + k].y = NONE16;
+                    } else {
+                        uint32_t k = eb_l;
+                        const uint32_t kb = (P + 7u) >> 3;
+                        for (uint32_t ta = 0; ta < T; ta += 8)
+                            for (uint32_t b = 0; b < kb; ++b, ++k)
+                                tiles[k] = make_uint2(tile_desc0(a_node + 8 * (t0 + ta), min(8u, T - ta), min(8u, P - 8 * b), b == 0, b == kb - 1), a_bk + 8 * (p0 + 8 * b));
+                    }
                 }
-                wave_sync();
-                KW_T(6);
-                if constexpr (TEAM > 1) {
-                    if (!have_v) {   // the value token: every window before this one has been relaxed; the seeds' slots get their dp
-                        bool stop = false;
-                        for (;;) {
-                            if (lds_get(&team->failed)) { stop = true; break; }
-                            if (lds_get(&team->v_done) == kwin) break;
-                            __builtin_amdgcn_s_sleep(2);
+                if (lane == 0) node[N] = make_uint2(0u, 0u);   // what the lanes past a run of tiles gather for: row 0 of the matrix, never swept
+            }
+            wave_sync();
+            KW_T(6);
+            if constexpr (TEAM > 1) {
+                if (!have_v) {   // the value token: every window before this one has been relaxed; the seeds' slots get their dp
+                    bool stop = false;
+                    for (;;) {
+                        if (lds_get(&team->failed)) { stop = true; break; }
+                        if (lds_get(&team->v_done) == kwin) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (stop) break;
+                    team_acquire();
+                    for (uint32_t sl = lane; sl < Nb; sl += 64) {
+                        const uint32_t x = bk[sl].x;
+                        if ((x & SEED_MARK) == SEED_MARK) {
+                            const uint32_t idx = x & (SEED_FAR - 1u);
+                            bk[sl].x = (x & SEED_FAR) ? (uint32_t)far_rec(fhead_w + idx)->dp : bank_dp[pb][idx];
                         }
-                        if (stop) break;
-                        team_acquire();
-                        for (uint32_t sl = lane; sl < Nb; sl += 64) {
-                            const uint32_t x = bk[sl].x;
-                            if ((x & SEED_MARK) == SEED_MARK) {
-                                const uint32_t idx = x & (SEED_FAR - 1u);
-                                bk[sl].x = (x & SEED_FAR) ? (uint32_t)far_rec(fhead_w + idx)->dp : bank_dp[pb][idx];
+                    }
+                    wave_sync();
+                    have_v = true;
+                }
+            }
+            {
+                const uint8_t *connb = (const uint8_t *)d.conn;
+                const uint2 null_tile = make_uint2((a_node + 8 * N) | TILE_FIRST, a_bk);
+                for (uint32_t q = 0; q < nw;) {
+                    const uint64_t rest = slowmask >> q;
+                    const uint32_t qs = rest ? q + (uint32_t)__ffsll((unsigned long long)rest) - 1u : nw;   // the next any-shape position (nw: none)
+                    const uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)eb_l, (int)q), tb = (uint32_t)__builtin_amdgcn_readlane((int)eb_l, (int)qs);
+                    if (tb > ta) tiles_run<false>(tiles, ta, tb, null_tile, lane, a_bk, connb, true);
+                    if (qs < nw) {
+                        // any shape with streamed (wide) predecessors: SLOWT targets at a time, the lanes split the predecessors -- the bucket's in LDS, then the
+                        // FIFO's; costs straight from the matrix (connection.rs:12-14); key = (total, node index): strict '<' over ascending insertion order (lattice.rs:125,136)
+                        const uint32_t t0 = bcast32(nb[qs]), T = bcast32(nb[qs + 1]) - t0, p0 = bcast32(boff[qs]), P = bcast32(boff[qs + 1]) - p0;
+                        const uint32_t wn = bcast32(wideN[qs]), wlo = bcast32(fcnt[qs]);
+                        for (uint32_t tg = 0; tg < T; tg += SLOWT) {  // SLOWT targets share every load of a predecessor
+                            const uint32_t nt8 = min(SLOWT, T - tg);
+                            uint64_t key[SLOWT];
+                            const uint8_t *col[SLOWT];
+#pragma unroll
+                            for (int k = 0; k < (int)SLOWT; ++k) {
+                                key[k] = ~0ull;
+                                col[k] = connb + node[t0 + tg + min((uint32_t)k, nt8 - 1)].y;   // the target's row of the matrix
                             }
-                        }
-                        wave_sync();
-                        have_v = true;
-                    }
-                }
-                {
-                    uint32_t dT = 0, dP = 0, dt0 = 0, d0 = 1u << 31, d1 = 0, d2 = 0;
-                    if (lane < nq) {
-                        dt0 = nb0;
-                        const uint32_t dp0 = boff[ql], deb = eb_l - eb0;
-                        dT = nb1 - dt0;
-                        dP = boff[ql + 1] - dp0;
-                        const uint32_t wn_l = wideN[ql];
-                        const bool fastq = dP <= 32 && dT - 1u < 127u && wn_l == 0;
-                        d0 = sweep_desc0(a_ncs, dt0, dT, dP, fastq);
-                        d1 = a_bk + 8 * dp0;
-                        d2 = a_mp + 2 * deb;
-                        if (dP == 0 && wn_l == 0) {   // nothing ends here (lattice.rs:121-140 with an empty edges[pos]): its targets stay at INF (set by emit) with no
-                            d0 = 0;                    // predecessor -- no step on the chain for this position
-                            for (uint32_t k = 0; k < dT; ++k) pre[dt0 + k] = (uint16_t)NONE16;
-                        }
-                    }
-                    for (uint32_t r = 0; r < nq; ++r) {
-                        const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)r);
-                        if (D0 == 0) continue;
-                        const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)r);
-                        const uint32_t D2 = (uint32_t)__builtin_amdgcn_readlane((int)d2, (int)r);
-                        if (!(D0 >> 31)) {
-                            sweep_position_fast(lane, D0, D1, D2, a_ncs, a_pre, a_bk);   // kgpu_device.h: the step both LDS kernels share
-                        } else {
-                            // any shape, and the streamed (wide) positions: one target at a time, the lanes split its predecessors;
-                            // key = (total, node index) -- strict '<' over ascending insertion order (lattice.rs:125,136)
-                            const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)dT, (int)r);
-                            const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)dP, (int)r);
-                            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)dt0, (int)r);
-                            const uint32_t p0 = (D1 - a_bk) >> 3, eb = (D2 - a_mp) >> 1;
-                            const uint32_t q = qa + r;
-                            const uint32_t wn = wideN[q] & 0x7FFFFFFFu, wlo = fcnt[q];
-                            const bool nopair = (wideN[q] >> 31) != 0;
-                            for (uint32_t tg = 0; tg < T; tg += SLOWT) {  // SLOWT targets share every load of a predecessor
-                                const uint32_t nt8 = min(SLOWT, T - tg);
-                                uint64_t key[SLOWT];
-                                const int16_t *col[SLOWT];
-#pragma unroll
-                                for (int k = 0; k < (int)SLOWT; ++k) {
-                                    key[k] = ~0ull;
-                                    const uint32_t L = nLeft[t0 + tg + min((uint32_t)k, nt8 - 1)];
-                                    col[k] = conn_row(d, L);
-                                }
-                                for (uint32_t jj = lane; jj < P; jj += 64) {
-                                    const uint2 e = bk[p0 + jj];
-                                    const uint32_t gi = rb + (e.y >> 16), r = e.y & 0xFFFFu;
-                                    int32_t cc[SLOWT];
-#pragma unroll
-                                    for (int k = 0; k < (int)SLOWT; ++k)   // (no pair table for this position: the costs straight from the matrix, connection.rs:12-14)
-                                        cc[k] = (uint32_t)k < nt8 ? (nopair ? (int32_t)col[k][r] : (int32_t)mpair[eb + (tg + k) * KGPU_PSTRIDE(P) + jj]) : 0;
-#pragma unroll
-                                    for (int k = 0; k < (int)SLOWT; ++k)
-                                        if ((uint32_t)k < nt8) {
-                                            const int32_t v = (int32_t)e.x + cc[k];
-                                            const uint64_t ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | gi;
-                                            key[k] = ck < key[k] ? ck : key[k];
-                                        }
-                                }
-                                for (uint32_t f = wlo + lane; f < wlo + wn; f += 64) {
-                                    const Far e = *far_rec(f);
-                                    const uint32_t r = e.right & 0xFFFFu;
-                                    int32_t cc[SLOWT];
-#pragma unroll
-                                    for (int k = 0; k < (int)SLOWT; ++k) cc[k] = (uint32_t)k < nt8 ? (int32_t)col[k][r] : 0;
-#pragma unroll
-                                    for (int k = 0; k < (int)SLOWT; ++k)
-                                        if ((uint32_t)k < nt8) {
-                                            const int32_t v = e.dp + cc[k];
-                                            const uint64_t ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | e.node;
-                                            key[k] = ck < key[k] ? ck : key[k];
-                                        }
-                                }
+                            for (uint32_t jj = lane; jj < P; jj += 64) {
+                                const uint2 e = bk[p0 + jj];
+                                const uint32_t gi = rb + (e.y >> 16), r2 = e.y & 0xFFFFu;
 #pragma unroll
                                 for (int k = 0; k < (int)SLOWT; ++k)
                                     if ((uint32_t)k < nt8) {
-                                        const uint64_t kk = wave_min_u64(key[k]);
-                                        if (lane == 0) {
-                                            const uint32_t cs = nCS[t0 + tg + k];
-                                            int32_t dpv = INF; uint32_t prv = NONE16;
-                                            if (kk != ~0ull) {
-                                                const int32_t tot = (int32_t)((uint32_t)(kk >> 32) ^ 0x80000000u) + (int32_t)(int16_t)cs;
-                                                if (tot < INF) { dpv = tot; prv = (uint32_t)kk - rb; }
-                                            }
-                                            pre[t0 + tg + k] = (uint16_t)prv;
-                                            bk[cs >> 16].x = (uint32_t)dpv;
-                                        }
+                                        const int32_t v = (int32_t)e.x + (int32_t)*(const int16_t *)(col[k] + r2);
+                                        const uint64_t ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | gi;
+                                        key[k] = ck < key[k] ? ck : key[k];
                                     }
-                                wave_sync();
                             }
+                            for (uint32_t f = wlo + lane; f < wlo + wn; f += 64) {
+                                const Far e = *far_rec(f);
+                                const uint32_t r2 = e.right & 0xFFFFu;
+#pragma unroll
+                                for (int k = 0; k < (int)SLOWT; ++k)
+                                    if ((uint32_t)k < nt8) {
+                                        const int32_t v = e.dp + (int32_t)*(const int16_t *)(col[k] + r2);
+                                        const uint64_t ck = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | e.node;
+                                        key[k] = ck < key[k] ? ck : key[k];
+                                    }
+                            }
+#pragma unroll
+                            for (int k = 0; k < (int)SLOWT; ++k)
+                                if ((uint32_t)k < nt8) {
+                                    const uint64_t kk = wave_min_u64(key[k]);
+                                    if (lane == 0) {
+                                        const uint32_t cs = node[t0 + tg + k].x;
+                                        int32_t dpv = INF; uint32_t prv = NONE16;
+                                        if (kk != ~0ull) {
+                                            const int32_t tot = (int32_t)((uint32_t)(kk >> 32) ^ 0x80000000u) + (int32_t)(int16_t)cs;
+                                            if (tot < INF) { dpv = tot; prv = (uint32_t)kk - rb; }
+                                        }
+                                        node[t0 + tg + k].y = prv & 0xFFFFu;
+                                        bk[cs >> 16].x = (uint32_t)dpv;
+                                    }
+                                }
                             wave_sync();
                         }
-                        __builtin_amdgcn_wave_barrier();
                     }
+                    q = qs + 1;
                 }
-                wave_sync();
-                KW_T(7);
-                qa = qb;
             }
+            wave_sync();
+            KW_T(7);
 
             KW_ARGS();
             if constexpr (TEAM > 1) {
@@ -905,7 +867,7 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
             // -- flush: node records to HBM, far-out entries to the FIFO, the buckets beyond the window to the carry list
             if constexpr (TEAM == 1) if (!chunk_get(nchunk, nchunks_have, (gw + N - 1) >> NCH_LOG, (4u + (uint32_t)sizeof(NodeRec)) << NCH_LOG)) { failed = true; why = 3; break; }
             for (uint32_t t = lane; t < N; t += 64) {
-                const uint32_t p = pre[t], st = nStart[t];
+                const uint32_t p = node[t].y & 0xFFFFu, st = nStart[t];
                 const uint32_t gp = p == NONE16 ? NONE : rb + p;
                 NodeRec rec;
                 rec.sid = nSid[t];
