@@ -215,7 +215,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         // a parked match: {trie id, chars | records << 8}; one word id (21 bits) | chars (8) | records (3; 0 = look the count up)
         // when the ids fit (DictView::leaf_dup: fewer than 2^21 morphs)
         const uint32_t MS = (d.leaf_dup && d.n_unk_morph < (1u << 21)) ? 4u : 8u;
-        const uint32_t need1 = align_up(B + 4, 4) + 24 * (C + 2) + 2 * align_up(C + 2, 4) + align_up(C * MAXM * MS, 16) + 32;
+        const uint32_t need1 = align_up(B + 4, 4) + 22 * (C + 2) + 2 * align_up(C + 2, 4) + align_up(C * MAXM * MS, 16) + 32;
         const uint32_t est = max(need1, (uint32_t)(((uint64_t)B * a.est_q8) >> 8) + KGPU_EST_SLACK);
         uint32_t npg = own_slice ? POOL_PAGES : pages_for(est);
         // routing: a sentence expected to need more than max_pages would hold a large part of the pool for a long
@@ -254,8 +254,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         uint32_t *ebase = (uint32_t *)(smem + off); off += 4 * (C + 2);  // first pair index per position
         uint16_t *cbyte = (uint16_t *)(smem + off); off += 2 * (C + 2);  // char -> byte offset
         uint16_t *uspan = (uint16_t *)(smem + off); off += 2 * (C + 2);  // unknown span (0 = none)
-        uint16_t *path = (uint16_t *)(smem + off);  off += 2 * (C + 2);  // backtrace
-        uint16_t *cp16 = (uint16_t *)(smem + off);  off += 2 * (C + 2);  // BMP code point (0xFFFF: not BMP)
+        uint16_t *cp16 = (uint16_t *)(smem + off);  off += 2 * (C + 2);  // BMP code point (0xFFFF: not BMP), then the character's code: the walk's
+        uint16_t *path = cp16;                                            // ... and, once the walk is through, the backtrace's
         uint8_t *ccat = smem + off;                 off += align_up(C + 2, 4);
         uint8_t *mcnt = smem + off;                 off += align_up(C + 2, 4);
         const uint32_t mbytes = align_up(C * MAXM * MS, 16);
@@ -415,18 +415,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         const uint32_t N = bcast32(ncarry), Nb = bcast32(bcarry), NT = bcast32(tcarry);
         const uint32_t NTp = align_up(NT, 8);  // the list is padded to whole groups of eight with tiles that store nothing
 
-        // ---- LDS carve, part 2: buckets, node arrays, tile list ---------------------
+        // ---- LDS carve, part 2: node arrays, buckets, tile list ---------------------
+        // What emit 3a writes (per node: morph id, end position) lies BELOW the match buffer it reads; the buckets (filled by 3b) and the tile list (3c) may
+        // lie over it: a sentence's peak is max(3a's, the sweep's), not their sum.  A node's start position is not kept: the tokens look it up in nb[].
         off = align_up(off, 8);
-        uint2 *bk = (uint2 *)(smem + off);          off += 8 * (Nb + 2);  // bucket (= edges[e]): {dp, 2 * right | node << 16}; [Nb]: sink for EOS; [Nb + 1]: the absent candidate
         uint2 *node = (uint2 *)(smem + off);        off += 8 * (N + 1);  // {word cost (i16) | bucket slot of the node << 16, byte offset of the node's matrix row (left * rows * 2)}; [N]: the padding tiles' target
                                                                     // the sweep stores the best predecessor into the low half of .y once the node's costs are gathered
         int32_t *nSid = (int32_t *)(smem + off);    off += 4 * N;   // +id known, -id unknown, 0 dummy
-        uint16_t *nStart = (uint16_t *)(smem + off); off += 2 * N;
         off = align_up(off, 8);
-        const uint32_t off_emit_end = off;                          // everything above is written by emit
-        uint2 *tiles = (uint2 *)(smem + off);                       // the tile list; overlays the match buffer (written after emit)
+        const uint32_t off_emit_end = off;                          // everything above is written by emit 3a
+        uint2 *bk = (uint2 *)(smem + off);          off += 8 * (Nb + 2);  // bucket (= edges[e]): {dp, 2 * right | node << 16}; [Nb]: sink for EOS; [Nb + 1]: the absent candidate
+        uint2 *tiles = (uint2 *)(smem + off);                       // the tile list
         if (N > 0xFFFF) { defer_s(s); break; }
-        // exact requirement: emit-written arrays stay below the match buffer; afterwards the tile list overlays it
+        // exact requirement: what 3a writes stays below the match buffer; afterwards the buckets and the tile list overlay it
         const uint32_t need_emit = off_emit_end + mbytes + 16, need_full = off + 8 * NTp;
         if (need_emit > lds_bytes || need_full > lds_bytes) {
             // reservation too small: release, wait (holding nothing) for the exact size, redo
@@ -468,10 +469,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                     const uint2 w = *(const uint2 *)(mbuf + 2 * (i * MAXM + m));
                     id = w.x; end = i + (w.y & 255u); nrec = w.y >> 8;
                 }
-                for (uint32_t r = 0; r < nrec; ++r, ++t) { nSid[t] = (int32_t)(id + r); nStart[t] = (uint16_t)i; node[t].y = end; }
+                for (uint32_t r = 0; r < nrec; ++r, ++t) { nSid[t] = (int32_t)(id + r); node[t].y = end; }
             }
             if (span)   // lattice.rs:87-97,190-201
-                for (uint32_t r = 0; r < ucnt; ++r, ++t) { nSid[t] = -(int32_t)(ufirst + r); nStart[t] = (uint16_t)i; node[t].y = i + span; }
+                for (uint32_t r = 0; r < ucnt; ++r, ++t) { nSid[t] = -(int32_t)(ufirst + r); node[t].y = i + span; }
         }
         wave_sync();
         // 3b, lane = node: its morph record (one gather per 64 nodes instead of one dependent load per record of the
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         }
         if (lane == 0) {
             node[N - 1] = make_uint2(Nb << 16, d.eos_left * rows2);  // EOS: Morph(0,0,0), ranked id; its dp goes to the sink slot
-            nStart[N - 1] = (uint16_t)C; nSid[N - 1] = 0;
+            nSid[N - 1] = 0;
             bk[0] = make_uint2(0u, d.bos_right << 1);  // BOS: dp None -> 0 (lattice.rs:127), right_id 0 (ranked), node 0
             bk[Nb + 1] = make_uint2(0x7FFEFFFFu, 0u);  // what a position without predecessors relaxes from: a total no real one reaches (real <= INF + 32767) that
                                                        // cannot overflow when a connection cost and a word cost are added, and stays >= INF when they are negative
@@ -559,6 +560,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         const uint64_t ts = b0 - a.offsets[0] + s;
         wave_sync();
         {
+            // the start position of node t: the last i with nb[i] <= t (nb[] = first node index per position, ascending; an empty position shares its
+            // successor's) -- a binary search per token instead of a half-word per node written by emit and kept in LDS through the sweep
+            const uint32_t hb = 1u << (31 - __clz((int)max(C, 1u)));
+            auto start_of = [&](uint32_t t) { uint32_t lo = 0; for (uint32_t st = hb; st; st >>= 1) { const uint32_t m = lo + st; if (m <= C && nb[m] <= t) lo = m; } return lo; };
             for (uint32_t k = lane; k < K; k += 64) {
                 const uint32_t t = path[K - 1 - k];
                 const int32_t sid = nSid[t];
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                     tk.id = 0; tk.cls = KGPU_CLASS_DUMMY; tk.position = B; tk.start = C; tk.end = C + 3; tk.byte_len = 0;
                 } else {
                     // a word is never last on the path (EOS is): it ends where its successor starts
-                    const uint32_t st = nStart[t], en = nStart[path[K - 2 - k]], bs = cbyte[st];
+                    const uint32_t st = start_of(t), en = start_of(path[K - 2 - k]), bs = cbyte[st];
                     tk.id = sid > 0 ? sid : -sid;
                     tk.cls = sid > 0 ? KGPU_CLASS_KNOWN : KGPU_CLASS_UNKNOWN;
                     tk.position = bs; tk.start = st; tk.end = en; tk.byte_len = cbyte[en] - bs;
