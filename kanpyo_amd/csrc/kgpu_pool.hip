@@ -194,7 +194,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         // ticket tk of workgroup b -> list entry (tk / W) * (G W) + b W + tk % W: W CONSECUTIVE entries per workgroup and round -- neighbours in the text (their
         // offsets and bytes share cache lines) and, when the list is ordered by length (k_order_by_length), sentences that finish together: a workgroup keeps its
         // LDS until its last wavefront is through
-        if (!work_next_at(io, a, (uint64_t)(tk / W) * ((uint64_t)gridDim.x * W) + (uint64_t)blockIdx.x * W + tk % W, s)) break;
+        // (a workgroup's first W tickets -- all of them in a launch of one sentence per wavefront -- need no division by the run-time W)
+        const uint64_t widx = tk < W ? (uint64_t)blockIdx.x * W + tk : (uint64_t)(tk / W) * ((uint64_t)gridDim.x * W) + (uint64_t)blockIdx.x * W + tk % W;
+        if (!work_next_at(io, a, widx, s)) break;
 #endif
         const uint64_t b0 = a.offsets[s];
         const uint64_t Bl = a.offsets[s + 1] - b0;
