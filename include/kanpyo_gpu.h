@@ -163,7 +163,10 @@ typedef struct kgpu_plan_info {
     uint32_t window_workgroups;       /* ... grid of one launch                                                    */
     uint32_t streams;                 /* HIP streams the dictionary's NULL-stream contexts share: 4 when the process has GPU_MAX_HW_QUEUES >= 5
                                          (the library sets it to 16 itself when it is loaded before the HIP runtime initialises and the variable
-                                         is unset), else 3 -- and kgpu_last_error() then carries a warning after kgpu_dict_create            */
+                                         is unset), else 3 -- and kgpu_last_error() then carries a warning after kgpu_dict_create.
+                                         NOTE: that setenv(GPU_MAX_HW_QUEUES=16) is PROCESS-WIDE -- it changes the hardware-queue allocation of every
+                                         other HIP user in the process (PyTorch, RCCL); KGPU_NO_PREINIT=1 in the environment, or setting the variable
+                                         yourself, leaves it alone (the library then runs on three shared streams, long batches included)        */
     uint32_t long_streams;            /* further streams, one per context up to this many, for batches whose chain starts with the windowed kernel
                                          (long sentences: average length >= KGPU_WINDOW_FIRST bytes, default 1024): what the hardware queues leave
                                          -- 8 with 16 queues, 2 with 8, 0 (such batches stay on `streams`) with HIP's default 4                */
