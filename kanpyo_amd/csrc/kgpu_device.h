@@ -402,9 +402,8 @@ __device__ __forceinline__ void tile_sweep8(const TileGroup &G, uint32_t d0, uin
             lds_st<uint16_t>(na + 4u, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
             lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
         }
-#ifndef KGPU_TILE_NOBARRIER
-        __builtin_amdgcn_wave_barrier();
-#endif
+        // (no scheduling barrier between tiles: the compiler keeps the order of LDS accesses it cannot tell apart, and the next tile's address arithmetic and
+        // first reads may slide under this tile's second reduction: 118.9 -> 121.6 M sentences/s over three interleaved runs)
     }
 }
 // Tiles [ta, tb) of the list at `tiles` (LDS), in order.  PADDED: tb - ta is a multiple of eight (the kernel padded its list with tiles that store nothing),
