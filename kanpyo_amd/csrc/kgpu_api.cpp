@@ -1647,7 +1647,7 @@ extern "C" int kgpu_tokenize_batch(kgpu_dict *d, const uint8_t *utf8, const uint
     const double t_call = now();
     // chunks of 8192 sentences, ten in the device pipeline (measured on 400k sentences: 16384 x 6: 55.6, 8192 x 10: 61.2, 4096 x 14: 58.8 M sentences/s)
     const uint64_t CHUNK_BYTES = std::min<uint64_t>(hooks.chunk_bytes, 2ull << 20);
-    const uint64_t CHUNK_SENTS = std::min<uint64_t>(hooks.chunk_sents, std::min<uint64_t>(8192, std::max<uint64_t>(2048, n / 12)));
+    const uint64_t CHUNK_SENTS = std::min<uint64_t>(hooks.chunk_sents, std::min<uint64_t>(8192, std::max<uint64_t>(1024, n / 12)));   // (round 6: the floor was 2048 -- with the pool kernel at 59 us per 4096 sentences a 4096-sentence call runs 182 -> 174 us as four chunks)
     const bool pinned_in = (offsets[n] - offsets[0]) != 0 && is_pinned_host(utf8) && is_pinned_host(offsets);
     constexpr int MAX_DEPTH = 16;
     const int DEPTH = (int)std::min<uint64_t>(MAX_DEPTH, std::max<uint64_t>(3, hooks.depth));
