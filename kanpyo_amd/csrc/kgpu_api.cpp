@@ -1404,22 +1404,29 @@ static int small_call(kgpu_dict *d, kgpu_ctx *c, SmallReq *const *reqs, size_t n
 // The combiner's lock: held for a push_back and two additions (tens of nanoseconds), taken by every caller -- and by a whole batch's followers at the same
 // instant, when the leader's one wake-up releases them into their next calls.  A pthread mutex puts each of them to sleep and wakes it again through the kernel:
 // measured with 128 callers, 40-48 us of (system) CPU per call in the lock alone -- more CPU than a 16-CPU cgroup quota grants, so the group spent most of each
-// 100 ms period throttled (profiles/experiments/r05_callers_cpu.txt).  Test-and-test-and-set with pause; a holder that lost its CPU is waited for with yields.
+// 100 ms period throttled (profiles/experiments/r05_callers_cpu.txt).  Test-and-test-and-set with pause and backoff, a few yields, then asleep on the word.
 struct SpinLock {
+    // 0 free, 1 held, 2 held and somebody may be asleep on the word.  Spinning is bounded (round 6, advisor): a holder that lost its CPU -- more callers than
+    // CPUs, a cgroup quota, a lower-priority holder under SCHED_FIFO -- is not waited for with yields for ever; after ~four yields the waiter sleeps on the
+    // word (futex) and the release wakes one sleeper.  The uncontended and the briefly contended paths never enter the kernel.
     std::atomic<uint32_t> v{0};
     void lock() {
-        // (a lost exchange backs off for twice as long, up to 32 pauses: two dozen threads that all saw the word free do not all write it again at the next release)
-        for (unsigned spins = 0, backoff = 1;;) {
+        // (a lost compare-and-swap backs off for twice as long, up to 32 pauses: two dozen threads that all saw the word free do not all write it again at the next release)
+        for (unsigned spins = 0, backoff = 1, yields = 0; yields < 4;) {
             if (v.load(std::memory_order_relaxed) == 0) {
-                if (v.exchange(1, std::memory_order_acquire) == 0) return;
+                uint32_t z = 0;
+                if (v.compare_exchange_weak(z, 1, std::memory_order_acquire, std::memory_order_relaxed)) return;
                 for (unsigned k = 0; k < backoff; ++k) cpu_relax();
                 if (backoff < 32) backoff *= 2;
             }
             cpu_relax();
-            if (++spins >= 2048) { sched_yield(); spins = 0; }
+            if (++spins >= 2048) { sched_yield(); spins = 0; ++yields; }
         }
+        while (v.exchange(2, std::memory_order_acquire) != 0) syscall(SYS_futex, (uint32_t *)&v, FUTEX_WAIT_PRIVATE, 2u, nullptr, nullptr, 0);
     }
-    void unlock() { v.store(0, std::memory_order_release); }
+    void unlock() {
+        if (v.exchange(0, std::memory_order_release) == 2) syscall(SYS_futex, (uint32_t *)&v, FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
+    }
     static void cpu_relax() {
 #if defined(__x86_64__)
         __builtin_ia32_pause();
@@ -1493,22 +1500,27 @@ static int small_call_combined(kgpu_dict *d, SmallReq &me) {
     std::shared_ptr<Combiner::Batch> mine;
     const bool trace = small_trace_on();
     uint64_t k0 = trace ? cpu_ns() : 0;
-    {
-        std::unique_lock<SpinLock> l(cb.mu);
-        std::shared_ptr<Combiner::Batch> b = cb.open;
-        if (b && !b->closed && b->n + me.n <= SMALL_MAX_N && b->bytes + my_bytes <= SMALL_MAX_BYTES) {   // join the batch being assembled
-            b->reqs.push_back(&me); b->n += me.n; b->bytes += my_bytes;
-            l.unlock();
-            const uint64_t k1 = trace ? cpu_ns() : 0;
-            while (b->done.load(std::memory_order_acquire) == 0) futex_wait(&b->done, 0);   // the leader has written my records and my rc before it sets the word
-            if (trace) { g_sc[0] += 1; g_sc[2] += k1 - k0; g_sc[3] += cpu_ns() - k1; }
-            if (me.rc > 0 && me.err[0]) set_error("%s", me.err);
-            return me.rc;
+    for (;;) {   // (a batch is allocated OUTSIDE the lock -- the lock is held for a push_back and two additions -- and only by a caller that found none to join)
+        {
+            std::unique_lock<SpinLock> l(cb.mu);
+            std::shared_ptr<Combiner::Batch> b = cb.open;
+            if (b && !b->closed && b->n + me.n <= SMALL_MAX_N && b->bytes + my_bytes <= SMALL_MAX_BYTES) {   // join the batch being assembled
+                b->reqs.push_back(&me); b->n += me.n; b->bytes += my_bytes;
+                l.unlock();
+                const uint64_t k1 = trace ? cpu_ns() : 0;
+                while (b->done.load(std::memory_order_acquire) == 0) futex_wait(&b->done, 0);   // the leader has written my records and my rc before it sets the word
+                if (trace) { g_sc[0] += 1; g_sc[2] += k1 - k0; g_sc[3] += cpu_ns() - k1; }
+                if (me.rc > 0 && me.err[0]) set_error("%s", me.err);
+                return me.rc;
+            }
+            if (mine) {
+                mine->reqs.push_back(&me); mine->n = me.n; mine->bytes = my_bytes;
+                cb.open = mine;   // (a batch another leader still holds open but that has no room for me stays its leader's: it closes it itself)
+                break;
+            }
         }
         mine = std::make_shared<Combiner::Batch>();
         mine->reqs.reserve(SMALL_MAX_N);   // (no reallocation under the lock later)
-        mine->reqs.push_back(&me); mine->n = me.n; mine->bytes = my_bytes;
-        cb.open = mine;   // (a batch another leader still holds open but that has no room for me stays its leader's: it closes it itself)
     }
     // Leader.  A lone caller launches at once.  With other callers inside the entry point the batch stays open for a short window -- and, when
     // the device already has its fill of small launches in flight, until one of them completes (or the batch is full): the batch size follows the

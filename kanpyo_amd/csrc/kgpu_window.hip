@@ -778,8 +778,10 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                     for (uint32_t sl = lane; sl < Nb; sl += 64) {
                         const uint32_t x = bk[sl].x;
                         if ((x & SEED_MARK) == SEED_MARK) {
+                            // (every slot below Nb holds INF or a marker here -- emit wrote INF for this window's own nodes, the seeds step the markers -- so the
+                            // pattern cannot be a real dp; the index is checked all the same: a stale slot must not become an out-of-bounds read of the FIFO)
                             const uint32_t idx = x & (SEED_FAR - 1u);
-                            bk[sl].x = (x & SEED_FAR) ? (uint32_t)far_rec(fhead_w + idx)->dp : bank_dp[pb][idx];
+                            if ((x & SEED_FAR) ? idx < fin : idx < ncarry) bk[sl].x = (x & SEED_FAR) ? (uint32_t)far_rec(fhead_w + idx)->dp : bank_dp[pb][idx];
                         }
                     }
                     wave_sync();

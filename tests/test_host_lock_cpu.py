@@ -1,4 +1,4 @@
-"""The small-call combiner's lock (kgpu_api.cpp: struct SpinLock -- test-and-test-and-set with backoff, a yield every 2048 spins) stressed on the CPU, no
+"""The small-call combiner's lock (kgpu_api.cpp: struct SpinLock -- test-and-test-and-set with backoff, a few yields, then a futex sleep on the word) stressed on the CPU, no
 device: the struct is cut out of the source AS IT STANDS and compiled into tests/c_abi/lock_stress.cpp.  The combiner serves the reference's call shape --
 tokenize(&self) from many threads, one sentence per call (src/tokenizer.rs:16, src/bin/kanpyo.rs:106-126); its parity under load is
 tests/test_gpu_concurrent.py's business, this test is about the lock letting exactly one thread in."""
@@ -21,7 +21,7 @@ def shipped_lock(d):
     assert "alignas(64) SpinLock mu;" in s, "the combiner no longer uses SpinLock: point this test at its lock"
     h = os.path.join(d, "shipped_lock.h")
     with open(h, "w") as f:
-        f.write("#include <atomic>\n#include <cstdint>\n#include <sched.h>\n" + s[i:j] + "\n")
+        f.write("#include <atomic>\n#include <cstdint>\n#include <sched.h>\n#include <linux/futex.h>\n#include <sys/syscall.h>\n#include <unistd.h>\n" + s[i:j] + "\n")
     return h
 
 
