@@ -553,6 +553,14 @@ static int next_event(kgpu_ctx *c, hipEvent_t *ev) {
 static int ctx_pick_chain(kgpu_ctx *c, uint64_t n, uint64_t total_bytes, bool dump) {
     const unsigned lim = c->plan.window_first_bytes;   // (KGPU_WINDOW_FIRST, read with the launch plan when the context is created)
     c->window_first = lim && n && c->plan.n_pools && c->plan.window_lds_bytes && !dump && c->stop_after == 0 && !c->no_window && total_bytes >= (uint64_t)lim * n;
+    // Dense lattices: when four reservations of the learnt size (LDS bytes per input byte, steered by the redo rate: kgpu_ctx_sync) do not fit the pool, the
+    // batch's pool workgroups get THREE wavefronts -- a fourth sentence would only wait for pages (the dense-lattice dictionary, natural density N/C = 8.6:
+    // 57.8 -> 62.2 M sentences/s; cfg 2's reservations fit and it stays at four: three would cost it 21 %; profiles/experiments/r06_tile_sweep.txt)
+    {
+        static const unsigned pct = [] { const char *e = getenv("KGPU_ROOMY_PCT"); const int v = e ? atoi(e) : 92; return (unsigned)(v < 0 ? 0 : v); }();   // (measurement; 0 = never)
+        const uint64_t est1 = n ? ((total_bytes / n) * c->dict->est_q8.load(std::memory_order_relaxed) >> 8) + 768u : 0u;
+        c->roomy = pct && n && c->plan.n_pools && c->plan.pool_limit_auto && c->plan.pool_waves[0] == 4 && 4u * est1 * 100u > (uint64_t)c->plan.pool_bytes[0] * pct;
+    }
     if (c->own_stream) { c->h2d_queued = false; return KGPU_OK; }
     hipStream_t want = c->short_stream;
     // ... and so does a pool-first chain whose last batch sent an eighth or more of its sentences on to the windowed kernel: its launches behind the pool
@@ -631,6 +639,7 @@ static int enqueue(kgpu_ctx *c, const BatchArgs &a) {
             pl.pool_bytes[0] = pl.alt_pool_bytes; pl.pool_waves[0] = pl.alt_pool_waves; pl.pool_workgroups[0] = pl.alt_pool_workgroups;
             pl.pool_max_pages[0] = a.n <= 4u * 4096u ? 56u : 64u;
         }
+        else if (pools_now > 0 && c->roomy) pl.pool_waves[0] = 3;   // (the same pools, the same grid: a workgroup's tickets hand its share out to three wavefronts)
         // The windowed launch behind the pools: as many workgroups as the last batch's share of routed sentences suggests (+ a quarter), not the chip's 4096 -- the
         // list is strided, so an estimate that is too small only makes a workgroup take a second sentence (the context's first batch gets the full grid).
         static const int grid_mode = [] { const char *e = getenv("KGPU_WINDOW_GRID"); return e ? atoi(e) : -1; }();   // (measurement: 0 = always the full grid)

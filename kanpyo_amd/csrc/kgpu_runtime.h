@@ -107,6 +107,7 @@ struct kgpu_ctx {
     hipStream_t short_stream = nullptr, long_stream = nullptr;   // what `stream` alternates between (library-owned streams only)
     bool own_stream = false;            // the caller's stream: never switched
     bool window_first = false;          // the next batch's chain starts with the windowed kernel (no pool launch in front)
+    bool roomy = false;                 // ... its pool workgroups run three wavefronts instead of four (four reservations of the learnt size do not fit a pool)
     bool last_team = false;             // the pending batch's chain started with the two-wavefronts-per-sentence form (one more work list in the chain)
     int counted_long = 0;               // what the pending batch added to kgpu_dict::long_sentences_in_flight
     uint32_t win_share_q8 = 0;          // share of the last pool-first batch's sentences that the pools routed to the windowed kernel (x256): an eighth or more
