@@ -71,7 +71,7 @@ struct kgpu_dict {
     std::vector<kgpu_ctx *> pool;
     // LDS bytes reserved per input byte (x256) by the pool kernel before the lattice is known; a
     // property of the dictionary + the text, so it is learnt once and shared by all contexts
-    std::atomic<uint32_t> est_q8{80 * 256};
+    std::atomic<uint32_t> est_q8{64 * 256};   // (round 6: the lattice takes ~52 bytes of LDS per input byte on IPADIC-shaped text; was 80)
     // Batches left for which the second (whole-CU) pool is launched.  Its workgroups need a CU's
     // entire LDS just to start and find their list empty, which stalls them -- and the launches
     // queued behind -- until both 80 KB pools of that CU have drained; so it is only issued while

@@ -256,6 +256,38 @@ def test_full_size_properties_cfg2(full):
     assert checked >= 4
 
 
+def test_full_size_dense_dictionary(libs):
+    """The dense-lattice variant of the 392k-record dictionary (natural density, SURVEY 8a a15: N ~ 8-10 x C; more than eight predecessors at 61 % of the
+    positions -- target groups of several tiles, chunks that combine, three wavefronts per pool by the runtime's rule): cfg 2-shaped text at full size
+    (100k sentences, batches of 4096), the tiling properties on all of it, oracle equality on every 6th batch."""
+    from kanpyo_amd import Tokenizer, synth
+    from kanpyo_amd.tokenizer import pack_sentences
+
+    _, oracle = libs
+    sd = synth.build_dict(dense=True)
+    tok, orc = Tokenizer(sd.dict), oracle.OracleTokenizer.from_dict(sd.dict)
+    sents = synth.make_corpus(sd, 100_000, 1, "cfg2")
+    checked = 0
+    for lo in range(0, len(sents), 4096):
+        utf8, offs = pack_sentences(sents[lo : lo + 4096])
+        t, toff, status = tok.tokenize_packed(utf8, offs)
+        assert not status.any()
+        cnt = (toff[1:] - toff[:-1]).astype(np.int64)
+        assert (cnt >= 1).all()
+        last = t[toff[1:].astype(np.int64) - 1]
+        assert (last["cls"] == 0).all() and np.array_equal(last["position"].astype(np.int64), (offs[1:] - offs[:-1]).astype(np.int64))
+        first = np.zeros(len(t), dtype=bool); first[toff[:-1].astype(np.int64)] = True
+        nxt = ~first
+        assert (t["position"][first] == 0).all()
+        assert np.array_equal(t["position"][nxt], (t["position"] + t["byte_len"])[np.nonzero(nxt)[0] - 1])
+        if lo % (4096 * 6) == 0:
+            exp = orc.tokenize_batch(utf8, offs, 8)
+            assert np.array_equal(toff, exp.offsets) and np.array_equal(t, exp.tokens)
+            checked += 1
+    assert checked >= 4
+    tok.close()
+
+
 def _device_run(tok, sentences, mode):
     """Drive the device-resident C ABI (kgpu_ctx_*) with torch-owned HBM buffers."""
     import torch
