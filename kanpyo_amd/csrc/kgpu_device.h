@@ -340,7 +340,7 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t k) {  // over the 64 l
 // A tile is up to 8 targets x 8 predecessors of one start position, pair (ti, j) on lane 8 ti + j; a position with T targets and P predecessors is
 // ceil(T / 8) x ceil(P / 8) tiles -- (a, b) = (target group, predecessor chunk), b fastest: a group's chunks are consecutive, the last one reduces and stores.
 // Descriptor (two words, built once per position by the kernel): D0 = LDS address of node[t0 + 8 a] (18 bits) | 8 (Tt - 1) << 18 (6 bits) | 8 (Pt - 1) << 24 (6) |
-// first chunk << 30 | last chunk << 31 (the two byte offsets ready-made: one s_bfe each where they are used), D1 = LDS address of bk[p0 + 8 b].  node[t] = {word cost (i16) | bucket slot of the node << 16, byte offset of the node's
+// first chunk << 30 | last chunk << 31 (the two byte offsets ready-made: one s_bfe each where they are used), D1 = LDS address of bk[p0 + 8 b].  node[t] = {word cost (i16) | BYTE OFFSET of the node's bucket slot << 16 (8 x slot: SLOT_SHIFT; the kernels' LDS budgets keep slots below 8192), byte offset of the node's
 // matrix row (left * rows * 2)}; bk[] = bucket entries {dp, 2 * right | node index << 16} (the node index relative to whatever base the kernel uses).
 //   GATHER: the lane loads its own connection cost M[right(j)][left(ti)] from the matrix into a REGISTER (byte offset = row offset + 2 * right: one add) -- no
 //     pair table in LDS -- and a group of eight tiles is requested while the previous group is swept: the matrix's latency is off the dependency chain.
@@ -354,6 +354,7 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t k) {  // over the 64 l
 // minima 43, a taken branch 32): no fence per tile -- one wavefront's DS instructions execute in issue order.
 struct TileGroup { uint32_t c[8]; };   // per tile of a group: the lane's connection cost (a dword loaded at the cost's 2-byte-aligned address; the low half counts)
 constexpr uint32_t TILE_FIRST = 1u << 30, TILE_LAST = 1u << 31;
+constexpr uint32_t SLOT_SHIFT = 19, SLOT_MAX = 8191;   // node[t].x = word cost | slot << SLOT_SHIFT: the upper half IS the slot's byte offset in bk[] (one sdwa add in the sweep)
 __device__ __forceinline__ uint32_t tile_desc0(uint32_t a_node_t, uint32_t Tt, uint32_t Pt, bool first, bool last) {
     return a_node_t | ((Tt - 1u) << 21) | ((Pt - 1u) << 27) | (first ? TILE_FIRST : 0u) | (last ? TILE_LAST : 0u);
 }
@@ -396,7 +397,7 @@ __device__ __forceinline__ void tile_sweep8(const TileGroup &G, uint32_t d0, uin
             const int32_t tot = vmin + (int32_t)(int16_t)cs;
             const bool ok = tot < INF;
             lds_st<uint16_t>(na + 4u, (uint16_t)((ok ? nmin : 0xFFFFFFFFu) >> 16));
-            lds_st<uint32_t>(a_bk + 8 * (cs >> 16), (uint32_t)(ok ? tot : INF));
+            lds_st<uint32_t>(a_bk + (cs >> 16), (uint32_t)(ok ? tot : INF));
         };
         // (ONE test for "the only chunk of its group" in front of a second copy of the reduction measured 5 % SLOWER: 111-115 against 117-121 M sentences/s)
         {

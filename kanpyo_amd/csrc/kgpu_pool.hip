@@ -116,6 +116,46 @@ __device__ __forceinline__ uint32_t pool_wait_alloc(uint64_t *bm, uint32_t k, ui
     return NONE;
 }
 
+
+// The backtrace (lattice.rs:144-153), one lane: node `last` (EOS), then best predecessors (the low half of node[].y; a_y = LDS address of node[0].y) until a
+// node has none -- BOS, or a node nothing reached; the indices go to the half-words at a_path, last first.  -> their count.  The walk costs the whole
+// wavefront a slot of four cycles per instruction for one lane's work, K times a sentence, and the compiler's version of this loop is seventeen instructions a
+// step (exec-mask bookkeeping for the divergent exit, the loaded half-word zero-extended again, values moved between registers): spelled out it is the
+// address (one shift-add), the read, the test, the exit branch, the path's store -- two steps a round so that nothing moves, then the cursor, the count and
+// the bound (node indices fall strictly along a path, so it ends within C + 1 steps; the walk is bounded all the same -- a round may run one step over: the
+// two bytes behind path[] are the dead category array's -- and the count clamped).
+__device__ __forceinline__ uint32_t backtrace_path(uint32_t a_y, uint32_t a_path, uint32_t last, uint32_t C) {
+    uint32_t pos = last, pa = a_path, ad, pr, k;
+    asm volatile(
+        "s_mov_b32 %[k], 0\n"
+        "Lbt_loop%=:\n\t"
+        "v_lshl_add_u32 %[ad], %[pos], 3, %[ay]\n\t"
+        "ds_read_u16 %[pr], %[ad]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0xffff, %[pr]\n\t"
+        "s_cbranch_vccnz Lbt_done%=\n\t"
+        "ds_write_b16 %[pa], %[pos]\n\t"
+        "v_lshl_add_u32 %[ad], %[pr], 3, %[ay]\n\t"
+        "ds_read_u16 %[pos], %[ad]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0xffff, %[pos]\n\t"
+        "s_cbranch_vccnz Lbt_odd%=\n\t"
+        "ds_write_b16 %[pa], %[pr] offset:2\n\t"
+        "v_add_u32_e32 %[pa], 4, %[pa]\n\t"
+        "s_add_u32 %[k], %[k], 2\n\t"
+        "s_cmp_le_u32 %[k], %[c]\n\t"
+        "s_cbranch_scc1 Lbt_loop%=\n\t"
+        "s_branch Lbt_done%=\n"
+        "Lbt_odd%=:\n\t"
+        "s_add_u32 %[k], %[k], 1\n"
+        "Lbt_done%=:\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [k] "=&s"(k), [pos] "+v"(pos), [pa] "+v"(pa), [ad] "=&v"(ad), [pr] "=&v"(pr)
+        : [ay] "s"(a_y), [c] "s"(C)
+        : "vcc", "scc", "memory");
+    return min(k, C + 1);
+}
+
 }  // namespace
 
 // PROF: device-side work counters + per-phase shader clocks (KGPU_PROFILE_WORK).  A separate
@@ -204,13 +244,33 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         if (Bl + 64 > pool_cap || Bl > 0xFFF0) { defer_s(s); continue; }
         const uint32_t B = (uint32_t)Bl;
         const uint8_t *gtext = a.utf8 + b0;
-        // chars of the sentence (sizes the per-position arrays); the bytes are re-read from L1 below
-        uint32_t C = 0;
-        for (uint32_t k0 = 0; k0 < B; k0 += 64) {
-            const uint32_t k = k0 + lane;
-            const uint32_t b = k < B ? gtext[k] : 0x80u;
-            C += __popcll(__ballot(k < B && (b & 0xC0) != 0x80));
-        }
+        // chars of the sentence (sizes the per-position arrays).  A sentence of up to ~250 bytes is ONE load: lane l takes the aligned dword l of the text (an
+        // aligned dword that holds a byte of the sentence never leaves its page), a byte-align with the next lane's word makes it bytes 4 l .. 4 l + 3 of the
+        // sentence, bytes past the end become continuation bytes (0x80: they start no character, and the four behind the end are the padding the decoder
+        // reads); the characters are counted from the words and the words go to LDS as they are below.  Longer ones: a byte per lane and round, re-read from L1.
+        const uint32_t tsh = (uint32_t)(uintptr_t)gtext & 3u;
+        const bool one_load = B + tsh + 4 <= 256;
+        auto load_words = [&]() {
+            uint32_t w = 0x80808080u;
+            const uint32_t lo = 4 * lane;
+            if (B != 0 && lo < tsh + B) w = *(const uint32_t *)(gtext - tsh + lo);
+            const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)w, (int)w, 0x130 /* wave_shl:1: lane l reads lane l + 1 */, 0xF, 0xF, false);
+            const uint32_t al = __builtin_amdgcn_alignbyte(nx, w, tsh);
+            const uint32_t q1 = (uint32_t)min(max((int32_t)B - (int32_t)lo, 0), 4);
+            const uint32_t m = q1 >= 4 ? 0xFFFFFFFFu : ((1u << (8 * q1)) - 1u);   // the sentence's bytes in this word
+            return (al & m) | (0x80808080u & ~m);
+        };
+        uint32_t C = 0, tw = 0;
+        if (one_load) {
+            tw = load_words();
+            const uint32_t cont = tw & ~(tw << 1) & 0x80808080u;   // bit 7 of every 10xxxxxx byte
+            C = 256u - (uint32_t)(__popcll(__ballot((cont & 0x80u) != 0)) + __popcll(__ballot((cont & 0x8000u) != 0)) + __popcll(__ballot((cont & 0x800000u) != 0)) + __popcll(__ballot((cont & 0x80000000u) != 0)));
+        } else
+            for (uint32_t k0 = 0; k0 < B; k0 += 64) {
+                const uint32_t k = k0 + lane;
+                const uint32_t b = k < B ? gtext[k] : 0x80u;
+                C += __popcll(__ballot(k < B && (b & 0xC0) != 0x80));
+            }
         // reservation: what the per-position arrays + match buffer need for sure, or the host-adapted
         // estimate of the whole lattice, whichever is larger.  A sentence expected not to fit an empty
         // pool is routed on without paying for a trie walk that would be thrown away.
@@ -243,11 +303,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         KGPU_TICK(0);
         // ---- phase 0a: stage the sentence in LDS, count chars -----------------
         uint8_t *text = smem;
-        for (uint32_t k0 = 0; k0 < B + 4; k0 += 64) {
-            const uint32_t k = k0 + lane;
-            const uint32_t b = k < B ? gtext[k] : 0x80u;
-            if (k < B + 4) text[k] = (uint8_t)b;
-        }
+        if (one_load && attempt == 0) {   // (a redo stages the bytes the long way)
+            if (4 * lane < B + 4) *(uint32_t *)(smem + 4 * lane) = tw;
+        } else
+            for (uint32_t k0 = 0; k0 < B + 4; k0 += 64) {
+                const uint32_t k = k0 + lane;
+                const uint32_t b = k < B ? gtext[k] : 0x80u;
+                if (k < B + 4) text[k] = (uint8_t)b;
+            }
         // ---- LDS carve: per-char arrays from the bottom, match buffer from the top
         uint32_t off = align_up(B + 4, 4);
         uint32_t *nb = (uint32_t *)(smem + off);    off += 4 * (C + 2);  // node count -> first node index
@@ -428,7 +491,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         const uint32_t off_emit_end = off;                          // everything above is written by emit 3a
         uint2 *bk = (uint2 *)(smem + off);          off += 8 * (Nb + 2);  // bucket (= edges[e]): {dp, 2 * right | node << 16}; [Nb]: sink for EOS; [Nb + 1]: the absent candidate
         uint2 *tiles = (uint2 *)(smem + off);                       // the tile list
-        if (N > 0xFFFF) { defer_s(s); break; }
+        if (N > 0xFFFF || Nb + 1 > SLOT_MAX) { defer_s(s); break; }   // (neither fits a pool: 8 bytes per bucket entry)
         // exact requirement: what 3a writes stays below the match buffer; afterwards the buckets and the tile list overlay it
         const uint32_t need_emit = off_emit_end + mbytes + 16, need_full = off + 8 * NTp;
         if (need_emit > lds_bytes || need_full > lds_bytes) {
@@ -496,13 +559,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             for (int k = 0; k < 4; ++k) {
                 if (tt[k] < N - 1) {
                     const uint32_t slot = boff[ee[k]] + atomicAdd(&bfill[ee[k]], 1u);
-                    node[tt[k]] = make_uint2((uint32_t)(uint16_t)mm[k].cost | (slot << 16), (uint32_t)(uint16_t)mm[k].left * rows2);
+                    node[tt[k]] = make_uint2((uint32_t)(uint16_t)mm[k].cost | (slot << SLOT_SHIFT), (uint32_t)(uint16_t)mm[k].left * rows2);
                     bk[slot].y = ((uint32_t)(uint16_t)mm[k].right << 1) | (tt[k] << 16);   // ids are non-negative i16 (checked at create): 2 * right fits the half-word
                 }
             }
         }
         if (lane == 0) {
-            node[N - 1] = make_uint2(Nb << 16, d.eos_left * rows2);  // EOS: Morph(0,0,0), ranked id; its dp goes to the sink slot
+            node[N - 1] = make_uint2(Nb << SLOT_SHIFT, d.eos_left * rows2);  // EOS: Morph(0,0,0), ranked id; its dp goes to the sink slot
             nSid[N - 1] = 0;
             bk[0] = make_uint2(0u, d.bos_right << 1);  // BOS: dp None -> 0 (lattice.rs:127), right_id 0 (ranked), node 0
             bk[Nb + 1] = make_uint2(0x7FFEFFFFu, 0u);  // what a position without predecessors relaxes from: a total no real one reaches (real <= INF + 32767) that
@@ -552,10 +615,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         KGPU_ARGS();
         // ---- phase 5: backtrace (lattice.rs:144-153) + Node -> Token (tokenizer.rs:22-43)
         uint32_t K = 0;
-        if (lane == 0) {
-            uint32_t pos = N - 1, pr;
-            while ((pr = node[pos].y & 0xFFFFu) != NONE16 && K <= C) { path[K++] = (uint16_t)pos; pos = pr; }  // K <= C + 1 always; bound the walk anyway
-        }
+        if (lane == 0) K = backtrace_path(a_node + 4, lds0 + (uint32_t)((uint8_t *)path - pool), N - 1, C);
         K = bcast32(K);
         // staging slot of the sentence: K <= C + 1 <= B + 1 tokens always fit at b0 + s
         // (no cursor atomics: a single hot word serialises ~90 sentences/us chip-wide)
@@ -563,23 +623,29 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         wave_sync();
         {
             // the start position of node t: the last i with nb[i] <= t (nb[] = first node index per position, ascending; an empty position shares its
-            // successor's) -- a binary search per token instead of a half-word per node written by emit and kept in LDS through the sweep
+            // successor's; nb[C + 1] = N > t stops a probe past the end) -- a binary search per token instead of a half-word per node written by emit and kept
+            // in LDS through the sweep.  A word is never last on the path (EOS is): it ends where its successor starts -- the next lane's search.
             const uint32_t hb = 1u << (31 - __clz((int)max(C, 1u)));
-            auto start_of = [&](uint32_t t) { uint32_t lo = 0; for (uint32_t st = hb; st; st >>= 1) { const uint32_t m = lo + st; if (m <= C && nb[m] <= t) lo = m; } return lo; };
-            for (uint32_t k = lane; k < K; k += 64) {
-                const uint32_t t = path[K - 1 - k];
-                const int32_t sid = nSid[t];
-                kgpu_token tk;
-                if (sid == 0) {  // Dummy -> "EOS" (tokenizer.rs:27-28,34)
-                    tk.id = 0; tk.cls = KGPU_CLASS_DUMMY; tk.position = B; tk.start = C; tk.end = C + 3; tk.byte_len = 0;
-                } else {
-                    // a word is never last on the path (EOS is): it ends where its successor starts
-                    const uint32_t st = start_of(t), en = start_of(path[K - 2 - k]), bs = cbyte[st];
-                    tk.id = sid > 0 ? sid : -sid;
-                    tk.cls = sid > 0 ? KGPU_CLASS_KNOWN : KGPU_CLASS_UNKNOWN;
-                    tk.position = bs; tk.start = st; tk.end = en; tk.byte_len = cbyte[en] - bs;
+            auto start_of = [&](uint32_t t) { uint32_t lo = 0; for (uint32_t st = hb; st; st >>= 1) { const uint32_t m = min(lo + st, C + 1); if (nb[m] <= t) lo = m; } return lo; };
+            for (uint32_t k0 = 0; k0 < K; k0 += 64) {
+                const uint32_t k = k0 + lane;
+                const uint32_t t = path[K - 1 - min(k, K - 1)];
+                const uint32_t st = start_of(t);
+                uint32_t en = (uint32_t)__builtin_amdgcn_update_dpp((int)st, (int)st, 0x130 /* wave_shl:1: lane l reads lane l + 1 */, 0xF, 0xF, false);
+                if (lane == 63 && k + 1 < K) en = start_of(path[K - 2 - k]);   // (more than 64 tokens: the successor belongs to the next round)
+                if (k < K) {
+                    const int32_t sid = nSid[t];
+                    kgpu_token tk;
+                    if (sid == 0) {  // Dummy -> "EOS" (tokenizer.rs:27-28,34)
+                        tk.id = 0; tk.cls = KGPU_CLASS_DUMMY; tk.position = B; tk.start = C; tk.end = C + 3; tk.byte_len = 0;
+                    } else {
+                        const uint32_t bs = cbyte[st];
+                        tk.id = sid > 0 ? sid : -sid;
+                        tk.cls = sid > 0 ? KGPU_CLASS_KNOWN : KGPU_CLASS_UNKNOWN;
+                        tk.position = bs; tk.start = st; tk.end = en; tk.byte_len = cbyte[en] - bs;
+                    }
+                    a.stage[ts + k] = tk;
                 }
-                a.stage[ts + k] = tk;
             }
         }
         if (lane == 0) { a.status[s] = KGPU_SENT_OK; a.tok_count[s] = K; }

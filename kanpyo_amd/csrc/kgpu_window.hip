@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                                           off0 + 8 * (Nb + NF + 1) + align_up(Nb, 8) + cbytes(Nb - boff[nw]) + (lds_bytes - moff));
             const uint32_t lds_base = off0 + mbytes + 16;
             const uint32_t fit_len = (nw * (lds_bytes - lds_base) * 7u) / (max(lds_used, lds_base + 1u) - lds_base) / 8u;   // (63 x 160 KB x 7 < 2^32)
-            if (N > 0x7FFF || NF >= 0x7FFF || Nb + NF > 0xFFF0 || lds_used > lds_bytes) {
+            if (N > 0x7FFF || NF >= 0x7FFF || Nb + NF + 1 > SLOT_MAX || lds_used > lds_bytes) {   // (SLOT_MAX: a node carries its slot's byte offset in a half-word)
                 if (wlim > 4 && nw > 1) { wlim = max(4u, min(nw - 1, fit_len)); continue; }  // the same window once more, as long as the LDS allows at this density
                 failed = true; why = 8;
                 break;
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                         if (ee[k] == 0x7FFFu) slot = Nb + NF;                                   // EOS: the sink
                         else if (ee[k] & 0x8000u) slot = Nb + (ee[k] & 0x7FFFu);                 // ends beyond the LDS buckets: a far-out slot
                         else { slot = boff[ee[k]] + atomicAdd(&bfill[ee[k]], 1u); brel[slot] = (uint8_t)ee[k]; }
-                        node[tt[k]] = make_uint2((uint32_t)(uint16_t)mm[k].cost | (slot << 16), (uint32_t)(uint16_t)mm[k].left * rows2);
+                        node[tt[k]] = make_uint2((uint32_t)(uint16_t)mm[k].cost | (slot << SLOT_SHIFT), (uint32_t)(uint16_t)mm[k].left * rows2);
                         bk[slot] = make_uint2((uint32_t)INF, ((uint32_t)(uint16_t)mm[k].right << 1) | ((gw + tt[k] - rb) << 16));   // (2 * right: ids are non-negative i16)
                     }
                 }
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                                             if (tot < INF) { dpv = tot; prv = (uint32_t)kk - rb; }
                                         }
                                         node[t0 + tg + k].y = prv & 0xFFFFu;
-                                        bk[cs >> 16].x = (uint32_t)dpv;
+                                        bk[cs >> SLOT_SHIFT].x = (uint32_t)dpv;
                                     }
                                 }
                             wave_sync();
