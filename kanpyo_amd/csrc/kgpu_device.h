@@ -209,7 +209,8 @@ __device__ __forceinline__ void ct_walk(const DictView &d, int32_t p, int32_t bp
         if (leaf < 0) { uint32_t id, dup; leaf_decode(d, leaf, id, dup); on_match(id, depth, dup); }
         const uint32_t c = code_at(depth);
         const uint32_t q = (uint32_t)bp + c;
-        const CtNode nx = d.da2[(c != 0xFFFFu && q < d.da2_len) ? q : 0u];
+        CtNode nx = d.da2[(c != 0xFFFFu && q < d.da2_len) ? q : 0u];
+        asm volatile("" : "+v"(nx.base), "+v"(nx.check), "+v"(nx.leaf));   // ONE load: left alone, the compiler loads `check` first and the rest behind the test -- a second round trip a character
         if (nx.check != p) break;  // da.rs:162-165 (slot 0 has check 0, nodes start at 1)
         p = (int32_t)q;
         bp = nx.base;
@@ -227,8 +228,9 @@ __device__ __forceinline__ void ct_walk2(const DictView &d, bool onA, CA &&codeA
     while (a.live || b.live) {
         const uint32_t cA = a.live ? codeA(a.depth) : 0xFFFFu, cB = b.live ? codeB(b.depth) : 0xFFFFu;
         const uint32_t qA = (uint32_t)a.bp + cA, qB = (uint32_t)b.bp + cB;
-        const CtNode nA = d.da2[(cA != 0xFFFFu && qA < d.da2_len) ? qA : 0u];
-        const CtNode nB = d.da2[(cB != 0xFFFFu && qB < d.da2_len) ? qB : 0u];
+        CtNode nA = d.da2[(cA != 0xFFFFu && qA < d.da2_len) ? qA : 0u];
+        CtNode nB = d.da2[(cB != 0xFFFFu && qB < d.da2_len) ? qB : 0u];
+        asm volatile("" : "+v"(nA.base), "+v"(nA.check), "+v"(nA.leaf), "+v"(nB.base), "+v"(nB.check), "+v"(nB.leaf));   // (whole records, both in flight: see ct_walk)
         if (a.live) {
             if (nA.check != a.p) a.live = false;
             else {

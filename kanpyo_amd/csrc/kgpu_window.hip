@@ -976,12 +976,42 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                 for (;;) {
                     uint32_t npos = pos, nnl = nl, fin2 = 0;
                     if (lane == 0) {
-                        for (;;) {
-                            const uint32_t pr = win[npos - wlo];
-                            if (pr == NONE || K + nnl > C) { fin2 = 1; break; }  // the chain's first node (normally BOS) is dropped
-                            lpath[nnl++] = npos;
-                            npos = pr;
-                            if (npos < wlo || nnl == PATHL) break;
+                        // (one lane's walk at the whole wavefront's four cycles an instruction: spelled out -- the compiler's version of this loop is 32 instructions
+                        // a step, this one 13: the address, the read, the end test, the path's store, the window test, the count.  `cap`: room in the parked path,
+                        // and the bound C + 1 on a path's length, which a chain of falling indices cannot reach before its end: then the walk is over as well.)
+                        const uint32_t room = PATHL - nnl, left = K + nnl > C ? 0u : C + 1 - K - nnl, cap = min(room, left);
+                        const uint32_t a_lds = (uint32_t)(uintptr_t)(KGPU_LDS(uint8_t) *)lds;
+                        const uint32_t a_rel = a_lds + (uint32_t)((uint8_t *)win - lds) - 4u * wlo;   // LDS address of win[i - wlo] = a_rel + 4 i
+                        uint32_t lp = a_lds + (uint32_t)((uint8_t *)(lpath + nnl) - lds), n = 0, ad, pr;
+                        if (cap == 0) fin2 = 1;
+                        else {
+                            asm volatile(
+                                "s_mov_b32 %[n], 0\n\t"
+                                "s_mov_b32 %[fin], 0\n"
+                                "Lwb_loop%=:\n\t"
+                                "v_lshl_add_u32 %[ad], %[pos], 2, %[rel]\n\t"
+                                "ds_read_b32 %[pr], %[ad]\n\t"
+                                "s_waitcnt lgkmcnt(0)\n\t"
+                                "v_cmp_eq_u32_e32 vcc, -1, %[pr]\n\t"
+                                "s_cbranch_vccnz Lwb_fin%=\n\t"
+                                "ds_write_b32 %[lp], %[pos]\n\t"
+                                "v_add_u32_e32 %[lp], 4, %[lp]\n\t"
+                                "v_mov_b32_e32 %[pos], %[pr]\n\t"
+                                "s_add_u32 %[n], %[n], 1\n\t"
+                                "v_cmp_gt_u32_e32 vcc, %[wlo], %[pr]\n\t"
+                                "s_cbranch_vccnz Lwb_out%=\n\t"
+                                "s_cmp_lt_u32 %[n], %[cap]\n\t"
+                                "s_cbranch_scc1 Lwb_loop%=\n\t"
+                                "s_branch Lwb_out%=\n"
+                                "Lwb_fin%=:\n\t"
+                                "s_mov_b32 %[fin], 1\n"
+                                "Lwb_out%=:\n\t"
+                                "s_waitcnt lgkmcnt(0)"
+                                : [n] "=&s"(n), [fin] "=&s"(fin2), [pos] "+v"(npos), [lp] "+v"(lp), [ad] "=&v"(ad), [pr] "=&v"(pr)
+                                : [rel] "s"(bcast32(a_rel)), [wlo] "s"(bcast32(wlo)), [cap] "s"(bcast32(cap))
+                                : "vcc", "scc", "memory");
+                            nnl += n;
+                            if (!fin2 && n == cap && left <= room) fin2 = 1;   // the bound, not the parking space: over
                         }
                     }
                     pos = bcast32(npos); nl = bcast32(nnl); done = bcast32(fin2) != 0;
