@@ -423,10 +423,12 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
         d->view.da2_len = (uint32_t)ct.da.size();
         d->view.n_nb = (uint32_t)ct.nb_cp.size();
     }
+    // ONE table for the known and the unknown words' records (DictView: unk_morph == morph + n_morph): a node's record is one index away whichever kind it is
+    std::vector<Morph8> all_morphs(morphs);
+    all_morphs.insert(all_morphs.end(), unk_morphs.begin(), unk_morphs.end());
     conn.resize(conn.size() + 2, 0);   // the pool kernel reads a cost with a dword load at its (2-byte-aligned) address: the last element's load stays inside the allocation
     if ((rc = upload(d, first, &d->view.first)) ||
-        (rc = upload(d, da, &d->view.da)) || (rc = upload(d, morphs, &d->view.morph)) ||
-        (rc = upload(d, unk_morphs, &d->view.unk_morph)) || (rc = upload(d, conn, &d->view.conn)) ||
+        (rc = upload(d, da, &d->view.da)) || (rc = upload(d, all_morphs, &d->view.morph)) || (rc = upload(d, conn, &d->view.conn)) ||
         (rc = upload(d, cat, &d->view.cat)) || (rc = upload(d, cinfo, &d->view.cinfo))) {
         kgpu_dict_destroy(d);
         return rc;
@@ -435,6 +437,7 @@ extern "C" int kgpu_dict_create(const kgpu_dict_blobs *b, int device, kgpu_dict 
     d->view.leaf_dup = leaf_dup;
     d->view.n_morph = (uint32_t)morphs.size();
     d->view.n_unk_morph = (uint32_t)unk_morphs.size();
+    d->view.unk_morph = d->view.morph + morphs.size();
     d->view.conn_rows = (uint32_t)rows;
     d->view.bos_right = bos_right; d->view.eos_left = eos_left;
     d->view.cat_len = (uint32_t)std::min<size_t>(cat.size(), 0x110000);

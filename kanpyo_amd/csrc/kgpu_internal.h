@@ -55,7 +55,7 @@ struct DictView {
     const DaNode *first;     // [65536] per BMP code point: {node, base[node]} after walking its UTF-8 bytes from
                              // the root, or {0, byte steps attempted before the walk failed}
     const Morph8 *morph;     uint32_t n_morph;
-    const Morph8 *unk_morph; uint32_t n_unk_morph;
+    const Morph8 *unk_morph; uint32_t n_unk_morph;   // == morph + n_morph: one table (record of node sid: morph[sid > 0 ? sid - 1 : n_morph - 1 - sid])
     const int16_t *conn;     uint32_t conn_rows;  // element (right,left) at left*rows+right (ids frequency-ranked, see kgpu_api.cpp)
     uint32_t bos_right, eos_left;                  // the ranked ids of context id 0 (BOS/EOS Morph(0,0,0))
     const uint8_t *cat;      uint32_t cat_len;    // char_category_def.rs:17,33-38

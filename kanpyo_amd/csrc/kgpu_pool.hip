@@ -171,10 +171,13 @@ __device__ __forceinline__ uint32_t backtrace_path(uint32_t a_y, uint32_t a_path
 struct PoolArgs {
     DictView d; BatchArgs a; WorkIO io;
     uint32_t pool_bytes, max_pages, stop_after /* ablation timing only; 0 = run everything */;
+    uint32_t page, page_magic;   // bytes per page of the pool (pool_page_bytes) and floor(2^32 / page) + 1: pages_for is one multiply-high (exact below 2^32 / page bytes)
 };
 // BYTE: the dictionary has no character-level copy of its trie (KGPU_BYTE_TRIE, or a key set it cannot represent): the walk goes byte by byte.
 // A separate instantiation chosen at launch: the product kernel carries one walker, not two (SGPRs, spill code, instruction cache).
-template <bool PROF, bool BYTE>
+// WIDE: a parked match is two words {trie id, chars | records << 8} instead of one (a dictionary of 2^21 records or more, or leaves without their record
+// count): likewise chosen at launch -- tested per match in the walk and in the emit phase it was four instructions each time.
+template <bool PROF, bool BYTE, bool WIDE>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_WPE))) void k_tokenize_pool(PoolArgs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t pool[];
     typedef const __attribute__((address_space(4))) PoolArgs *KArgs;
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         a.utf8 = kq_->a.utf8; a.offsets = kq_->a.offsets; a.n = kq_->a.n; a.ctl = kq_->a.ctl; a.arena = kq_->a.arena; a.arena_bytes = kq_->a.arena_bytes; a.stage = kq_->a.stage; a.tok_count = kq_->a.tok_count; a.status = kq_->a.status; a.out = kq_->a.out; a.out_cap = kq_->a.out_cap; a.tok_offsets = kq_->a.tok_offsets; a.count_work = kq_->a.count_work; a.ovf[0] = kq_->a.ovf[0]; a.ovf[1] = kq_->a.ovf[1]; a.ovf[2] = kq_->a.ovf[2]; a.ovf[3] = kq_->a.ovf[3]; a.est_q8 = kq_->a.est_q8; a.dump_lattice = kq_->a.dump_lattice; a.fused_host = kq_->a.fused_host; a.fused_seq = kq_->a.fused_seq; a.stat_slots = kq_->a.stat_slots; \
         io.in_list = kq_->io.in_list; io.in_count = kq_->io.in_count; io.out_list = kq_->io.out_list; io.out_count = kq_->io.out_count; io.late_count = kq_->io.late_count; stop_after = kq_->stop_after; } while (0)
     KGPU_ARGS();
-    const uint32_t pool_bytes = kargs->pool_bytes, max_pages = kargs->max_pages;
+    const uint32_t max_pages = kargs->max_pages;
     const uint32_t lane = threadIdx.x & 63u, wave = bcast32(threadIdx.x >> 6) /* SGPR: everything per-sentence is wave-uniform */, W = blockDim.x >> 6;
     const int32_t base_root = d.da[1].base;
     // a sentence this kernel does not serve: onto the next launch's list; its token count reads 0 until a later kernel has served it (when the
@@ -197,8 +200,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
     // W == 1: the workgroup is one wavefront with a pool of its own -- a fixed LDS slice.  Nothing to share, nothing to wait for:
     // every sentence gets the whole slice (no estimate, no redo), what does not fit goes to the next launch.
     const bool own_slice = W == 1;
-    const uint32_t page = ((pool_bytes - POOL_HDR) / POOL_PAGES) & (own_slice ? ~7u : ~15u);
-    auto pages_for = [&](uint32_t bytes) { return (bytes + page - 1) / page; };  // (a reciprocal multiply instead: measured, no difference)
+    const uint32_t page = kargs->page, page_magic = kargs->page_magic;
+    auto pages_for = [&](uint32_t bytes) { return __umulhi(bytes + page - 1, page_magic); };   // = (bytes + page - 1) / page (launch_tokenize_pool)
     // the workgroup's sentences -- list entries blockIdx.x + k * gridDim.x -- are handed to its wavefronts by a ticket in LDS (the dword behind the bitmap): a
     // wavefront that is through takes the next one, instead of every wavefront owning every W-th (with four or more sentences per wavefront -- batches of 16 384 and
     // more -- the static form left the early finishers of a workgroup waiting for its slowest wavefront's whole share; no global atomic: that lost in round 2)
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         // pool is routed on without paying for a trie walk that would be thrown away.
         // a parked match: {trie id, chars | records << 8}; one word id (21 bits) | chars (8) | records (3; 0 = look the count up)
         // when the ids fit (DictView::leaf_dup: fewer than 2^21 morphs)
-        const uint32_t MS = (d.leaf_dup && d.n_unk_morph < (1u << 21)) ? 4u : 8u;
+        constexpr uint32_t MS = WIDE ? 8u : 4u;   // (launch_tokenize_pool: one word when d.leaf_dup and fewer than 2^21 records)
         const uint32_t need1 = align_up(B + 4, 4) + 22 * (C + 2) + 2 * align_up(C + 2, 4) + align_up(C * MAXM * MS, 16) + 32;
         const uint32_t est = max(need1, (uint32_t)(((uint64_t)B * a.est_q8) >> 8) + KGPU_EST_SLACK);
         uint32_t npg = own_slice ? POOL_PAGES : pages_for(est);
@@ -550,10 +553,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 tt[k] = t0 + 64 * k + lane;
-                const bool v = tt[k] < N - 1;
-                const int32_t sid = v ? nSid[tt[k]] : 1;
-                ee[k] = v ? node[tt[k]].y : 0u;
-                mm[k] = *(sid > 0 ? d.morph + (sid - 1) : d.unk_morph + (-sid - 1));
+                const uint32_t tc = min(tt[k], N - 2);   // (lanes past the last word read its entries: no exec mask around the reads; N >= 3 here)
+                const int32_t sid = nSid[tc];
+                ee[k] = node[tc].y;
+                mm[k] = d.morph[sid > 0 ? (uint32_t)sid - 1u : d.n_morph - 1u - (uint32_t)sid];   // the unknown words' records follow the known ones' (DictView)
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -625,8 +628,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
             // the start position of node t: the last i with nb[i] <= t (nb[] = first node index per position, ascending; an empty position shares its
             // successor's; nb[C + 1] = N > t stops a probe past the end) -- a binary search per token instead of a half-word per node written by emit and kept
             // in LDS through the sweep.  A word is never last on the path (EOS is): it ends where its successor starts -- the next lane's search.
+            // (any power of two >= the highest one in C may start the search -- a probe past the end is clamped onto nb[C + 1] -- so up to 255 characters it is eight
+            // steps with nothing between them; beyond, the loop)
             const uint32_t hb = 1u << (31 - __clz((int)max(C, 1u)));
-            auto start_of = [&](uint32_t t) { uint32_t lo = 0; for (uint32_t st = hb; st; st >>= 1) { const uint32_t m = min(lo + st, C + 1); if (nb[m] <= t) lo = m; } return lo; };
+            auto start_of = [&](uint32_t t) {
+                uint32_t lo = 0;
+                if (C < 256) {
+#pragma unroll
+                    for (uint32_t st = 128; st; st >>= 1) { const uint32_t m = min(lo + st, C + 1); if (nb[m] <= t) lo = m; }
+                } else
+                    for (uint32_t st = hb; st; st >>= 1) { const uint32_t m = min(lo + st, C + 1); if (nb[m] <= t) lo = m; }
+                return lo;
+            };
             for (uint32_t k0 = 0; k0 < K; k0 += 64) {
                 const uint32_t k = k0 + lane;
                 const uint32_t t = path[K - 1 - min(k, K - 1)];
@@ -769,28 +782,34 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
 // granularity makes this smaller than 160 KB / pool_bytes would suggest for odd sizes).
 int pool_workgroups_per_cu(uint32_t pool_bytes, uint32_t waves) {
     if (pool_bytes > 64 * 1024)
-        if (hipFuncSetAttribute((const void *)k_tokenize_pool<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)k_tokenize_pool<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes) != hipSuccess) return 0;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_pool<false, false>, (int)(64 * waves), (size_t)pool_bytes) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_tokenize_pool<false, false, false>, (int)(64 * waves), (size_t)pool_bytes) != hipSuccess) return 0;
     return n;
 }
 
-template <bool PROF, bool BYTE>
+template <bool PROF, bool BYTE, bool WIDE>
 static int launch_pool_inst(const PoolArgs &pa, uint32_t pool_bytes, uint32_t waves, int n_workgroups, void *stream) {
     if (pool_bytes > 64 * 1024) {  // beyond the default dynamic-LDS cap the kernel has to opt in
-        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool<PROF, BYTE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)k_tokenize_pool<PROF, BYTE, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((k_tokenize_pool<PROF, BYTE>), dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, pa);
+    hipLaunchKernelGGL((k_tokenize_pool<PROF, BYTE, WIDE>), dim3(n_workgroups), dim3(64 * waves), pool_bytes, (hipStream_t)stream, pa);
     return (int)hipGetLastError();
+}
+template <bool PROF, bool BYTE>
+static int launch_pool_wide(bool wide, const PoolArgs &pa, uint32_t pool_bytes, uint32_t waves, int n_workgroups, void *stream) {
+    return wide ? launch_pool_inst<PROF, BYTE, true>(pa, pool_bytes, waves, n_workgroups, stream) : launch_pool_inst<PROF, BYTE, false>(pa, pool_bytes, waves, n_workgroups, stream);
 }
 
 int launch_tokenize_pool(const DictView &d, const BatchArgs &a, const WorkIO &io, uint32_t pool_bytes, uint32_t waves,
                          uint32_t max_pages, int n_workgroups, uint32_t stop_after, void *stream) {
-    const PoolArgs pa{d, a, io, pool_bytes, max_pages, stop_after};
-    const bool byte_walk = d.da2 == nullptr;
-    if (a.count_work) return byte_walk ? launch_pool_inst<true, true>(pa, pool_bytes, waves, n_workgroups, stream) : launch_pool_inst<true, false>(pa, pool_bytes, waves, n_workgroups, stream);
-    return byte_walk ? launch_pool_inst<false, true>(pa, pool_bytes, waves, n_workgroups, stream) : launch_pool_inst<false, false>(pa, pool_bytes, waves, n_workgroups, stream);
+    const uint32_t page = ((pool_bytes - POOL_HDR) / POOL_PAGES) & (waves == 1 ? ~7u : ~15u);   // (a workgroup of one wavefront owns its slice: finer pages)
+    if (page == 0) return (int)hipErrorInvalidValue;
+    const PoolArgs pa{d, a, io, pool_bytes, max_pages, stop_after, page, (uint32_t)((1ull << 32) / page) + 1u};
+    const bool byte_walk = d.da2 == nullptr, wide = !(d.leaf_dup && d.n_unk_morph < (1u << 21));
+    if (a.count_work) return byte_walk ? launch_pool_wide<true, true>(wide, pa, pool_bytes, waves, n_workgroups, stream) : launch_pool_wide<true, false>(wide, pa, pool_bytes, waves, n_workgroups, stream);
+    return byte_walk ? launch_pool_wide<false, true>(wide, pa, pool_bytes, waves, n_workgroups, stream) : launch_pool_wide<false, false>(wide, pa, pool_bytes, waves, n_workgroups, stream);
 }
 
 }  // namespace kgpu

@@ -679,7 +679,7 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                     const bool v = tt[k] < N;
                     const int32_t sid = v ? nSid[tt[k]] : 1;
                     ee[k] = v ? node[tt[k]].y : 0u;
-                    mm[k] = sid == 0 ? Morph8{(int16_t)d.eos_left, 0, 0, 0} : *(sid > 0 ? d.morph + (sid - 1) : d.unk_morph + (-sid - 1));
+                    mm[k] = sid == 0 ? Morph8{(int16_t)d.eos_left, 0, 0, 0} : d.morph[sid > 0 ? (uint32_t)sid - 1u : d.n_morph - 1u - (uint32_t)sid];   // (one table: DictView)
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
