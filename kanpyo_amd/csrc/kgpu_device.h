@@ -413,11 +413,14 @@ __device__ __forceinline__ void tile_sweep8(const TileGroup &G, uint32_t d0, uin
         // first reads may slide under this tile's second reduction: 118.9 -> 121.6 M sentences/s over three interleaved runs)
     }
 }
-// Tiles [ta, tb) of the list at `tiles` (LDS), in order.  PADDED: tb - ta is a multiple of eight (the kernel padded its list with tiles that store nothing),
-// no per-tile guard.  null_tile: what the lanes past the end hold -- a descriptor whose gather address is always valid and that is never swept (a gather past
-// the last group reads it: NOT a group already swept, whose nodes' row offsets have their best predecessors in the low half by now).  sweep_on = false:
-// measurement (every group's gather, no sweep).
-template <bool PADDED>
+// Tiles [ta, tb) of the list at `tiles` (LDS), in order.  null_tile: what the lanes past the end of a window hold -- a descriptor whose gather address is
+// always valid and that is never swept (the last group's gather reads it for the tiles it does not have: NOT a group already swept, whose nodes' row offsets
+// have their best predecessors in the low half by now).  sweep_on = false: measurement (every group's gather, no sweep).
+// A window's groups are gathered one ahead of the sweep: while group g is swept out of one register set the costs of group g + 1 arrive in the other, and
+// are moved over when the sweep is through (eight register moves a group: by then they have long arrived).  Nothing is gathered behind a window's LAST group
+// -- the earlier form alternated the two sets and, to keep the compiler's wait counts exact on every path, gathered "for nothing" behind the end: a third of
+// all gathers on a cfg 2 sentence (~64 tiles in windows of 56: 13 group gathers for 8 groups) -- and only the last group's sweep (code of its own) tests a
+// tile against the count, so lists need no padding to whole groups.
 __device__ __forceinline__ void tiles_run(const uint2 *tiles, uint32_t ta, uint32_t tb, uint2 null_tile, uint32_t lane, uint32_t a_bk, const uint8_t *connb, bool sweep_on) {
     const uint32_t j8 = 8u * (lane & 7u), tg8 = lane & 0x38u;   // lane = 8 ti + j
     int32_t rv = 0; uint32_t ry = 0;
@@ -427,13 +430,14 @@ __device__ __forceinline__ void tiles_run(const uint2 *tiles, uint32_t ta, uint3
         const uint32_t nt = min(56u, tb - w0), ng = (nt + 7u) >> 3;
         TileGroup GA, GB;
         tile_gather8(GA, d0, d1, 0u, tg8, j8, connb);
-        for (uint32_t g = 0; g < ng; g += 2) {
-            tile_gather8(GB, d0, d1, g + 1 < ng ? 8 * (g + 1) : 56u, tg8, j8, connb);
-            if (sweep_on) tile_sweep8<!PADDED>(GA, d0, d1, 8 * g, nt - 8 * g, tg8, j8, a_bk, rv, ry);
-            tile_gather8(GA, d0, d1, g + 2 < ng ? 8 * (g + 2) : 56u, tg8, j8, connb);
-            if (g + 1 < ng && sweep_on) tile_sweep8<!PADDED>(GB, d0, d1, 8 * (g + 1), nt - 8 * (g + 1), tg8, j8, a_bk, rv, ry);
+        uint32_t g = 0;
+        for (; g + 1 < ng; ++g) {
+            tile_gather8(GB, d0, d1, 8 * (g + 1), tg8, j8, connb);
+            if (sweep_on) tile_sweep8<false>(GA, d0, d1, 8 * g, 8u, tg8, j8, a_bk, rv, ry);
+            GA = GB;
         }
-        if (!sweep_on) asm volatile("" :: "v"(GA.c[0]), "v"(GA.c[7]), "v"(GB.c[0]), "v"(GB.c[7]));
+        if (sweep_on) tile_sweep8<true>(GA, d0, d1, 8 * g, nt - 8 * g, tg8, j8, a_bk, rv, ry);
+        else asm volatile("" :: "v"(GA.c[0]), "v"(GA.c[7]));
     }
 }
 

@@ -481,7 +481,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         }
         // scalarise: the carve and the fit test below must be wave-uniform branches
         const uint32_t N = bcast32(ncarry), Nb = bcast32(bcarry), NT = bcast32(tcarry);
-        const uint32_t NTp = align_up(NT, 8);  // the list is padded to whole groups of eight with tiles that store nothing
 
         // ---- LDS carve, part 2: node arrays, buckets, tile list ---------------------
         // What emit 3a writes (per node: morph id, end position) lies BELOW the match buffer it reads; the buckets (filled by 3b) and the tile list (3c) may
@@ -496,7 +495,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         uint2 *tiles = (uint2 *)(smem + off);                       // the tile list
         if (N > 0xFFFF || Nb + 1 > SLOT_MAX) { defer_s(s); break; }   // (neither fits a pool: 8 bytes per bucket entry)
         // exact requirement: what 3a writes stays below the match buffer; afterwards the buckets and the tile list overlay it
-        const uint32_t need_emit = off_emit_end + mbytes + 16, need_full = off + 8 * NTp;
+        const uint32_t need_emit = off_emit_end + mbytes + 16, need_full = off + 8 * NT;
         if (need_emit > lds_bytes || need_full > lds_bytes) {
             // reservation too small: release, wait (holding nothing) for the exact size, redo
             pool_free(bm, pg, 0, npg, lane);
@@ -597,8 +596,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
                         tiles[k] = make_uint2(tile_desc0(a_node + 8 * (t0 + ta), min(8u, T - ta), min(8u, P - 8 * b), b == 0, b == kb - 1), a_bk + 8 * (p0 + 8 * b));
             }
         }
-        const uint32_t null0 = (a_node + 8 * N) | TILE_FIRST;   // padding: a target group that is never reduced (its gather reads M[BOS's right][0]: always in the matrix)
-        if (lane < NTp - NT) tiles[NT + lane] = make_uint2(null0, a_bk);
+        const uint32_t null0 = (a_node + 8 * N) | TILE_FIRST;   // what the last group gathers for the tiles it does not have: a target group that is never reduced (M[BOS's right][0]: always in the matrix)
         wave_sync();
         KGPU_TICK(5);
         KGPU_STOP(5)
@@ -607,7 +605,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KGPU_POOL_
         // ---- phase 4: stage B over the tile list (kgpu_device.h: tiles_run -- the gather into registers, the sweep; lattice.rs:116-142, connection.rs:12-14) ----
         {
             const uint64_t tg0 = prof ? __builtin_amdgcn_s_memtime() : 0;
-            tiles_run<true>(tiles, 0u, NTp, make_uint2(null0, a_bk), lane, a_bk, (const uint8_t *)d.conn, stop_after != 6);   // (6: ablation timing -- the gathers alone)
+            tiles_run(tiles, 0u, NT, make_uint2(null0, a_bk), lane, a_bk, (const uint8_t *)d.conn, stop_after != 6);   // (6: ablation timing -- the gathers alone)
             if (prof && stop_after == 6) cyc_gather += __builtin_amdgcn_s_memtime() - tg0;
         }
         wave_sync();

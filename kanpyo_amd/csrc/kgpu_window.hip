@@ -795,7 +795,7 @@ __global__ __launch_bounds__(64 * TEAM) __attribute__((amdgpu_waves_per_eu(TEAM 
                     const uint64_t rest = slowmask >> q;
                     const uint32_t qs = rest ? q + (uint32_t)__ffsll((unsigned long long)rest) - 1u : nw;   // the next any-shape position (nw: none)
                     const uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)eb_l, (int)q), tb = (uint32_t)__builtin_amdgcn_readlane((int)eb_l, (int)qs);
-                    if (tb > ta) tiles_run<false>(tiles, ta, tb, null_tile, lane, a_bk, connb, true);
+                    if (tb > ta) tiles_run(tiles, ta, tb, null_tile, lane, a_bk, connb, true);
                     if (qs < nw) {
                         // any shape with streamed (wide) predecessors: SLOWT targets at a time, the lanes split the predecessors -- the bucket's in LDS, then the
                         // FIFO's; costs straight from the matrix (connection.rs:12-14); key = (total, node index): strict '<' over ascending insertion order (lattice.rs:125,136)
