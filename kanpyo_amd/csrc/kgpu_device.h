@@ -419,15 +419,15 @@ __device__ __forceinline__ void tile_sweep8(const TileGroup &G, uint32_t d0, uin
 // A window's groups are gathered one ahead of the sweep: while group g is swept out of one register set the costs of group g + 1 arrive in the other, and
 // are moved over when the sweep is through (eight register moves a group: by then they have long arrived).  Nothing is gathered behind a window's LAST group
 // -- the earlier form alternated the two sets and, to keep the compiler's wait counts exact on every path, gathered "for nothing" behind the end: a third of
-// all gathers on a cfg 2 sentence (~64 tiles in windows of 56: 13 group gathers for 8 groups) -- and only the last group's sweep (code of its own) tests a
+// all gathers on a cfg 2 sentence (~64 tiles in windows of 56, as they were: 13 group gathers for 8 groups) -- and only the last group's sweep (code of its own) tests a
 // tile against the count, so lists need no padding to whole groups.
 __device__ __forceinline__ void tiles_run(const uint2 *tiles, uint32_t ta, uint32_t tb, uint2 null_tile, uint32_t lane, uint32_t a_bk, const uint8_t *connb, bool sweep_on) {
     const uint32_t j8 = 8u * (lane & 7u), tg8 = lane & 0x38u;   // lane = 8 ti + j
     int32_t rv = 0; uint32_t ry = 0;
-    for (uint32_t w0 = ta; w0 < tb; w0 += 56) {       // a window of 56 descriptors (seven groups) in registers, read out with v_readlane; lanes 56..63: padding
-        const uint2 dd = (lane < 56 && w0 + lane < tb) ? tiles[w0 + lane] : null_tile;
+    for (uint32_t w0 = ta; w0 < tb; w0 += 64) {       // a window of 64 descriptors (eight groups) in registers, read out with v_readlane; lanes past the end: the null tile
+        const uint2 dd = w0 + lane < tb ? tiles[w0 + lane] : null_tile;
         const uint32_t d0 = dd.x, d1 = dd.y;
-        const uint32_t nt = min(56u, tb - w0), ng = (nt + 7u) >> 3;
+        const uint32_t nt = min(64u, tb - w0), ng = (nt + 7u) >> 3;
         TileGroup GA, GB;
         tile_gather8(GA, d0, d1, 0u, tg8, j8, connb);
         uint32_t g = 0;

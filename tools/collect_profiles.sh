@@ -17,7 +17,7 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace"
 cp "$REPO/bench_full.json" "$OUT/trace.json"
 cp "$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)" "$OUT/${TAG}_kernel_stats.csv"
 # the same trace per dispatch: k_tokenize_pool by grid size (full 4096-sentence batches, the ragged last batch of a pass, small calls)
-{ echo "# rocprofv3 --kernel-trace of: python bench.py --steps 20 --warmup 5 --no-cpu --no-extras; bench line of the same run: trace.json"; python "$REPO/tools/trace_pool.py" "$(find "$OUT/trace" -name "*kernel_trace.csv" | head -1)"; python - "$OUT/trace.json" <<'PY'
+{ echo "# rocprofv3 --kernel-trace of: python bench.py --steps 20 --warmup 5 --no-cpu --no-extras; bench line of the same run: trace.json"; python "$REPO/tools/trace_pool.py" "$(find "$OUT/trace" -name "*kernel_trace.csv" | head -1)" 480; python - "$OUT/trace.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); r = d["roofline"]
 print(f"bench.py (same run, HIP events): value {d['value']:.0f} sentences/s, avg_kernel_ms {r['avg_kernel_ms']:.4f}, avg_launch_chain_ms {r['avg_launch_chain_ms']:.4f}, launches_timed {r['launches_timed']}")
