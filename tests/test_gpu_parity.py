@@ -152,6 +152,33 @@ def test_edge_cases(full):
     assert_same(tok, orc, ["すもももももももものうち"] * 257)
 
 
+def test_byte_length_and_alignment_boundaries(full):
+    """Every byte length from 0 to 300 at every alignment of its first byte in the batch (the pool kernel takes a sentence of up to ~250 bytes as one aligned
+    dword per lane and byte-aligns it against the next lane's; longer ones byte by byte), sentences of more than 64 tokens (the successor's start position
+    comes from the next lane, the 64th token's from the next round), of 255 / 256 / 257 characters (the start-position search has eight fixed steps up to 255),
+    and lattices of 1 .. ~130 tiles (stage B's windows of 64 descriptors, a last group of 1 .. 8 tiles) -- all against the oracle."""
+    sd, tok, orc = full
+    from kanpyo_amd import synth
+
+    base = [t for t in synth.make_corpus(sd, 400, 5, "cfg3") if len(t) >= 110][:64]   # dictionary words and unknown runs, 110+ characters each
+    assert len(base) == 64
+    sents = []
+    for L in range(0, 301):
+        body = base[L % len(base)]
+        cut = body.encode("utf-8")[: (L // 3) * 3].decode("utf-8", errors="ignore")   # whole characters of the corpus' text ...
+        cut += "a1b"[: L - len(cut.encode("utf-8"))] if len(cut.encode("utf-8")) <= L else ""
+        while len(cut.encode("utf-8")) < L:
+            cut += "z"                                                                   # ... topped up to the byte length with ASCII
+        assert len(cut.encode("utf-8")) == L
+        sents.append(cut)
+    for pad in ("", "x", "xy", "xyz"):                 # shifts every later sentence's first byte through the four alignments
+        assert_same(tok, orc, [pad] + sents)
+    many_tokens = ["あ1" * n for n in (31, 32, 33, 63, 64, 65, 100)] + ["a あ" * 50]
+    chars = ["あ" * n for n in (254, 255, 256, 257)] + ["1a" * 128, "1a" * 127 + "1"]
+    assert_same(tok, orc, many_tokens + chars)
+    assert_same(tok, orc, [base[i][:n] for i, n in enumerate(range(1, 64))])   # 1 .. 63 characters: tile counts around the group and window sizes
+
+
 def test_invalid_utf8_is_flagged_not_tokenized(full):
     from kanpyo_amd import _lib
     from kanpyo_amd.tokenizer import pack_sentences
