@@ -304,9 +304,16 @@ def main():
                 break
     if W > 0:
         job(W)
-    for c in eng.ctxs:
-        if not os.environ.get("BENCH_NO_EVENTS"):
-            c.set_profiling(PROFILE_EVENTS | PROFILE_SAMPLED)  # HIP events around every 4th launch chain, on the stream the kernels run on
+    # HIP events around every 4th launch chain of every context, on the stream the kernels run on (what profiles/r06_kernel_stats.csv is compared with).
+    # The events are not free -- a record is a barrier packet on its stream: over five interleaved runs 124.5-136.6 M sentences/s against 136.9-138.5 with none, and
+    # 136.7-137.8 with the events on two of the eight contexts only (BENCH_EVENT_CTXS=0,5: there the timed launches last 94-98 us instead of 86-88, the chip overlaps
+    # more of them, and the per-launch roofline fraction FALLS while the job's rate rises; profiles/experiments/r06_tile_sweep.txt).  The default stays what the
+    # committed rocprofv3 trace was collected with.
+    ev = os.environ.get("BENCH_EVENT_CTXS", "all")   # (measurement: "all", a list like "0,5", or "" for none)
+    timed_ctxs = set(range(len(eng.ctxs))) if ev == "all" else {int(x) % len(eng.ctxs) for x in ev.split(",") if x.strip()}
+    for i, c in enumerate(eng.ctxs):
+        if i in timed_ctxs and not os.environ.get("BENCH_NO_EVENTS"):
+            c.set_profiling(PROFILE_EVENTS | PROFILE_SAMPLED)
         c.profile(reset=True)
     for k in gathered:
         gathered[k] = 0

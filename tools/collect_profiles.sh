@@ -1,7 +1,8 @@
 #!/bin/bash
 # GPU box: everything profiles/ holds for a round -- the bench line, rocprofv3 kernel-trace stats of the same command, the PMC
 # passes (pool kernel: cfg 2; long-sentence kernel: cfg 5 and cfg 3), per-phase counters.
-# usage: bash tools/collect_profiles.sh <outdir> <round tag, e.g. r02> [pool]      ("pool": the cfg 2 / pool-kernel part only -- about a third of the time)
+# usage: bash tools/collect_profiles.sh <outdir> <round tag, e.g. r02> [pool|headline]      ("pool": the cfg 2 / pool-kernel part only -- about a third of the time;
+#        "headline": the bench line and the kernel trace of the same command only -- when bench.py changed and the library did not: ~4 minutes)
 set -u
 OUT=$(realpath -m "$1"); TAG=$2; PART=${3:-all}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
@@ -23,6 +24,7 @@ d = json.load(open(sys.argv[1])); r = d["roofline"]
 print(f"bench.py (same run, HIP events): value {d['value']:.0f} sentences/s, avg_kernel_ms {r['avg_kernel_ms']:.4f}, avg_launch_chain_ms {r['avg_launch_chain_ms']:.4f}, launches_timed {r['launches_timed']}")
 PY
 } > "$OUT/${TAG}_pool_dispatches.txt"
+if [ "$PART" = headline ]; then rm -rf "$OUT"/trace; echo done; exit 0; fi
 if [ "$PART" = all ]; then
 # cfg 5 through tools/window_timing.py (one 1000-document batch per context): eight contexts = eight launches in flight = the ordinary, one-wavefront-per-document
 # form of the windowed kernel (k_tokenize_window<false, 1>); one context = a lone batch = its team form (<false, 2>).  cfg 3 through tools/bench_cfg.py.

@@ -2,7 +2,9 @@
 """Where the HOST thread's time goes while bench.py's headline job runs (cfg 2, batches of 4096, Q contexts): per batch the wait for the context's
 previous batch (kgpu_ctx_sync), the enqueue itself (kgpu_tokenize_device: the launches) and the Python around them.  If the waits are short the job is
 bound by the submitting thread, not by the GPU.
-usage: python tools/submit_probe.py [steps] [Q]"""
+usage: python tools/submit_probe.py [steps] [Q] [instances]
+instances > 0: instead, the plain job's rate for that many Tokenizer instances made one after the other in this process (each has its own dictionary copy in HBM and its own
+shared streams): does the headline's mode (a run's rate goes with how many launches overlap) belong to the process or to the streams?"""
 import os
 import sys
 import time
@@ -15,10 +17,26 @@ from kanpyo_amd import Tokenizer, _lib, synth
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 Q = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+instances = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 _lib.lib()
 sd = synth.build_dict()
 wl = Workload([synth.make_corpus(sd, N_SENT, seed=1, kind="cfg2")], 0, 1)
 dev = torch.device("cuda", 0)
+if instances > 0:
+    for k in range(instances):
+        tok = Tokenizer(sd.dict, device=0)
+        eng = GpuEngine(tok, dev, wl, queue=Q, streams=0, ring=1)
+        t_end = time.perf_counter() + 0.7
+        while time.perf_counter() < t_end:
+            run_job(eng, 5)
+        rates = []
+        for rep in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            run_job(eng, steps)
+            torch.cuda.synchronize(); rates.append(steps * N_SENT / (time.perf_counter() - t0) / 1e6)
+        print(f"instance {k}: " + " / ".join(f"{r:.1f}" for r in rates) + " M sentences/s")
+        del eng, tok
+    sys.exit(0)
 tok = Tokenizer(sd.dict, device=0)
 eng = GpuEngine(tok, dev, wl, queue=Q, streams=0, ring=1)
 t_end = time.perf_counter() + 1.5
