@@ -304,11 +304,9 @@ def main():
                 break
     if W > 0:
         job(W)
-    # HIP events around every 4th launch chain of every context, on the stream the kernels run on (what profiles/r06_kernel_stats.csv is compared with).
-    # The events are not free -- a record is a barrier packet on its stream: over five interleaved runs 124.5-136.6 M sentences/s against 136.9-138.5 with none, and
-    # 136.7-137.8 with the events on two of the eight contexts only (BENCH_EVENT_CTXS=0,5: there the timed launches last 94-98 us instead of 86-88, the chip overlaps
-    # more of them, and the per-launch roofline fraction FALLS while the job's rate rises; profiles/experiments/r06_tile_sweep.txt).  The default stays what the
-    # committed rocprofv3 trace was collected with.
+    # HIP events around every 4th launch chain of every context, on the stream the kernels run on (what profiles/r06_kernel_stats.csv is compared with).  They are
+    # not free -- a record is a barrier packet on its stream: five interleaved runs 124.5-136.6 M sentences/s against 136.9-138.5 with none and 136.7-137.8 with the
+    # events on two of the eight contexts (BENCH_EVENT_CTXS=0,5: the per-launch fraction FALLS there while the rate rises; profiles/experiments/r06_tile_sweep.txt).
     ev = os.environ.get("BENCH_EVENT_CTXS", "all")   # (measurement: "all", a list like "0,5", or "" for none)
     timed_ctxs = set(range(len(eng.ctxs))) if ev == "all" else {int(x) % len(eng.ctxs) for x in ev.split(",") if x.strip()}
     for i, c in enumerate(eng.ctxs):
@@ -443,7 +441,7 @@ def main():
     if world == 1 and not args.no_stages:
         import bench_extras
 
-        roof["stages"] = bench_extras.measure_stages(eng, torch, (a, b, c_))
+        roof["stages"] = bench_extras.stage_split(eng, tok, dev, corpora, args.queue, torch, (a, b, c_))
         for k, name in (("A", "A_lattice"), ("B", "B_viterbi"), ("C", "C_emit")):
             roof[f"stage_{k}_ms"], roof[f"stage_{k}_frac"] = roof["stages"][name]["ms_per_step"], roof["stages"][name]["frac"]
         try:

@@ -276,10 +276,11 @@ def run_single_process(args):
 
 # ------------------------------------------------------------------ legs of the N = 1 run (each returns a dict for bench_full.json)
 
-def measure_stages(eng, torch, stage_bytes):
+def measure_stages(eng, torch, stage_bytes, steps=3):
     """Per-stage roofline: the same pipeline with every sentence stopped after a stage (kgpu_ctx_set_ablation, measurement-only mode of the runtime);
-    a stage's time is the difference of consecutive stop levels at full occupancy.  Five interleaved repetitions of three steps per level, the FASTEST
-    counts: a stopped chain is a 40 us kernel per batch, so a level's time is easily the host's launch rate or one scheduling hiccup instead of the GPU's.
+    a stage's time is the difference of consecutive stop levels at full occupancy.  Five interleaved repetitions of `steps` steps per level, the FASTEST
+    counts: a stopped chain is a 25-40 us kernel per 4096-sentence batch, so a level's time is easily the host's launch rate (15-20 us per batch) or one
+    scheduling hiccup instead of the GPU's -- bench.py therefore hands over an engine with batches of 16 384 (a quarter of the launches per step).
     stage_bytes: (A, B, C) algorithmic bytes per step.  B_viterbi = connection-cost gather + sweep."""
     from kanpyo_amd.device import STAGE_ALL, STAGE_LATTICE, STAGE_VITERBI
 
@@ -291,8 +292,8 @@ def measure_stages(eng, torch, stage_bytes):
             run_job(eng, 1)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            run_job(eng, 3)
-            runs[name].append((time.perf_counter() - t1) / 3 * 1e3)
+            run_job(eng, steps)
+            runs[name].append((time.perf_counter() - t1) / steps * 1e3)
     for c in eng.ctxs:
         c.set_ablation(STAGE_ALL)
     ms = {k: min(v) for k, v in runs.items()}
@@ -306,6 +307,25 @@ def measure_stages(eng, torch, stage_bytes):
 
     out = {k: line(k) for k in sb}
     out["level_ms_per_step_runs"] = {k: [round(x, 4) for x in v] for k, v in runs.items()}
+    return out
+
+
+def stage_split(eng, tok, dev, corpora, queue, torch, stage_bytes):
+    """measure_stages over an engine of its own with batches of 16 384: in batches of 4096 the level that stops after the lattice is a 25 us kernel per batch
+    against the submitting thread's 15-20 us per batch -- partly the host's rate, and stage B, a difference, came out at 0.21-0.36 ms by the box's CPU
+    (profiles/experiments/r06_tile_sweep.txt).  If that engine cannot be made the headline's own (batches of 4096) is used: the split never breaks the line."""
+    eng_s = None
+    try:
+        eng_s = GpuEngine(tok, dev, Workload(corpora[:1], 0, 1, batch=4 * BATCH), queue=queue, streams=0, ring=1)
+        run_job(eng_s, 4)
+        out = measure_stages(eng_s, torch, stage_bytes, steps=8)
+        out["batch"] = 4 * BATCH
+    except Exception as e:
+        print(f"stage split in batches of {4 * BATCH} failed ({e}): batches of {BATCH}", file=sys.stderr)
+        out = measure_stages(eng, torch, stage_bytes)
+        out["batch"] = BATCH
+    if eng_s is not None:
+        eng_s.close()
     return out
 
 
